@@ -1,0 +1,119 @@
+/* vvae_hip.h -- C ABI of libvvae_hip.so: the MI355X (gfx950) kernels of the video-VAE hot path.
+ *
+ * The reference (floatingtrees/video-VAE) has no native code and no FFI: every op below replaces an
+ * XLA-lowered Flax/JAX call.  Each entry point cites the reference call site it stands in for
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the Python-side binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every buffer is BORROWED device memory owned by the caller;
+ *   - activations are channels-last (n,t,h,w,c) seen as rows of `C` channels with row pitch `ld*`
+ *     (in elements, >= C), so a channel slice of a wider buffer is a valid operand;
+ *   - `dtype`: VVAE_DT_F32 (0) or VVAE_DT_BF16 (1) is the STORAGE type of activations; parameters and
+ *     parameter gradients are always fp32 in Flax layout (Conv kernel (kt,kh,kw,Cin,Cout));
+ *   - `stream` is a hipStream_t; everything is enqueued asynchronously on it, nothing synchronises;
+ *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
+ *   - no global mutable state except the vvae_conv3d_force_generic test hook.
+ */
+#ifndef VVAE_HIP_H
+#define VVAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VVAE_DT_F32 0
+#define VVAE_DT_BF16 1
+#define VVAE_ERR_BAD_ARG 1001
+#define VVAE_ERR_WORKSPACE 1002
+
+/* ---- Conv3d, SAME padding, stride 1, odd kernel: nnx.Conv at train/unet.py:13-21 (3x3x3 ConvBlock3D),
+ *      :111-113 (3x7x7 patch_mixer), :144-153 (1x1x1 final_conv) and their autodiff (dgrad, wgrad). ---- */
+size_t vvae_conv3d_workspace_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                                   int which /* 0 fwd, 1 dgrad, 2 wgrad */);
+int vvae_conv3d_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                    int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                    void* ws, size_t ws_bytes, void* stream);
+int vvae_conv3d_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx,
+                      int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                      void* ws, size_t ws_bytes, void* stream);
+int vvae_conv3d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
+                      int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                      void* ws, size_t ws_bytes, void* stream);
+void vvae_conv3d_force_generic(int on);   /* test hook: 1 = bypass the bf16 fast path */
+/* the any-shape fp32-matrix-core path, exported so tests can cross-check the fast path against it */
+int vvae_conv3d_fwd_generic(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                            int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
+int vvae_conv3d_dgrad_generic(const void* dy, int lddy, const float* w, void* dx, int lddx,
+                              int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
+int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
+                              int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
+int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out, int which, int flags);
+size_t vvae_conv3d_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int which);
+int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                         int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
+                         void* ws, size_t ws_bytes, void* stream);
+int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
+                           int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                           void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum over V rows of x[v][c] (bias gradients) */
+int vvae_colsum(const void* x, int ld, long V, int C, float* out, int dtype, void* stream);
+
+/* ---- GroupNorm(G, eps) + SiLU: nnx.GroupNorm + nnx.silu at train/unet.py:22-23,28-29.
+ *      sums: fp64 [N][G][2] (sum, sum of squares) produced by vvae_gn_stats; S = voxels per sample. ---- */
+int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, int dtype, void* stream);
+int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const double* sums, const float* gamma, const float* beta,
+                     int N, long S, int C, int G, float eps, int dtype, void* stream);
+int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const double* sums,
+                     const float* gamma, const float* beta, double* csum /* fp64 [N][C][2] scratch */,
+                     float* dgamma, float* dbeta, int N, long S, int C, int G, float eps, int dtype, void* stream);
+
+/* ---- max-pool (1,2,2)/(1,2,2): nnx.max_pool at train/unet.py:50.  NT = n*t planes; H, W = input size.
+ *      bwd: dx = (dskip ? dskip : 0) + scatter(dpool) to the first arg-max of each window. ---- */
+int vvae_maxpool_1x2x2_fwd(const void* x, int ldx, void* y, int ldy, int NT, int H, int W, int C, int dtype, void* stream);
+int vvae_maxpool_1x2x2_bwd(const void* x, int ldx, const void* dpool, int lddp, const void* dskip, int ldds,
+                           void* dx, int lddx, int NT, int H, int W, int C, int dtype, void* stream);
+
+/* ---- ConvTranspose kernel (1,2,2) strides (1,2,2): nnx.ConvTranspose at train/unet.py:61-69,78.
+ *      out[2i+d] = x[i] * K[1-d] per spatial axis (kernel NOT flipped).  H, W = input (low) resolution. ---- */
+int vvae_convt_1x2x2_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                         int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int vvae_convt_1x2x2_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx,
+                           int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int vvae_convt_1x2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw,
+                           int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* ---- temporal attention core: q_norm/k_norm + RoPE + masked softmax(QK^T/sqrt(D))V,
+ *      train/layers.py:159-170 (called from FactoredAttention, layers.py:212-213).
+ *      qkv (A,T,3*heads*D) pitch ld; mask uint8 (ceil(A/mask_div), T) 1 = attend, or NULL. ---- */
+int vvae_temporal_attn_fwd(const void* qkv, int ld, void* out, int ldo, const float* q_scale, const float* k_scale,
+                           const float* cos_table, const float* sin_table, const uint8_t* mask, int mask_div,
+                           int A, int T, int heads, int D, float eps, int dtype, void* stream);
+int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, void* dqkv, int lddq,
+                           const float* q_scale, const float* k_scale, const float* cos_table, const float* sin_table,
+                           const uint8_t* mask, int mask_div, float* dq_scale, float* dk_scale,
+                           int A, int T, int heads, int D, float eps, int dtype, void* stream);
+
+/* ---- reparameterise + KL: train/model.py:124-128, train/rl_nonadversarial.py:146-147. ---- */
+int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, const float* mask, float* z, float* kl,
+                        int B, int T, long per, int dtype, void* stream);
+int vvae_reparam_kl_bwd(const void* mean, const void* logvar, const float* eps, const float* mask, const float* dz,
+                        const float* gkl, void* dmean, void* dlogvar, int B, int T, long per, int dtype, void* stream);
+
+/* ---- masked MSE / MAE: train/rl_nonadversarial.py:114-121.  video sample = b / video_div (pair doubling). ---- */
+int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* mask, float* mse, float* mae,
+                            int B, int T, long P, int video_div, int dtype, void* stream);
+int vvae_masked_mse_mae_bwd(const void* video, const void* recon, const float* mask, const float* gmse, const float* gmae,
+                            void* drecon, int B, int T, long P, int video_div, int dtype, void* stream);
+
+/* ---- optimiser: optax.chain(clip_by_global_norm, adam) at train/rl_nonadversarial.py:248-251. ---- */
+int vvae_sqnorm_accum(const float* g, long n, double* out, void* stream);
+int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_sq,
+                        float gscale, float max_norm, float lr, float b1, float b2, float eps, long count, void* stream);
+int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VVAE_HIP_H */

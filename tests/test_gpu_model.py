@@ -1,0 +1,187 @@
+"""GPU parity of the assembled path: UNet, VideoVAE (both flavours), losses, optimiser step -- HIP vs CPU oracle."""
+import copy
+
+import pytest
+import torch
+
+from oracle import unet as OU
+from oracle import model as OM
+from oracle import loss as OLoss
+from oracle import optim as OOpt
+from util import assert_close, assert_close_scaled, rnd
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(height=32, width=32, channels=3, patch_size=8, encoder_depth=1, decoder_depth=1, mlp_dim=64, num_heads=4,
+            qkv_features=32, max_temporal_len=8, spatial_compression_rate=4, unembedding_upsample_rate=4)
+
+
+def _load(module, params, dev):
+    sd = module.state_dict()
+    assert set(sd) == set(params), (set(sd) ^ set(params))
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(v)
+    return module.to(dev)
+
+
+@pytest.mark.parametrize("shape,levels,base", [((1, 8, 64, 64, 12), 3, 16), ((2, 3, 16, 24, 5), 2, 8)])
+def test_unet_fwd_bwd_fp32(dev, shape, levels, base):
+    """Config C1-sized UNet (B=1, 3x8x64x64 features) fp32: output and every parameter gradient vs the oracle."""
+    import video_vae_amd as V
+    c = shape[-1]
+    p = OU.init_unet(c, base, levels, 3, seed=5, zero_final=False)
+    for k in p:
+        if k.endswith("bias") or k.endswith("scale"):
+            p[k] = p[k] + 0.1 * rnd(p[k].shape, hash(k) % 1000)
+    x = rnd(shape, 40, 0.5)
+    gy = rnd(shape[:-1] + (3,), 41)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = OU.unet(po, xo)
+    yo.backward(gy)
+    m = _load(V.UNet(c, base, levels, 3, V.Rngs(0), dtype=torch.float32), p, dev)
+    xg = x.to(dev).requires_grad_(True)
+    yg = m(xg)
+    yg.backward(gy.to(dev))
+    assert_close(yg, yo, what="unet out")
+    assert_close_scaled(xg.grad, xo.grad, rel=2e-3, what="dx")
+    for k, prm in m.named_parameters():
+        assert_close_scaled(prm.grad, po[k].grad, rel=2e-3, what=f"d{k}")
+
+
+def test_unet_bf16_close_to_emulated_oracle(dev):
+    import video_vae_amd as V
+    p = OU.init_unet(12, 16, 2, 3, seed=6, zero_final=False)
+    x = rnd((1, 4, 32, 32, 12), 42, 0.5)
+    yo = OU.unet(p, x, torch.bfloat16)
+    m = _load(V.UNet(12, 16, 2, 3, V.Rngs(0), dtype=torch.bfloat16), p, dev)
+    yg = m(x.to(dev))
+    assert yg.dtype == torch.bfloat16
+    assert_close(yg, yo, rtol=5e-2, atol=5e-2 * float(yo.abs().max()), what="bf16 unet")
+
+
+def _noise(cfg, b, t, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"gumbel_u": torch.rand((b, t, 1), generator=g),
+            "reparam_eps": torch.randn((b, t, cfg.hw, cfg.latent_dim), generator=g),
+            "bernoulli_u": torch.rand((2 * b, t, 1, 1), generator=g)}
+
+
+@pytest.mark.parametrize("flavour", ["model", "rl"])
+def test_video_vae_loss_and_grads_fp32(dev, flavour):
+    """Full tiny VAE (32x32, patch 8, depth 1): forward tuple, loss terms and all gradients vs the oracle."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, rl_model
+    cfg = OM.VAEConfig(**TINY)
+    p = OM.init_video_vae(cfg, seed=3, zero_final=False)
+    b, t = 2, 8
+    video = torch.rand((b, t, 32, 32, 3), generator=torch.Generator().manual_seed(0))
+    mask = torch.ones(b, t); mask[1, 6:] = 0
+    noise = _noise(cfg, b, t, 7)
+    emask = OLoss.expand_mask(mask.bool(), cfg.hw)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    if flavour == "model":
+        out_o = OM.video_vae(po, cfg, video, emask, noise)
+        loss_o, aux_o = OLoss.loss_fn_plain(out_o, video, mask)
+        cls = V.VideoVAE
+    else:
+        out_o = OM.video_vae_rl(po, cfg, video, emask, noise)
+        loss_o, aux_o = OLoss.loss_fn_rl(out_o, video, mask)
+        cls = rl_model.VideoVAE
+    loss_o.backward()
+    m = _load(cls(rngs=V.Rngs(2), dtype=torch.float32, **TINY), p, dev)
+    rngs = V.Rngs(3)
+    for k, v in noise.items():
+        rngs.inject(k, v)
+    vg, mg = video.to(dev), mask.to(dev)
+    em = L.expand_mask(mg.bool(), cfg.hw)
+    if flavour == "model":
+        loss_g, aux_g = L.loss_fn_plain(m, vg, em, mg, rngs, L.HPARAMS)
+    else:
+        loss_g, aux_g = L.loss_fn(m, vg, em, mg, rngs, L.HPARAMS)
+    loss_g.backward()
+    assert_close(aux_g["reconstruction"], aux_o["reconstruction"], what="reconstruction")
+    for k in aux_o:
+        if k != "reconstruction":
+            assert_close(aux_g[k], aux_o[k], rtol=1e-3, atol=1e-5, what=k)
+    assert_close(loss_g, loss_o, rtol=1e-3, atol=1e-5, what="loss")
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None, k
+        assert torch.isfinite(prm.grad).all(), k
+        assert_close_scaled(prm.grad, po[k].grad, rel=5e-3, what=f"d{k}")
+
+
+def test_rl_outputs_contract(dev):
+    """Reference shape/binary contracts (claude_distributed/test_rl_model.py:132-136)."""
+    import video_vae_amd as V
+    from video_vae_amd import rl_model, loss as L
+    m = rl_model.VideoVAE(rngs=V.Rngs(2), dtype=torch.float32, **TINY).to(dev)
+    b, t = 2, 8
+    video = torch.rand((b, t, 32, 32, 3), device=dev)
+    em = L.expand_mask(torch.ones(b, t, device=dev).bool(), 16)
+    recon, comp, sel, sel_mask, lv, mean = m(video, em, V.Rngs(1))
+    assert recon.shape == (2 * b, t, 32, 32, 3) and comp.shape == (2 * b, t, 16, 48)
+    assert sel.shape == (2 * b, t, 1, 1) and sel_mask.shape == (2 * b, t, 1, 1)
+    assert set(sel_mask.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_optimizer_steps_match_oracle(dev):
+    """clip_by_global_norm + adam + warmup-cosine over 3 updates vs the optax restatement."""
+    import video_vae_amd as V
+    from video_vae_amd import optim
+    m = V.UNet(4, 8, 1, 3, V.Rngs(1), dtype=torch.float32)
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(dev)
+    kw = dict(init_value=0.0, peak_value=1e-2, warmup_steps=2, decay_steps=10, end_value=1e-3)
+    opt = optim.Optimizer(m, optim.warmup_cosine_decay_schedule(**kw), max_norm=1.0)
+    adam = OOpt.Adam(p0)
+    po = p0
+    for step in range(3):
+        grads = {k: rnd(v.shape, 100 + step * 31 + i, 0.3 if step else 5.0) for i, (k, v) in enumerate(p0.items())}
+        opt.zero_grad()
+        for k, prm in m.named_parameters():
+            prm.grad.copy_(grads[k].to(dev))
+        opt.update()
+        po, gn, lr = OOpt.train_update(po, grads, adam, kw)
+        assert abs(opt.grad_norm() - float(gn)) <= 1e-4 * float(gn)
+        for k, prm in m.named_parameters():
+            assert_close(prm, po[k], rtol=1e-4, atol=1e-6, what=f"step{step} {k}")
+
+
+def test_loss_decreases_on_fixed_batch(dev):
+    """Reference integration property (claude_distributed/test_training_loop.py:168-178): 10 steps, lr 1e-3."""
+    import video_vae_amd as V
+    from video_vae_amd import optim, loss as L, rl_model
+    m = rl_model.VideoVAE(rngs=V.Rngs(2), dtype=torch.float32, **TINY).to(dev)
+    opt = optim.Optimizer(m, 1e-3)
+    video = torch.rand((2, 8, 32, 32, 3), device=dev); mask = torch.ones(2, 8, device=dev)
+    rngs = V.Rngs(3)
+    losses = []
+    for _ in range(10):
+        loss, aux = L.train_step(m, opt, video, mask, L.HPARAMS, 16, rngs)
+        assert torch.isfinite(loss)
+        losses.append(float(aux["MSE"]))
+    assert sum(losses[5:]) / 5 < sum(losses[:5]) / 5, losses
+
+
+def test_checkpoint_roundtrip(dev, tmp_path):
+    import video_vae_amd as V
+    from video_vae_amd import optim
+    m = V.UNet(4, 8, 1, 3, V.Rngs(1), dtype=torch.float32).to(dev)
+    opt = optim.Optimizer(m, 1e-2)
+    x = torch.randn(1, 2, 8, 8, 4, device=dev)
+    for _ in range(2):
+        opt.zero_grad(); m(x).square().mean().backward(); opt.update()
+    V.save_checkpoint(m, opt, str(tmp_path / "ck"))
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = V.UNet(4, 8, 1, 3, V.Rngs(9), dtype=torch.float32).to(dev)
+    opt2 = optim.Optimizer(m2, 1e-2)
+    assert V.load_checkpoint(m2, opt2, str(tmp_path / "ck")) is None
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    assert opt2.count == opt.count and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    opt.zero_grad(); m(x).square().mean().backward(); opt.update()
+    opt2.zero_grad(); m2(x).square().mean().backward(); opt2.update()
+    # wgrad accumulates with fp32 atomics: replicas agree to rounding, not bitwise
+    assert torch.allclose(opt.p, opt2.p, rtol=1e-4, atol=1e-6)

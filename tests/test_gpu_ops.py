@@ -1,0 +1,267 @@
+"""GPU parity: every HIP op (through the C ABI via video_vae_amd.ops) against the CPU oracle, same seeded inputs.
+
+fp32 bar: rtol 1e-3 / atol 1e-4 (BASELINE.json:north_star).  bf16 storage: the oracle is run with dtype=bf16
+emulation and compared at bf16 resolution (rtol 2e-2, atol scaled).
+"""
+import pytest
+import torch
+
+from oracle import nn as O
+from oracle import layers as OL
+from oracle import loss as OLoss
+from util import assert_close, assert_close_scaled, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from video_vae_amd import ops
+    return ops
+
+
+CONV_CASES = [
+    # n, t, h, w, cin, cout, kt, kh, kw
+    (1, 4, 8, 8, 5, 7, 3, 3, 3),
+    (2, 3, 6, 10, 12, 12, 3, 7, 7),
+    (1, 2, 4, 4, 16, 3, 1, 1, 1),
+    (1, 3, 9, 7, 16, 16, 3, 3, 3),
+    (2, 2, 8, 8, 32, 16, 3, 3, 3),
+    (1, 1, 5, 5, 4, 20, 1, 3, 3),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_fwd_bwd(dev, case, dtype):
+    ops = _ops()
+    n, t, h, w, ci, co, kt, kh, kw = case
+    x = rnd((n, t, h, w, ci), 1)
+    k = rnd((kt, kh, kw, ci, co), 2, (kt * kh * kw * ci) ** -0.5)
+    b = rnd((co,), 3, 0.1)
+    gy = rnd((n, t, h, w, co), 4)
+    od = dtype
+    xq = x.to(dtype).float()
+    xo = xq.clone().requires_grad_(True); ko = k.clone().requires_grad_(True); bo = b.clone().requires_grad_(True)
+    yo = O.conv3d_same(xo, ko, bo, od)
+    yo.backward(gy.to(dtype).float())
+    xg = xq.to(dev, dtype).requires_grad_(True); kg = k.to(dev).requires_grad_(True); bg = b.to(dev).requires_grad_(True)
+    yg = ops.conv3d(xg, kg, bg)
+    yg.backward(gy.to(dev, dtype))
+    if dtype == torch.float32:
+        assert_close(yg, yo, what="y")
+        assert_close_scaled(xg.grad, xo.grad, what="dx")
+        assert_close_scaled(kg.grad, ko.grad, what="dw")
+        assert_close_scaled(bg.grad, bo.grad, what="db")
+    else:
+        assert_close(yg, yo, rtol=2e-2, atol=2e-2, what="y")
+        assert_close_scaled(xg.grad, xo.grad, rel=2e-2, what="dx")
+        assert_close_scaled(kg.grad, ko.grad, rel=2e-2, what="dw")
+        assert_close_scaled(bg.grad, bo.grad, rel=2e-2, what="db")
+
+
+def test_conv3d_channel_slice_operands(dev):
+    """Operands that are channel slices of wider buffers (row pitch > C): the concat-elision case."""
+    ops = _ops()
+    x = rnd((1, 2, 6, 6, 24), 5)
+    k = rnd((3, 3, 3, 8, 16), 6, 0.1)
+    xs = x[..., 8:16]
+    want = O.conv3d_same(xs, k, None)
+    xg = x.to(dev)
+    out = torch.zeros((1, 2, 6, 6, 40), device=dev)
+    got = ops.conv3d_fwd_raw(xg[..., 8:16], k.to(dev), None, out=out[..., 16:32])
+    assert got.data_ptr() == out[..., 16:32].data_ptr()
+    assert_close(out[..., 16:32], want, what="sliced y")
+    assert float(out[..., :16].abs().max()) == 0 and float(out[..., 32:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape,groups", [((2, 3, 6, 6, 16), 8), ((1, 2, 4, 4, 12), 4), ((2, 2, 4, 6, 128), 8), ((1, 4, 8, 8, 3), 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_group_norm_silu(dev, shape, groups, dtype):
+    ops = _ops()
+    c = shape[-1]
+    x = (rnd(shape, 7) * 1.5 + 0.3).to(dtype).float()
+    sc = 1 + 0.2 * rnd((c,), 8); bi = 0.1 * rnd((c,), 9)
+    gy = rnd(shape, 10).to(dtype).float()
+    xo = x.clone().requires_grad_(True); so = sc.clone().requires_grad_(True); bo = bi.clone().requires_grad_(True)
+    yo = O.silu(O.group_norm(xo, so, bo, groups, dtype), dtype)
+    yo.backward(gy)
+    xg = x.to(dev, dtype).requires_grad_(True); sg = sc.to(dev).requires_grad_(True); bg = bi.to(dev).requires_grad_(True)
+    yg = ops.group_norm_silu(xg, sg, bg, groups, 1e-6)
+    yg.backward(gy.to(dev, dtype))
+    if dtype == torch.float32:
+        assert_close(yg, yo, what="y")
+        assert_close_scaled(xg.grad, xo.grad, what="dx")
+        assert_close_scaled(sg.grad, so.grad, what="dscale")
+        assert_close_scaled(bg.grad, bo.grad, what="dbias")
+    else:
+        assert_close(yg, yo, rtol=2e-2, atol=2e-2, what="y")
+        assert_close_scaled(xg.grad, xo.grad, rel=3e-2, what="dx")
+        assert_close_scaled(sg.grad, so.grad, rel=3e-2, what="dscale")
+        assert_close_scaled(bg.grad, bo.grad, rel=3e-2, what="dbias")
+
+
+def test_group_norm_stats_span_time(dev):
+    """GroupNorm statistics span (t,h,w): changing frame k must change the normalised output of frame j != k."""
+    ops = _ops()
+    x = rnd((1, 4, 4, 4, 8), 11).to(dev)
+    sc = torch.ones(8, device=dev); bi = torch.zeros(8, device=dev)
+    y0 = ops.group_norm_silu(x, sc, bi, 8)
+    x2 = x.clone(); x2[:, 3] += 5.0
+    y1 = ops.group_norm_silu(x2, sc, bi, 8)
+    assert float((y0[:, 0] - y1[:, 0]).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c", [16, 6])
+def test_max_pool(dev, dtype, c):
+    ops = _ops()
+    x = rnd((2, 3, 8, 6, c), 12).to(dtype).float()
+    gy = rnd((2, 3, 4, 3, c), 13).to(dtype).float()
+    xo = x.clone().requires_grad_(True)
+    yo = O.max_pool_1x2x2(xo)
+    yo.backward(gy)
+    xg = x.to(dev, dtype).requires_grad_(True)
+    yg = ops.max_pool_1x2x2(xg)
+    yg.backward(gy.to(dev, dtype))
+    assert torch.equal(yg.float().cpu(), yo.detach())
+    assert torch.equal(xg.grad.float().cpu(), xo.grad)
+
+
+def test_max_pool_ties_first_wins(dev):
+    ops = _ops()
+    x = torch.ones((1, 1, 2, 2, 8), device=dev, requires_grad=True)
+    ops.max_pool_1x2x2(x).sum().backward()
+    want = torch.zeros(1, 1, 2, 2, 8); want[0, 0, 0, 0] = 1
+    assert torch.equal(x.grad.cpu(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ci,co", [(32, 16), (5, 9), (128, 64)])
+def test_conv_transpose(dev, dtype, ci, co):
+    ops = _ops()
+    x = rnd((2, 2, 3, 5, ci), 14).to(dtype).float()
+    k = rnd((1, 2, 2, ci, co), 15, (4 * ci) ** -0.5); b = rnd((co,), 16, 0.1)
+    gy = rnd((2, 2, 6, 10, co), 17).to(dtype).float()
+    xo = x.clone().requires_grad_(True); ko = k.clone().requires_grad_(True); bo = b.clone().requires_grad_(True)
+    yo = O.conv_transpose_1x2x2(xo, ko, bo, dtype)
+    yo.backward(gy)
+    xg = x.to(dev, dtype).requires_grad_(True); kg = k.to(dev).requires_grad_(True); bg = b.to(dev).requires_grad_(True)
+    yg = ops.conv_transpose_1x2x2(xg, kg, bg)
+    yg.backward(gy.to(dev, dtype))
+    r = 1e-3 if dtype == torch.float32 else 2e-2
+    assert_close(yg, yo, rtol=r, atol=(1e-4 if dtype == torch.float32 else 2e-2), what="y")
+    assert_close_scaled(xg.grad, xo.grad, rel=r, what="dx")
+    assert_close_scaled(kg.grad, ko.grad, rel=r, what="dw")
+    assert_close_scaled(bg.grad, bo.grad, rel=r, what="db")
+
+
+def test_conv_transpose_disjoint_blocks(dev):
+    """Each input voxel maps to a disjoint 2x2 output block: a one-hot input lights exactly 4 output voxels."""
+    ops = _ops()
+    x = torch.zeros((1, 1, 3, 3, 4), device=dev); x[0, 0, 1, 2, :] = 1
+    k = rnd((1, 2, 2, 4, 4), 18).to(dev)
+    y = ops.conv_transpose_1x2x2(x, k, torch.zeros(4, device=dev))
+    nz = (y.abs().sum(-1) > 0).nonzero().cpu().tolist()
+    assert sorted(map(tuple, nz)) == [(0, 0, 2, 4), (0, 0, 2, 5), (0, 0, 3, 4), (0, 0, 3, 5)]
+
+
+def _attn_ref(qkv, qs, ks, mask, heads, max_len, dtype):
+    a, t, c3 = qkv.shape
+    q, k, v = torch.chunk(qkv, 3, dim=-1)
+    sp = lambda z: z.reshape(a, t, heads, -1)
+    q, k, v = sp(q), sp(k), sp(v)
+    q = O.layer_norm(q, qs, None, dtype); k = O.layer_norm(k, ks, None, dtype)
+    cos, sin = OL.rope_tables(q.shape[-1], max_len)
+    q, k = OL.rope(q, k, cos, sin, dtype)
+    return OL.dot_product_attention(q, k, v, mask, dtype).reshape(a, t, -1)
+
+
+@pytest.mark.parametrize("a,t,heads,d", [(6, 16, 8, 64), (5, 5, 4, 32), (3, 32, 2, 64), (2, 64, 1, 64), (4, 7, 2, 16)])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_temporal_attention_core(dev, a, t, heads, d, masked, dtype):
+    ops = _ops()
+    qkv = rnd((a, t, 3 * heads * d), 19).to(dtype).float()
+    qs = 1 + 0.2 * rnd((d,), 20); ks = 1 + 0.2 * rnd((d,), 21)
+    go = rnd((a, t, heads * d), 22).to(dtype).float()
+    mask = None
+    if masked:
+        lens = torch.tensor([max(1, t - (i * 3) % t) for i in range(a)])
+        mask = (torch.arange(t)[None, :] < lens[:, None]).reshape(a, 1, 1, t)
+    cos, sin = OL.rope_tables(d, 64)
+    xo = qkv.clone().requires_grad_(True); qso = qs.clone().requires_grad_(True); kso = ks.clone().requires_grad_(True)
+    yo = _attn_ref(xo, qso, kso, mask, heads, 64, dtype)
+    yo.backward(go)
+    xg = qkv.to(dev, dtype).requires_grad_(True); qsg = qs.to(dev).requires_grad_(True); ksg = ks.to(dev).requires_grad_(True)
+    m8 = mask.reshape(a, t).to(torch.uint8).to(dev) if masked else None
+    yg = ops.temporal_attention_core(xg, qsg, ksg, cos.to(dev), sin.to(dev), m8, 1, heads)
+    yg.backward(go.to(dev, dtype))
+    if dtype == torch.float32:
+        assert_close(yg, yo, what="out")
+        assert_close_scaled(xg.grad, xo.grad, what="dqkv")
+        assert_close_scaled(qsg.grad, qso.grad, what="dq_scale")
+        assert_close_scaled(ksg.grad, kso.grad, what="dk_scale")
+    else:
+        assert_close(yg, yo, rtol=3e-2, atol=3e-2, what="out")
+        assert_close_scaled(xg.grad, xo.grad, rel=5e-2, what="dqkv")
+
+
+def test_temporal_attention_masked_equals_truncated(dev):
+    """Reference property (train/scratch.py:46-57): keys >= L masked  ==  attention over the first L frames."""
+    ops = _ops()
+    a, t, heads, d, L = 4, 32, 2, 64, 10
+    qkv = rnd((a, t, 3 * heads * d), 23).to(dev)
+    qs = torch.ones(d, device=dev); ks = torch.ones(d, device=dev)
+    cos, sin = OL.rope_tables(d, 64)
+    cos, sin = cos.to(dev), sin.to(dev)
+    m8 = (torch.arange(t) < L).to(torch.uint8)[None].repeat(a, 1).to(dev)
+    full = ops.temporal_attention_core(qkv, qs, ks, cos, sin, m8, 1, heads)
+    trunc = ops.temporal_attention_core(qkv[:, :L].contiguous(), qs, ks, cos, sin, None, 1, heads)
+    assert_close(full[:, :L], trunc, what="masked vs truncated")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reparam_kl(dev, dtype):
+    ops = _ops()
+    b, t, hw, c = 3, 6, 4, 24
+    mean = rnd((b, t, hw, c), 24).to(dtype).float(); lv = (0.5 * rnd((b, t, hw, c), 25) - 1).to(dtype).float()
+    eps = rnd((b, t, hw, c), 26)
+    mask = torch.ones(b, t); mask[1, 4:] = 0; mask[2, 1:] = 0
+    gz = rnd((b, t, hw, c), 27); gk = rnd((b,), 28)
+    mo = mean.clone().requires_grad_(True); lo = lv.clone().requires_grad_(True)
+    zo = mo + eps * torch.exp(lo / 2)
+    klo = OLoss.kl_per_sample(mo, lo, mask)
+    (zo * gz).sum().add((klo * gk).sum()).backward()
+    mg = mean.to(dev, dtype).requires_grad_(True); lg = lv.to(dev, dtype).requires_grad_(True)
+    zg, klg = ops.reparameterise_kl(mg, lg, eps.to(dev), mask.to(dev))
+    ((zg * gz.to(dev)).sum() + (klg * gk.to(dev)).sum()).backward()
+    r = 1e-3 if dtype == torch.float32 else 2e-2
+    assert_close(zg, zo, rtol=r, atol=1e-4, what="z")
+    assert_close(klg, klo, rtol=r, atol=1e-5, what="kl")
+    assert_close_scaled(mg.grad, mo.grad, rel=r, what="dmean")
+    assert_close_scaled(lg.grad, lo.grad, rel=r, what="dlogvar")
+    # the two single-output forms
+    z2 = ops.reparameterise(mg.detach(), lg.detach(), eps.to(dev))
+    k2 = ops.kl_per_sample(mg.detach(), lg.detach(), mask.to(dev))
+    assert_close(z2, zo, rtol=r, atol=1e-4); assert_close(k2, klo, rtol=r, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("div", [1, 2])
+def test_masked_mse_mae(dev, dtype, div):
+    ops = _ops()
+    b, t, h, w, c = 4, 5, 6, 6, 3
+    video = torch.rand((b // div, t, h, w, c), generator=torch.Generator().manual_seed(29)).to(dtype).float()
+    recon = (video.repeat_interleave(div, 0) + 0.3 * rnd((b, t, h, w, c), 30)).to(dtype).float()
+    mask = torch.ones(b, t); mask[1, 3:] = 0; mask[3, 1:] = 0
+    g2 = rnd((b,), 31); g1 = rnd((b,), 32)
+    ro = recon.clone().requires_grad_(True)
+    mse_o, mae_o = OLoss.masked_mse_mae(video.repeat_interleave(div, 0), ro, mask)
+    ((mse_o * g2).sum() + (mae_o * g1).sum()).backward()
+    rg = recon.to(dev, dtype).requires_grad_(True)
+    mse_g, mae_g = ops.masked_mse_mae(video.to(dev, dtype), rg, mask.to(dev), div)
+    ((mse_g * g2.to(dev)).sum() + (mae_g * g1.to(dev)).sum()).backward()
+    r = 1e-3 if dtype == torch.float32 else 2e-2
+    assert_close(mse_g, mse_o, rtol=r, atol=1e-6, what="mse")
+    assert_close(mae_g, mae_o, rtol=r, atol=1e-6, what="mae")
+    assert_close_scaled(rg.grad, ro.grad, rel=r, what="drecon")

@@ -1,0 +1,55 @@
+// Public Conv3d entry points: pick the bf16 MFMA fast path when the shape qualifies, else the generic fp32-MFMA path.
+#include "common.hpp"
+
+extern "C" {
+int vvae_conv3d_fwd_generic(const void*, int, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*);
+int vvae_conv3d_dgrad_generic(const void*, int, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*);
+int vvae_conv3d_wgrad_generic(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, int, void*);
+int vvae_conv3d_fwd_bf16(const void*, int, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
+int vvae_conv3d_wgrad_bf16(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
+size_t vvae_conv3d_bf16_ws_bytes(int, int, int, int, int, int, int, int, int, int);
+int vvae_conv3d_bf16_supported(int, int, int, int, int, int, int, int, int);
+}
+
+static int g_force_generic = 0;
+
+// Test hook: 1 = always take the generic path (used to cross-check the fast path on the GPU).
+extern "C" void vvae_conv3d_force_generic(int on) { g_force_generic = on; }
+
+// Scratch bytes the caller must provide to fwd / dgrad / wgrad for this shape (0 = none needed).
+extern "C" size_t vvae_conv3d_workspace_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, int which)
+{
+    if (dtype != VVAE_DT_BF16 || g_force_generic) return 0;
+    return vvae_conv3d_bf16_ws_bytes(N, T, H, W, Cin, Cout, kt, kh, kw, which);
+}
+
+// y[n,t,h,w,co] = bias[co] + sum_{a,b,c,ci} x[n,t+a-pt,h+b-ph,w+c-pw,ci] * w[a,b,c,ci,co]   (zero padding)
+// x: (N,T,H,W,Cin) row pitch ldx; y: (N,T,H,W,Cout) row pitch ldy; w: Flax kernel (kt,kh,kw,Cin,Cout) fp32; bias fp32 or NULL.
+extern "C" int vvae_conv3d_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                               int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                               void* ws, size_t ws_bytes, void* stream)
+{
+    if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, ldy, 0, 0))
+        return vvae_conv3d_fwd_bf16(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, 0, ws, ws_bytes, stream);
+    return vvae_conv3d_fwd_generic(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
+}
+
+// dx[n,t,h,w,ci] = sum_{a,b,c,co} dy[n,t-a+pt,h-b+ph,w-c+pw,co] * w[a,b,c,ci,co]
+extern "C" int vvae_conv3d_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx,
+                                 int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                                 void* ws, size_t ws_bytes, void* stream)
+{
+    if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, lddx, lddy, 1, 0))
+        return vvae_conv3d_fwd_bf16(dy, lddy, w, nullptr, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, 1, ws, ws_bytes, stream);
+    return vvae_conv3d_dgrad_generic(dy, lddy, w, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
+}
+
+// dw[a,b,c,ci,co] = sum_v x[v+off(a,b,c)][ci] * dy[v][co] (fp32, overwritten); dbias[co] = sum_v dy[v][co] (or NULL).
+extern "C" int vvae_conv3d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
+                                 int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                                 void* ws, size_t ws_bytes, void* stream)
+{
+    if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, lddy, 2, 0))
+        return vvae_conv3d_wgrad_bf16(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, ws, ws_bytes, stream);
+    return vvae_conv3d_wgrad_generic(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
+}

@@ -1,0 +1,309 @@
+// Generic NDHWC Conv3d (SAME, stride 1, odd kernel) forward / data-grad / weight-grad.
+//
+// Replaces the XLA lowering of nnx.Conv at /root/reference/train/unet.py:13-21 (3x3x3),
+// :111-113 (3x7x7 patch_mixer) and :144-153 (1x1x1 final_conv), and their autodiff.
+//
+// This is the *any-shape, any-dtype* path: operands are converted to fp32 on load and
+// multiplied on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains,
+// 157 TFLOP/s peak), so results match an fp32 reference to rounding.  Its fragment
+// shapes need no transposes in NDHWC: the MFMA k index lives on lane>>4, so
+//   fwd/dgrad: A[voxel][k=channel] and B[k=channel][out-channel] are plain 4-byte loads,
+//   wgrad:     A[cin][k=voxel]     and B[k=voxel][cout]          likewise.
+// The bf16 fast path (conv3d_bf16.hip) takes over for 16-multiple channel counts.
+#include "common.hpp"
+
+namespace {
+
+struct ConvDims {
+    int N, T, H, W, Cin, Cout, kt, kh, kw;
+};
+
+// NT = number of 16-wide output-channel tiles per wave.
+// DGRAD=false: y[v][co] = bias[co] + sum_{tap,ci} x[v+off(tap)][ci] * w[tap][ci][co]
+// DGRAD=true : dx[v][ci] =          sum_{tap,co} dy[v-off(tap)][co] * w[tap][ci][co]
+template <typename T, bool DGRAD, int NT>
+__global__ __launch_bounds__(256) void conv3d_f32mfma_kernel(
+    const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+    T* __restrict__ y, int ldy, ConvDims d)
+{
+    const int CK = DGRAD ? d.Cout : d.Cin;     // contracted channels
+    const int CO = DGRAD ? d.Cin : d.Cout;     // produced channels
+    const long V = (long)d.N * d.T * d.H * d.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const long tile0 = ((long)blockIdx.x * 4 + wave) * 16;
+    const int o_base = blockIdx.y * NT * 16;
+
+    long v = tile0 + r;
+    const bool vvalid = v < V;
+    if (!vvalid) v = V - 1;
+    int ww = (int)(v % d.W); long q = v / d.W;
+    int hh = (int)(q % d.H); q /= d.H;
+    int tt = (int)(q % d.T); const int n = (int)(q / d.T);
+    const int pt = d.kt / 2, ph = d.kh / 2, pw = d.kw / 2;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int a = 0; a < d.kt; ++a) {
+        const int ti = DGRAD ? tt - a + pt : tt + a - pt;
+        for (int b = 0; b < d.kh; ++b) {
+            const int hi = DGRAD ? hh - b + ph : hh + b - ph;
+            for (int c = 0; c < d.kw; ++c) {
+                const int wi = DGRAD ? ww - c + pw : ww + c - pw;
+                const bool inb = vvalid && (unsigned)ti < (unsigned)d.T && (unsigned)hi < (unsigned)d.H &&
+                                 (unsigned)wi < (unsigned)d.W;
+                const long vin = (((long)n * d.T + ti) * d.H + hi) * d.W + wi;
+                const T* xrow = x + (inb ? vin : 0) * (long)ldx;
+                const int tap = (a * d.kh + b) * d.kw + c;
+                const float* wtap = w + (long)tap * d.Cin * d.Cout;
+                for (int k0 = 0; k0 < CK; k0 += 4) {
+                    const int kk = k0 + kq;
+                    const bool kin = kk < CK;
+                    const float av = (inb && kin) ? ldf(xrow + kk) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const int o = o_base + i * 16 + r;
+                        float bv = 0.f;
+                        if (kin && o < CO)
+                            bv = DGRAD ? wtap[(long)o * d.Cout + kk] : wtap[(long)kk * d.Cout + o];
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // C/D layout: col = lane&15 (channel), row = (lane>>4)*4 + j (voxel in the tile).
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int o = o_base + i * 16 + r;
+        if (o >= CO) continue;
+        const float bb = (!DGRAD && bias) ? bias[o] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long vo = tile0 + kq * 4 + j;
+            if (vo < V) stf(y + vo * (long)ldy + o, acc[i][j] + bb);
+        }
+    }
+}
+
+// dW[tap][ci][co] += sum_v x[v+off(tap)][ci] * dy[v][co]   (atomic fp32 accumulate; dW pre-zeroed)
+// grid: x = voxel chunk, y = tap, z = ci tile.  Each wave strides over 4-voxel k-steps.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv3d_wgrad_f32mfma_kernel(
+    const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, float* __restrict__ dw,
+    ConvDims d, int co_tile_base, int voxels_per_block)
+{
+    __shared__ float red[4][NT][64][4];
+    const long V = (long)d.N * d.T * d.H * d.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int tap = blockIdx.y;
+    const int c = tap % d.kw, b = (tap / d.kw) % d.kh, a = tap / (d.kw * d.kh);
+    const int ot = a - d.kt / 2, oh = b - d.kh / 2, ow = c - d.kw / 2;
+    const int ci = blockIdx.z * 16 + r;
+    const bool ci_ok = ci < d.Cin;
+    const long vbeg = (long)blockIdx.x * voxels_per_block;
+    long vend = vbeg + voxels_per_block;
+    if (vend > V) vend = V;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (long v0 = vbeg + wave * 4; v0 < vend; v0 += 16) {
+        const long v = v0 + kq;
+        const bool vok = v < vend;
+        const long vc = vok ? v : vbeg;
+        int ww = (int)(vc % d.W); long q = vc / d.W;
+        int hh = (int)(q % d.H); q /= d.H;
+        int tt = (int)(q % d.T); const int n = (int)(q / d.T);
+        const int ti = tt + ot, hi = hh + oh, wi = ww + ow;
+        const bool inb = vok && ci_ok && (unsigned)ti < (unsigned)d.T && (unsigned)hi < (unsigned)d.H &&
+                         (unsigned)wi < (unsigned)d.W;
+        const long vin = (((long)n * d.T + ti) * d.H + hi) * d.W + wi;
+        const float av = inb ? ldf(x + vin * (long)ldx + ci) : 0.f;
+        const T* dyrow = dy + vc * (long)lddy;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int co = (co_tile_base + i) * 16 + r;
+            const float bv = (vok && co < d.Cout) ? ldf(dyrow + co) : 0.f;
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave][i][lane][j] = acc[i][j];
+    __syncthreads();
+    // 256 threads reduce NT*64*4 values over the 4 waves.
+    for (int e = threadIdx.x; e < NT * 256; e += 256) {
+        const int i = e >> 8, l = (e >> 2) & 63, j = e & 3;
+        const float s = red[0][i][l][j] + red[1][i][l][j] + red[2][i][l][j] + red[3][i][l][j];
+        const int row = (l >> 4) * 4 + j, col = l & 15;           // row = ci in tile, col = co in tile
+        const int cii = blockIdx.z * 16 + row, co = (co_tile_base + i) * 16 + col;
+        if (cii < d.Cin && co < d.Cout) atomicAdd(dw + ((long)tap * d.Cin + cii) * d.Cout + co, s);
+    }
+}
+
+// out[c] = sum_v x[v][c]  (bias gradients).  grid.x blocks each reduce a voxel range; atomics to out.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long V, int C,
+                                                     float* __restrict__ out, int voxels_per_block)
+{
+    // thread layout: 256 threads; column c = tid % Cp (Cp = C rounded to pow2 <= 256), row lane = tid / Cp
+    __shared__ float red[256];
+    int Cp = 1;
+    while (Cp < C && Cp < 256) Cp <<= 1;
+    const int rows = 256 / Cp;
+    const int cl = threadIdx.x % Cp, rl = threadIdx.x / Cp;
+    const long vbeg = (long)blockIdx.x * voxels_per_block;
+    long vend = vbeg + voxels_per_block;
+    if (vend > V) vend = V;
+    for (int c0 = 0; c0 < C; c0 += Cp) {
+        const int c = c0 + cl;
+        float s = 0.f;
+        if (c < C)
+            for (long v = vbeg + rl; v < vend; v += rows) s += ldf(x + v * (long)ld + c);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            float t = 0.f;
+            for (int i = 0; i < rows; ++i) t += red[i * Cp + cl];
+            atomicAdd(out + c, t);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, bool DGRAD>
+int launch_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, ConvDims d,
+               hipStream_t s)
+{
+    const long V = (long)d.N * d.T * d.H * d.W;
+    const int CO = DGRAD ? d.Cin : d.Cout;
+    const int tiles = ceil_div(CO, 16);
+    const int nt = tiles >= 8 ? 8 : tiles >= 4 ? 4 : tiles >= 2 ? 2 : 1;
+    dim3 grid(ceil_div(V, 64), ceil_div(tiles, nt));
+    const T* xp = (const T*)x;
+    T* yp = (T*)y;
+#define GO(NTV) hipLaunchKernelGGL((conv3d_f32mfma_kernel<T, DGRAD, NTV>), grid, dim3(256), 0, s, xp, ldx, w, bias, yp, ldy, d)
+    switch (nt) {
+        case 8: GO(8); break;
+        case 4: GO(4); break;
+        case 2: GO(2); break;
+        default: GO(1); break;
+    }
+#undef GO
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int launch_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, ConvDims d,
+                 hipStream_t s)
+{
+    const long V = (long)d.N * d.T * d.H * d.W;
+    const int taps = d.kt * d.kh * d.kw;
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)taps * d.Cin * d.Cout, s);
+    if (e != hipSuccess) return (int)e;
+    const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
+    // aim for >= ~2048 blocks in total, chunk a multiple of 16 voxels
+    long blocks_xy = (long)taps * ci_tiles;
+    long want = 4096 / (blocks_xy > 0 ? blocks_xy : 1);
+    if (want < 1) want = 1;
+    long vpb = (V + want - 1) / want;
+    vpb = ((vpb + 15) / 16) * 16;
+    if (vpb < 256) vpb = 256;
+    dim3 grid(ceil_div(V, vpb), taps, ci_tiles);
+    const T* xp = (const T*)x;
+    const T* dyp = (const T*)dy;
+    for (int base = 0; base < co_tiles;) {
+        const int rem = co_tiles - base;
+        const int nt = rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
+#define GO(NTV) hipLaunchKernelGGL((conv3d_wgrad_f32mfma_kernel<T, NTV>), grid, dim3(256), 0, s, xp, ldx, dyp, lddy, dw, d, base, (int)vpb)
+        switch (nt) {
+            case 8: GO(8); break;
+            case 4: GO(4); break;
+            case 2: GO(2); break;
+            default: GO(1); break;
+        }
+#undef GO
+        VVAE_LAUNCH_CHECK();
+        base += nt;
+    }
+    if (dbias) {
+        e = hipMemsetAsync(dbias, 0, sizeof(float) * d.Cout, s);
+        if (e != hipSuccess) return (int)e;
+        const int vb = 4096;
+        hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(V, vb)), dim3(256), 0, s, dyp, lddy, V, d.Cout, dbias, vb);
+        VVAE_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+bool dims_ok(const ConvDims& d, int ldx, int ldy, bool dgrad)
+{
+    if (d.N <= 0 || d.T <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0) return false;
+    if (!(d.kt & 1) || !(d.kh & 1) || !(d.kw & 1)) return false;
+    const int cx = dgrad ? d.Cout : d.Cin, cy = dgrad ? d.Cin : d.Cout;
+    return ldx >= cx && ldy >= cy;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- C ABI (generic path)
+extern "C" int vvae_conv3d_fwd_generic(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                                       int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                                       int dtype, void* stream)
+{
+    ConvDims d{N, T, H, W, Cin, Cout, kt, kh, kw};
+    if (!x || !w || !y || !dims_ok(d, ldx, ldy, false)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VVAE_DT_F32) return launch_fwd<float, false>(x, ldx, w, bias, y, ldy, d, s);
+    if (dtype == VVAE_DT_BF16) return launch_fwd<bf16_t, false>(x, ldx, w, bias, y, ldy, d, s);
+    return VVAE_ERR_BAD_ARG;
+}
+
+extern "C" int vvae_conv3d_dgrad_generic(const void* dy, int lddy, const float* w, void* dx, int lddx,
+                                         int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                                         int dtype, void* stream)
+{
+    ConvDims d{N, T, H, W, Cin, Cout, kt, kh, kw};
+    if (!dy || !w || !dx || !dims_ok(d, lddy, lddx, true)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VVAE_DT_F32) return launch_fwd<float, true>(dy, lddy, w, nullptr, dx, lddx, d, s);
+    if (dtype == VVAE_DT_BF16) return launch_fwd<bf16_t, true>(dy, lddy, w, nullptr, dx, lddx, d, s);
+    return VVAE_ERR_BAD_ARG;
+}
+
+extern "C" int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
+                                         int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                                         int dtype, void* stream)
+{
+    ConvDims d{N, T, H, W, Cin, Cout, kt, kh, kw};
+    if (!x || !dy || !dw || !dims_ok(d, ldx, lddy, false)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VVAE_DT_F32) return launch_wgrad<float>(x, ldx, dy, lddy, dw, dbias, d, s);
+    if (dtype == VVAE_DT_BF16) return launch_wgrad<bf16_t>(x, ldx, dy, lddy, dw, dbias, d, s);
+    return VVAE_ERR_BAD_ARG;
+}
+
+// out[c] (fp32, overwritten) = sum over V rows of x[v][c]
+extern "C" int vvae_colsum(const void* x, int ld, long V, int C, float* out, int dtype, void* stream)
+{
+    if (!x || !out || V <= 0 || C <= 0 || ld < C) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, s);
+    if (e != hipSuccess) return (int)e;
+    const int vb = 4096;
+    if (dtype == VVAE_DT_F32)
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(ceil_div(V, vb)), dim3(256), 0, s, (const float*)x, ld, V, C, out, vb);
+    else if (dtype == VVAE_DT_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(ceil_div(V, vb)), dim3(256), 0, s, (const bf16_t*)x, ld, V, C, out, vb);
+    else
+        return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,328 @@
+// Fused GroupNorm(eps=1e-6, fast variance) + SiLU, forward and backward, channels-last.
+//
+// Replaces nnx.GroupNorm + nnx.silu of ConvBlock3D (/root/reference/train/unet.py:22-23,28-29):
+// statistics per (sample, group) over (t, h, w, C/G) in fp32 (accumulated across workgroups in
+// fp64 so the E[x^2]-E[x]^2 form does not cancel), y = silu((x-mean)*rstd*gamma + beta).
+//
+// All kernels are pure HBM streams: 16-byte vector loads per lane (VEC = 4 fp32 / 8 bf16 channels),
+// wave-level partial sums, one fp64 atomic per (block, group|channel).
+//   stats : read x                      -> sums[N][G][2]  (sum, sum of squares), fp64
+//   fwd   : read x, write y
+//   bwd 1 : read x, dy                  -> csum[N][C][2]  (sum dz*xhat, sum dz), fp64
+//   bwd 2 : read x, dy, write dx        (+ tiny kernel for dgamma, dbeta)
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxC = 1024;
+
+struct GnDims {
+    int N; long S; int C, G; float eps;      // S = voxels per sample
+};
+
+// Thread layout shared by all kernels: cvecs = C/VEC lanes across channels, rows = 256/cvecs voxels per pass.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int ldx, GnDims d,
+                                                       double* __restrict__ sums, int voxels_per_block)
+{
+    __shared__ float red[256][2];
+    __shared__ float chan[kMaxC][2];
+    const int cvecs = d.C / VEC, rows = 256 / cvecs;
+    const int cl = threadIdx.x % cvecs, rl = threadIdx.x / cvecs;
+    const int n = blockIdx.y;
+    const long vbeg = (long)blockIdx.x * voxels_per_block;
+    long vend = vbeg + voxels_per_block;
+    if (vend > d.S) vend = d.S;
+    const T* xs = x + (long)n * d.S * ldx;
+    float s[VEC], ss[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = ss[i] = 0.f;
+    if (rl < rows)
+        for (long v = vbeg + rl; v < vend; v += rows) {
+            float t[VEC];
+            VecIO<T, VEC>::load(xs + v * ldx + cl * VEC, t);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { s[i] += t[i]; ss[i] += t[i] * t[i]; }
+        }
+    // reduce over rows for each channel, one channel-of-the-vector at a time
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        red[threadIdx.x][0] = s[i]; red[threadIdx.x][1] = ss[i];
+        __syncthreads();
+        if (rl == 0) {
+            float a = 0.f, b = 0.f;
+            for (int r2 = 0; r2 < rows; ++r2) { a += red[r2 * cvecs + cl][0]; b += red[r2 * cvecs + cl][1]; }
+            chan[cl * VEC + i][0] = a; chan[cl * VEC + i][1] = b;
+        }
+        __syncthreads();
+    }
+    const int cpg = d.C / d.G;
+    if (threadIdx.x < d.G) {
+        double a = 0.0, b = 0.0;
+        for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { a += chan[c][0]; b += chan[c][1]; }
+        atomicAdd(sums + ((long)n * d.G + threadIdx.x) * 2, a);
+        atomicAdd(sums + ((long)n * d.G + threadIdx.x) * 2 + 1, b);
+    }
+}
+
+// per-block prologue: a_c = rstd_g*gamma_c, b_c = beta_c - mean_g*a_c for sample n
+__device__ __forceinline__ void load_affine(const double* sums, const float* gamma, const float* beta, const GnDims& d,
+                                            int n, float (*ab)[2], float* mean_g, float* rstd_g)
+{
+    const int cpg = d.C / d.G;
+    const double M = (double)d.S * cpg;
+    if (threadIdx.x < d.G) {
+        const double m = sums[((long)n * d.G + threadIdx.x) * 2] / M;
+        double var = sums[((long)n * d.G + threadIdx.x) * 2 + 1] / M - m * m;
+        if (var < 0.0) var = 0.0;
+        mean_g[threadIdx.x] = (float)m;
+        rstd_g[threadIdx.x] = rsqrtf((float)var + d.eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        const int g = c / cpg;
+        const float a = rstd_g[g] * gamma[c];
+        ab[c][0] = a;
+        ab[c][1] = beta[c] - mean_g[g] * a;
+    }
+    __syncthreads();
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                          const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, GnDims d, int voxels_per_block)
+{
+    __shared__ float ab[kMaxC][2];
+    __shared__ float mean_g[64], rstd_g[64];
+    const int n = blockIdx.y;
+    load_affine(sums, gamma, beta, d, n, ab, mean_g, rstd_g);
+    const int cvecs = d.C / VEC;
+    const long vbeg = (long)blockIdx.x * voxels_per_block;
+    long vend = vbeg + voxels_per_block;
+    if (vend > d.S) vend = d.S;
+    const long items = (vend - vbeg) * cvecs;
+    const T* xs = x + ((long)n * d.S + vbeg) * ldx;
+    T* ys = y + ((long)n * d.S + vbeg) * ldy;
+    for (long it = threadIdx.x; it < items; it += 256) {
+        const long v = it / cvecs; const int c0 = (int)(it % cvecs) * VEC;
+        float t[VEC];
+        VecIO<T, VEC>::load(xs + v * ldx + c0, t);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float z = t[i] * ab[c0 + i][0] + ab[c0 + i][1];
+            t[i] = z * sigmoidf_(z);
+        }
+        VecIO<T, VEC>::store(ys + v * ldy + c0, t);
+    }
+}
+
+// dz = dy * silu'(z), silu'(z) = s*(1 + z*(1-s)), s = sigmoid(z)
+__device__ __forceinline__ float dsilu(float z) {
+    const float s = sigmoidf_(z);
+    return s * (1.f + z * (1.f - s));
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                                 const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, GnDims d, double* __restrict__ csum,
+                                                                 int voxels_per_block)
+{
+    __shared__ float ab[kMaxC][2];
+    __shared__ float mean_g[64], rstd_g[64];
+    __shared__ float red[256][2];
+    const int n = blockIdx.y;
+    load_affine(sums, gamma, beta, d, n, ab, mean_g, rstd_g);
+    const int cvecs = d.C / VEC, rows = 256 / cvecs, cpg = d.C / d.G;
+    const int cl = threadIdx.x % cvecs, rl = threadIdx.x / cvecs;
+    const long vbeg = (long)blockIdx.x * voxels_per_block;
+    long vend = vbeg + voxels_per_block;
+    if (vend > d.S) vend = d.S;
+    const T* xs = x + (long)n * d.S * ldx;
+    const T* dys = dy + (long)n * d.S * lddy;
+    float s1[VEC], s2[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        s1[i] = s2[i] = 0.f;
+        const int g = (cl * VEC + i) / cpg;
+        mu[i] = mean_g[g]; rs[i] = rstd_g[g];
+    }
+    if (rl < rows)
+        for (long v = vbeg + rl; v < vend; v += rows) {
+            float t[VEC], g[VEC];
+            VecIO<T, VEC>::load(xs + v * ldx + cl * VEC, t);
+            VecIO<T, VEC>::load(dys + v * lddy + cl * VEC, g);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const int c = cl * VEC + i;
+                const float z = t[i] * ab[c][0] + ab[c][1];
+                const float dz = g[i] * dsilu(z);
+                s1[i] += dz * (t[i] - mu[i]) * rs[i];
+                s2[i] += dz;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        red[threadIdx.x][0] = s1[i]; red[threadIdx.x][1] = s2[i];
+        __syncthreads();
+        if (rl == 0) {
+            double a = 0.0, b = 0.0;
+            for (int r2 = 0; r2 < rows; ++r2) { a += red[r2 * cvecs + cl][0]; b += red[r2 * cvecs + cl][1]; }
+            const int c = cl * VEC + i;
+            atomicAdd(csum + ((long)n * d.C + c) * 2, a);
+            atomicAdd(csum + ((long)n * d.C + c) * 2 + 1, b);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                                T* __restrict__ dx, int lddx, const double* __restrict__ sums,
+                                                                const double* __restrict__ csum, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, GnDims d, int voxels_per_block)
+{
+    __shared__ float ab[kMaxC][2];
+    __shared__ float mean_g[64], rstd_g[64], m1_g[64], m2_g[64];
+    const int n = blockIdx.y;
+    load_affine(sums, gamma, beta, d, n, ab, mean_g, rstd_g);
+    const int cvecs = d.C / VEC, cpg = d.C / d.G;
+    if (threadIdx.x < d.G) {
+        const double M = (double)d.S * cpg;
+        double a = 0.0, b = 0.0;
+        for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
+            a += (double)gamma[c] * csum[((long)n * d.C + c) * 2 + 1];   // sum gamma*dz
+            b += (double)gamma[c] * csum[((long)n * d.C + c) * 2];       // sum gamma*dz*xhat
+        }
+        m1_g[threadIdx.x] = (float)(a / M);
+        m2_g[threadIdx.x] = (float)(b / M);
+    }
+    __syncthreads();
+    const long vbeg = (long)blockIdx.x * voxels_per_block;
+    long vend = vbeg + voxels_per_block;
+    if (vend > d.S) vend = d.S;
+    const long items = (vend - vbeg) * cvecs;
+    const T* xs = x + ((long)n * d.S + vbeg) * ldx;
+    const T* dys = dy + ((long)n * d.S + vbeg) * lddy;
+    T* dxs = dx + ((long)n * d.S + vbeg) * lddx;
+    for (long it = threadIdx.x; it < items; it += 256) {
+        const long v = it / cvecs; const int c0 = (int)(it % cvecs) * VEC;
+        float t[VEC], g[VEC];
+        VecIO<T, VEC>::load(xs + v * ldx + c0, t);
+        VecIO<T, VEC>::load(dys + v * lddy + c0, g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = c0 + i, gi = c / cpg;
+            const float z = t[i] * ab[c][0] + ab[c][1];
+            const float dz = g[i] * dsilu(z);
+            const float xh = (t[i] - mean_g[gi]) * rstd_g[gi];
+            t[i] = rstd_g[gi] * (gamma[c] * dz - m1_g[gi] - xh * m2_g[gi]);
+        }
+        VecIO<T, VEC>::store(dxs + v * lddx + c0, t);
+    }
+}
+
+__global__ void gn_param_grad_kernel(const double* __restrict__ csum, int N, int C, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) { a += csum[((long)n * C + c) * 2]; b += csum[((long)n * C + c) * 2 + 1]; }
+    dgamma[c] = (float)a;
+    dbeta[c] = (float)b;
+}
+
+inline int pick_vpb(long S, int N) {
+    // ~4096 blocks over the whole tensor, at least 128 voxels each
+    long want = 4096 / (N > 0 ? N : 1);
+    if (want < 1) want = 1;
+    long vpb = (S + want - 1) / want;
+    if (vpb < 128) vpb = 128;
+    return (int)vpb;
+}
+
+template <typename T> bool vec_ok(const void* p, int ld, int C) {
+    constexpr int V = VecWidth<T>::value;
+    return C % V == 0 && ld % V == 0 && ((uintptr_t)p % 16) == 0 && (256 % (C / V) == 0 || C / V <= 256);
+}
+
+bool gn_ok(const GnDims& d) {
+    return d.N > 0 && d.S > 0 && d.C > 0 && d.G > 0 && d.C % d.G == 0 && d.C <= kMaxC && d.G <= 64 && d.C <= 256 * 8;
+}
+
+}  // namespace
+
+#define GN_DISPATCH(KERNEL, VOK, ...)                                                                         \
+    do {                                                                                                      \
+        if (dtype == VVAE_DT_F32) {                                                                           \
+            typedef float T;                                                                                  \
+            if (VOK) hipLaunchKernelGGL((KERNEL<T, 4>), grid, dim3(256), 0, s, __VA_ARGS__);                  \
+            else hipLaunchKernelGGL((KERNEL<T, 1>), grid, dim3(256), 0, s, __VA_ARGS__);                      \
+        } else {                                                                                              \
+            typedef bf16_t T;                                                                                 \
+            if (VOK) hipLaunchKernelGGL((KERNEL<T, 8>), grid, dim3(256), 0, s, __VA_ARGS__);                  \
+            else hipLaunchKernelGGL((KERNEL<T, 1>), grid, dim3(256), 0, s, __VA_ARGS__);                      \
+        }                                                                                                     \
+    } while (0)
+
+// sums: fp64 [N][G][2], overwritten.
+extern "C" int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, int dtype, void* stream)
+{
+    GnDims d{N, S, C, G, 0.f};
+    if (!x || !sums || !gn_ok(d) || ldx < C || (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)N * G, s);
+    if (e != hipSuccess) return (int)e;
+    const int vpb = pick_vpb(S, N);
+    dim3 grid(ceil_div(S, vpb), N);
+    const bool vok = dtype == VVAE_DT_F32 ? vec_ok<float>(x, ldx, C) : vec_ok<bf16_t>(x, ldx, C);
+    if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
+    GN_DISPATCH(gn_stats_kernel, vok, (const T*)x, ldx, d, sums, vpb);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const double* sums, const float* gamma,
+                                const float* beta, int N, long S, int C, int G, float eps, int dtype, void* stream)
+{
+    GnDims d{N, S, C, G, eps};
+    if (!x || !y || !sums || !gamma || !beta || !gn_ok(d) || ldx < C || ldy < C ||
+        (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int vpb = pick_vpb(S, N);
+    dim3 grid(ceil_div(S, vpb), N);
+    const bool vok = dtype == VVAE_DT_F32 ? (vec_ok<float>(x, ldx, C) && vec_ok<float>(y, ldy, C))
+                                          : (vec_ok<bf16_t>(x, ldx, C) && vec_ok<bf16_t>(y, ldy, C));
+    if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
+    GN_DISPATCH(gn_silu_fwd_kernel, vok, (const T*)x, ldx, (T*)y, ldy, sums, gamma, beta, d, vpb);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// csum: fp64 workspace [N][C][2] (overwritten).  dgamma/dbeta fp32 [C] (overwritten).
+extern "C" int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const double* sums,
+                                const float* gamma, const float* beta, double* csum, float* dgamma, float* dbeta,
+                                int N, long S, int C, int G, float eps, int dtype, void* stream)
+{
+    GnDims d{N, S, C, G, eps};
+    if (!x || !dy || !dx || !sums || !gamma || !beta || !csum || !dgamma || !dbeta || !gn_ok(d) || ldx < C || lddy < C ||
+        lddx < C || (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(csum, 0, sizeof(double) * 2 * (size_t)N * C, s);
+    if (e != hipSuccess) return (int)e;
+    const int vpb = pick_vpb(S, N);
+    dim3 grid(ceil_div(S, vpb), N);
+    const bool vok = dtype == VVAE_DT_F32
+        ? (vec_ok<float>(x, ldx, C) && vec_ok<float>(dy, lddy, C) && vec_ok<float>(dx, lddx, C))
+        : (vec_ok<bf16_t>(x, ldx, C) && vec_ok<bf16_t>(dy, lddy, C) && vec_ok<bf16_t>(dx, lddx, C));
+    if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
+    GN_DISPATCH(gn_silu_bwd_reduce_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, sums, gamma, beta, d, csum, vpb);
+    VVAE_LAUNCH_CHECK();
+    GN_DISPATCH(gn_silu_bwd_apply_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, sums, csum, gamma, beta, d, vpb);
+    VVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, csum, N, C, dgamma, dbeta);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,327 @@
+// Reparameterise + KL, masked MSE/MAE, and the clip-by-global-norm + Adam update: fused HBM-streaming kernels.
+//
+// reparam : z = mean + eps * exp(log_var / 2)                    /root/reference/train/model.py:124-128
+// KL      : mean_{t,hw,c}[ 0.5 (e^lv - 1 - lv + mu^2) m_t / len ]  /root/reference/train/rl_nonadversarial.py:146-147
+// MSE/MAE : mean_{h,w,c}[ sum_t ((v - r) m_t)^2 / len ], |.| too   rl_nonadversarial.py:114-121
+// optimiser: optax.chain(clip_by_global_norm(1.0), adam(...))      rl_nonadversarial.py:248-251
+//
+// One read of each operand; per-sample sums go wave-shuffle -> LDS -> one fp32 atomic per block.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    __syncthreads();
+    return t;   // valid on thread 0
+}
+
+__device__ __forceinline__ float seq_len(const float* __restrict__ mrow, int T) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += mrow[t];
+    return fmaxf(s, 1.0f);
+}
+
+// grid (chunks, B).  per = hw*c elements per frame; M = T*per elements per sample.
+template <typename T_>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const T_* __restrict__ mean, const T_* __restrict__ logvar,
+                                                             const float* __restrict__ eps, const float* __restrict__ mask,
+                                                             float* __restrict__ z, float* __restrict__ kl, int T, long per,
+                                                             int elems_per_block)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const long M = (long)T * per;
+    const long beg = (long)blockIdx.x * elems_per_block;
+    long end = beg + elems_per_block; if (end > M) end = M;
+    const float* mrow = mask ? mask + (long)b * T : nullptr;
+    float acc = 0.f;
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        const long g = (long)b * M + i;
+        const float mu = ldf(mean + g), lv = ldf(logvar + g);
+        if (z) z[g] = mu + eps[g] * __expf(0.5f * lv);
+        if (kl) {
+            const float m = mrow ? mrow[i / per] : 1.f;
+            acc += 0.5f * (__expf(lv) - 1.f - lv + mu * mu) * m;
+        }
+    }
+    if (kl) {
+        const float t = block_sum(acc, red);
+        if (threadIdx.x == 0) {
+            const float len = mrow ? seq_len(mrow, T) : (float)T;
+            atomicAdd(kl + b, t / (len * (float)M));
+        }
+    }
+}
+
+template <typename T_>
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const T_* __restrict__ mean, const T_* __restrict__ logvar,
+                                                             const float* __restrict__ eps, const float* __restrict__ mask,
+                                                             const float* __restrict__ dz, const float* __restrict__ gkl,
+                                                             T_* __restrict__ dmean, T_* __restrict__ dlogvar, int T, long per,
+                                                             int elems_per_block)
+{
+    const int b = blockIdx.y;
+    const long M = (long)T * per;
+    const long beg = (long)blockIdx.x * elems_per_block;
+    long end = beg + elems_per_block; if (end > M) end = M;
+    const float* mrow = mask ? mask + (long)b * T : nullptr;
+    float kscale = 0.f;
+    if (gkl) {
+        const float len = mrow ? seq_len(mrow, T) : (float)T;
+        kscale = gkl[b] / (len * (float)M);
+    }
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        const long g = (long)b * M + i;
+        const float mu = ldf(mean + g), lv = ldf(logvar + g);
+        float dm = 0.f, dl = 0.f;
+        if (dz) { const float d = dz[g]; dm = d; dl = d * eps[g] * 0.5f * __expf(0.5f * lv); }
+        if (gkl) {
+            const float m = mrow ? mrow[i / per] : 1.f;
+            dm += kscale * m * mu;
+            dl += kscale * m * 0.5f * (__expf(lv) - 1.f);
+        }
+        stf(dmean + g, dm);
+        stf(dlogvar + g, dl);
+    }
+}
+
+// grid (chunks, B).  P = h*w*c elements per frame.  video sample index = b / video_div (pair doubling).
+template <typename T_, int VEC>
+__global__ __launch_bounds__(256) void masked_mse_mae_fwd_kernel(const T_* __restrict__ video, const T_* __restrict__ recon,
+                                                                 const float* __restrict__ mask, float* __restrict__ mse,
+                                                                 float* __restrict__ mae, int T, long P, int video_div,
+                                                                 int elems_per_block)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const long M = (long)T * P;
+    const long beg = (long)blockIdx.x * elems_per_block;
+    long end = beg + elems_per_block; if (end > M) end = M;
+    const float* mrow = mask + (long)b * T;
+    const T_* vs = video + (long)(b / video_div) * M;
+    const T_* rs = recon + (long)b * M;
+    float a2 = 0.f, a1 = 0.f;
+    for (long i = beg + (long)threadIdx.x * VEC; i < end; i += 256 * VEC) {
+        float v[VEC], r[VEC];
+        VecIO<T_, VEC>::load(vs + i, v);
+        VecIO<T_, VEC>::load(rs + i, r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float m = mrow[(i + k) / P];
+            const float e = (v[k] - r[k]) * m;
+            a2 += e * e; a1 += fabsf(e);
+        }
+    }
+    const float t2 = block_sum(a2, red);
+    const float t1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        const float sc = 1.f / (seq_len(mrow, T) * (float)P);
+        atomicAdd(mse + b, t2 * sc);
+        atomicAdd(mae + b, t1 * sc);
+    }
+}
+
+template <typename T_, int VEC>
+__global__ __launch_bounds__(256) void masked_mse_mae_bwd_kernel(const T_* __restrict__ video, const T_* __restrict__ recon,
+                                                                 const float* __restrict__ mask, const float* __restrict__ gmse,
+                                                                 const float* __restrict__ gmae, T_* __restrict__ drecon, int T, long P,
+                                                                 int video_div, int elems_per_block)
+{
+    const int b = blockIdx.y;
+    const long M = (long)T * P;
+    const long beg = (long)blockIdx.x * elems_per_block;
+    long end = beg + elems_per_block; if (end > M) end = M;
+    const float* mrow = mask + (long)b * T;
+    const T_* vs = video + (long)(b / video_div) * M;
+    const T_* rs = recon + (long)b * M;
+    T_* ds = drecon + (long)b * M;
+    const float sc = 1.f / (seq_len(mrow, T) * (float)P);
+    const float g2 = (gmse ? gmse[b] : 0.f) * sc, g1 = (gmae ? gmae[b] : 0.f) * sc;
+    for (long i = beg + (long)threadIdx.x * VEC; i < end; i += 256 * VEC) {
+        float v[VEC], r[VEC];
+        VecIO<T_, VEC>::load(vs + i, v);
+        VecIO<T_, VEC>::load(rs + i, r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float m = mrow[(i + k) / P];
+            const float e = (v[k] - r[k]) * m;                       // d/dr of e = -m
+            const float sg = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+            r[k] = -m * (2.f * e * g2 + sg * g1);
+        }
+        VecIO<T_, VEC>::store(ds + i, r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- optimiser
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out)
+{
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long n4 = n / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 t = g4[i];
+        acc += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) { const float t = g[n4 * 4 + threadIdx.x]; acc += t * t; }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, (double)t);
+}
+
+// p, m, v updated in place; optional bf16 shadow copy of p.  gscale: grads are multiplied by gscale first (1/world).
+// clip: g *= max_norm/||g|| only if ||g|| >= max_norm, with ||g|| = gscale*sqrt(*gnorm_sq)  (optax semantics).
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n,
+                                                        const double* __restrict__ gnorm_sq, float gscale, float max_norm, float lr,
+                                                        float b1, float b2, float eps, float c1, float c2)
+{
+    float clip = gscale;
+    if (gnorm_sq) {
+        const float gn = gscale * (float)sqrt(*gnorm_sq);
+        if (gn >= max_norm) clip = gscale * max_norm / gn;
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float pi = p[i] - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+        p[i] = pi;
+        if (p_bf16) p_bf16[i] = f2bf(pi);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = f2bf(x[i]);
+}
+
+inline int pick_epb(long M, int B) {
+    long want = 2048 / (B > 0 ? B : 1); if (want < 1) want = 1;
+    long epb = (M + want - 1) / want;
+    epb = ((epb + 2047) / 2048) * 2048;
+    return (int)epb;
+}
+
+}  // namespace
+
+// mean/logvar (B, T, per) in `dtype`; eps, z fp32; mask fp32 (B,T) or NULL; kl fp32 [B] overwritten.  z or kl may be NULL.
+extern "C" int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, const float* mask, float* z, float* kl,
+                                   int B, int T, long per, int dtype, void* stream)
+{
+    if (!mean || !logvar || (!z && !kl) || (z && !eps) || B <= 0 || T <= 0 || per <= 0) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (kl && (e = hipMemsetAsync(kl, 0, sizeof(float) * B, s)) != hipSuccess) return (int)e;
+    const long M = (long)T * per;
+    const int epb = pick_epb(M, B);
+    dim3 grid(ceil_div(M, epb), B);
+    if (dtype == VVAE_DT_F32)
+        hipLaunchKernelGGL((reparam_kl_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)mean, (const float*)logvar, eps, mask, z, kl, T, per, epb);
+    else if (dtype == VVAE_DT_BF16)
+        hipLaunchKernelGGL((reparam_kl_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)mean, (const bf16_t*)logvar, eps, mask, z, kl, T, per, epb);
+    else return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dz fp32 (or NULL), gkl fp32 [B] (or NULL) -> dmean, dlogvar in `dtype` (overwritten).
+extern "C" int vvae_reparam_kl_bwd(const void* mean, const void* logvar, const float* eps, const float* mask, const float* dz,
+                                   const float* gkl, void* dmean, void* dlogvar, int B, int T, long per, int dtype, void* stream)
+{
+    if (!mean || !logvar || !dmean || !dlogvar || (dz && !eps) || B <= 0 || T <= 0 || per <= 0) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)T * per;
+    const int epb = pick_epb(M, B);
+    dim3 grid(ceil_div(M, epb), B);
+    if (dtype == VVAE_DT_F32)
+        hipLaunchKernelGGL((reparam_kl_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)mean, (const float*)logvar, eps, mask, dz, gkl, (float*)dmean, (float*)dlogvar, T, per, epb);
+    else if (dtype == VVAE_DT_BF16)
+        hipLaunchKernelGGL((reparam_kl_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)mean, (const bf16_t*)logvar, eps, mask, dz, gkl, (bf16_t*)dmean, (bf16_t*)dlogvar, T, per, epb);
+    else return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// video (B/video_div, T, P), recon (B, T, P) in `dtype`; mask fp32 (B,T); mse, mae fp32 [B] overwritten.
+extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* mask, float* mse, float* mae,
+                                       int B, int T, long P, int video_div, int dtype, void* stream)
+{
+    if (!video || !recon || !mask || !mse || !mae || B <= 0 || T <= 0 || P <= 0 || video_div <= 0) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if ((e = hipMemsetAsync(mse, 0, sizeof(float) * B, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(mae, 0, sizeof(float) * B, s)) != hipSuccess) return (int)e;
+    const long M = (long)T * P;
+    const int epb = pick_epb(M, B);
+    dim3 grid(ceil_div(M, epb), B);
+    const bool al = ((uintptr_t)video % 16) == 0 && ((uintptr_t)recon % 16) == 0;
+    if (dtype == VVAE_DT_F32) {
+        if (al && M % 4 == 0) hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)video, (const float*)recon, mask, mse, mae, T, P, video_div, epb);
+        else hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)video, (const float*)recon, mask, mse, mae, T, P, video_div, epb);
+    } else if (dtype == VVAE_DT_BF16) {
+        if (al && M % 8 == 0) hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
+        else hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
+    } else return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// gmse / gmae fp32 [B] (either may be NULL) -> drecon (B, T, P) in `dtype`.
+extern "C" int vvae_masked_mse_mae_bwd(const void* video, const void* recon, const float* mask, const float* gmse, const float* gmae,
+                                       void* drecon, int B, int T, long P, int video_div, int dtype, void* stream)
+{
+    if (!video || !recon || !mask || !drecon || B <= 0 || T <= 0 || P <= 0 || video_div <= 0) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)T * P;
+    const int epb = pick_epb(M, B);
+    dim3 grid(ceil_div(M, epb), B);
+    const bool al = ((uintptr_t)video % 16) == 0 && ((uintptr_t)recon % 16) == 0 && ((uintptr_t)drecon % 16) == 0;
+    if (dtype == VVAE_DT_F32) {
+        if (al && M % 4 == 0) hipLaunchKernelGGL((masked_mse_mae_bwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)video, (const float*)recon, mask, gmse, gmae, (float*)drecon, T, P, video_div, epb);
+        else hipLaunchKernelGGL((masked_mse_mae_bwd_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)video, (const float*)recon, mask, gmse, gmae, (float*)drecon, T, P, video_div, epb);
+    } else if (dtype == VVAE_DT_BF16) {
+        if (al && M % 8 == 0) hipLaunchKernelGGL((masked_mse_mae_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, gmse, gmae, (bf16_t*)drecon, T, P, video_div, epb);
+        else hipLaunchKernelGGL((masked_mse_mae_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, gmse, gmae, (bf16_t*)drecon, T, P, video_div, epb);
+    } else return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// *out (fp64, device) += sum g[i]^2.  Caller zeroes *out once, then calls this per flat gradient buffer.
+extern "C" int vvae_sqnorm_accum(const float* g, long n, double* out, void* stream)
+{
+    if (!g || !out || n <= 0 || ((uintptr_t)g % 16) != 0) return VVAE_ERR_BAD_ARG;
+    long blocks = n / 1024 + 1; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// One optimizer.update over a flat fp32 buffer.  gnorm_sq: device fp64 (sum of squares of the *unscaled* grads) or NULL (no clip).
+extern "C" int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_sq,
+                                   float gscale, float max_norm, float lr, float b1, float b2, float eps, long count, void* stream)
+{
+    if (!p || !g || !m || !v || n <= 0 || count < 1) return VVAE_ERR_BAD_ARG;
+    const float c1 = 1.f - powf(b1, (float)count), c2 = 1.f - powf(b2, (float)count);
+    long blocks = n / 1024 + 1; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n,
+                       gnorm_sq, gscale, max_norm, lr, b1, b2, eps, c1, c2);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stream)
+{
+    if (!x || !y || n <= 0) return VVAE_ERR_BAD_ARG;
+    long blocks = n / 1024 + 1; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,296 @@
+// Spatial max-pool (1,2,2) and ConvTranspose (1,2,2)/(1,2,2), channels-last, forward and backward.
+//
+// max-pool  : nnx.max_pool(x, (1,2,2), strides (1,2,2)) of DownBlock3D, /root/reference/train/unet.py:50.
+// convT     : nnx.ConvTranspose(kernel (1,2,2), strides (1,2,2), SAME) of UpBlock3D, unet.py:61-69,78.
+//             lax.conv_transpose does NOT flip the kernel, so out[2i+d] = x[i] * K[1-d] per spatial axis
+//             (SURVEY.md Appendix A.4): every input voxel owns a disjoint 2x2 output block.
+//
+// Pool is a pure HBM stream (16-byte vectors).  ConvTranspose is a pointwise GEMM + pixel-shuffle store on
+// the fp32 matrix cores (v_mfma_f32_16x16x4_f32), writing straight into a channel slice (row pitch ldy)
+// of the concat buffer so jnp.concatenate (unet.py:80) never materialises.
+#include "common.hpp"
+
+namespace {
+
+struct PoolDims { int NT; int H, W, C; };   // NT = n*t planes; H, W = input (full) resolution
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, PoolDims d)
+{
+    const int cvecs = d.C / VEC, Ho = d.H / 2, Wo = d.W / 2;
+    const long items = (long)d.NT * Ho * Wo * cvecs;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c0 = (int)(it % cvecs) * VEC; long q = it / cvecs;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho); const long p = q / Ho;
+        const long vi = (p * d.H + 2 * ho) * d.W + 2 * wo;
+        float a[VEC], b[VEC], c[VEC], e[VEC];
+        VecIO<T, VEC>::load(x + vi * ldx + c0, a);
+        VecIO<T, VEC>::load(x + (vi + 1) * ldx + c0, b);
+        VecIO<T, VEC>::load(x + (vi + d.W) * ldx + c0, c);
+        VecIO<T, VEC>::load(x + (vi + d.W + 1) * ldx + c0, e);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(c[i], e[i]));
+        VecIO<T, VEC>::store(y + ((p * Ho + ho) * Wo + wo) * ldy + c0, a);
+    }
+}
+
+// dx[v] = (dskip ? dskip[v] : 0) + (v is the first arg-max of its window ? dpool[window] : 0)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dpool, int lddp,
+                                                          const T* __restrict__ dskip, int ldds, T* __restrict__ dx, int lddx,
+                                                          PoolDims d)
+{
+    const int cvecs = d.C / VEC, Ho = d.H / 2, Wo = d.W / 2;
+    const long items = (long)d.NT * Ho * Wo * cvecs;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c0 = (int)(it % cvecs) * VEC; long q = it / cvecs;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho); const long p = q / Ho;
+        const long vi = (p * d.H + 2 * ho) * d.W + 2 * wo;
+        const long vs[4] = {vi, vi + 1, vi + d.W, vi + d.W + 1};
+        float in[4][VEC], g[VEC], out[4][VEC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) VecIO<T, VEC>::load(x + vs[k] * ldx + c0, in[k]);
+        VecIO<T, VEC>::load(dpool + ((p * Ho + ho) * Wo + wo) * lddp + c0, g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dskip) VecIO<T, VEC>::load(dskip + vs[k] * ldds + c0, out[k]);
+            else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) out[k][i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            int best = 0; float m = in[0][i];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (in[k][i] > m) { m = in[k][i]; best = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k == best) out[k][i] += g[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) VecIO<T, VEC>::store(dx + vs[k] * lddx + c0, out[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- ConvTranspose 1x2x2
+struct CtDims { int NT; int H, W, Cin, Cout; };   // H, W = input (low) resolution; output is 2H x 2W
+
+__device__ __forceinline__ long up_voxel(long v, int a, int b, int H, int W) {
+    const int w = (int)(v % W); const long q = v / W; const int h = (int)(q % H); const long p = q / H;
+    return (p * (2 * H) + 2 * h + a) * (2L * W) + 2 * w + b;
+}
+
+// MODE 0 (fwd)  : y[up(v,a,b)][co] = bias[co] + sum_ci x[v][ci] * K[1-a][1-b][ci][co]   (blockIdx.z = a*2+b)
+// MODE 1 (dgrad): dx[v][ci] = sum_{a,b,co} dy[up(v,a,b)][co] * K[1-a][1-b][ci][co]
+template <typename T, int MODE, int NT>
+__global__ __launch_bounds__(256) void convt_f32mfma_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ out, int ldout, CtDims d)
+{
+    const int CK = MODE == 0 ? d.Cin : d.Cout, CO = MODE == 0 ? d.Cout : d.Cin;
+    const long V = (long)d.NT * d.H * d.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    const long tile0 = ((long)blockIdx.x * 4 + wave) * 16;
+    const int o_base = blockIdx.y * NT * 16;
+    long v = tile0 + r;
+    const bool vvalid = v < V;
+    if (!vvalid) v = V - 1;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ab_lo = MODE == 0 ? blockIdx.z : 0, ab_hi = MODE == 0 ? blockIdx.z + 1 : 4;
+    for (int ab = ab_lo; ab < ab_hi; ++ab) {
+        const int a = ab >> 1, b = ab & 1;
+        const float* wt = w + (long)((1 - a) * 2 + (1 - b)) * d.Cin * d.Cout;
+        const T* row = MODE == 0 ? in + v * (long)ldin : in + up_voxel(v, a, b, d.H, d.W) * (long)ldin;
+        for (int k0 = 0; k0 < CK; k0 += 4) {
+            const int kk = k0 + kq; const bool kin = kk < CK;
+            const float av = (vvalid && kin) ? ldf(row + kk) : 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int o = o_base + i * 16 + r;
+                float bv = 0.f;
+                if (kin && o < CO) bv = MODE == 0 ? wt[(long)kk * d.Cout + o] : wt[(long)o * d.Cout + kk];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int o = o_base + i * 16 + r;
+        if (o >= CO) continue;
+        const float bb = (MODE == 0 && bias) ? bias[o] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long vo = tile0 + kq * 4 + j;
+            if (vo >= V) continue;
+            const long dst = MODE == 0 ? up_voxel(vo, blockIdx.z >> 1, blockIdx.z & 1, d.H, d.W) : vo;
+            stf(out + dst * (long)ldout + o, acc[i][j] + bb);
+        }
+    }
+}
+
+// dK[1-a][1-b][ci][co] += sum_v x[v][ci] * dy[up(v,a,b)][co]   grid: x = voxel chunk, y = ab, z = ci tile
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void convt_wgrad_f32mfma_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                                  float* __restrict__ dw, CtDims d, int co_tile_base, int voxels_per_block)
+{
+    __shared__ float red[4][NT][64][4];
+    const long V = (long)d.NT * d.H * d.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    const int a = blockIdx.y >> 1, b = blockIdx.y & 1;
+    const int tap = (1 - a) * 2 + (1 - b);
+    const int ci = blockIdx.z * 16 + r;
+    const long vbeg = (long)blockIdx.x * voxels_per_block;
+    long vend = vbeg + voxels_per_block;
+    if (vend > V) vend = V;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long v0 = vbeg + wave * 4; v0 < vend; v0 += 16) {
+        const long v = v0 + kq; const bool vok = v < vend; const long vc = vok ? v : vbeg;
+        const float av = (vok && ci < d.Cin) ? ldf(x + vc * (long)ldx + ci) : 0.f;
+        const T* dyrow = dy + up_voxel(vc, a, b, d.H, d.W) * (long)lddy;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int co = (co_tile_base + i) * 16 + r;
+            const float bv = (vok && co < d.Cout) ? ldf(dyrow + co) : 0.f;
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave][i][lane][j] = acc[i][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NT * 256; e += 256) {
+        const int i = e >> 8, l = (e >> 2) & 63, j = e & 3;
+        const float s = red[0][i][l][j] + red[1][i][l][j] + red[2][i][l][j] + red[3][i][l][j];
+        const int cii = blockIdx.z * 16 + (l >> 4) * 4 + j, co = (co_tile_base + i) * 16 + (l & 15);
+        if (cii < d.Cin && co < d.Cout) atomicAdd(dw + ((long)tap * d.Cin + cii) * d.Cout + co, s);
+    }
+}
+
+template <typename T> bool vec_ok2(const void* p, int ld, int C) {
+    constexpr int V = VecWidth<T>::value;
+    return C % V == 0 && ld % V == 0 && ((uintptr_t)p % 16) == 0;
+}
+
+template <typename T, int MODE>
+int launch_convt(const void* in, int ldin, const float* w, const float* bias, void* out, int ldout, CtDims d, hipStream_t s)
+{
+    const long V = (long)d.NT * d.H * d.W;
+    const int CO = MODE == 0 ? d.Cout : d.Cin;
+    const int tiles = ceil_div(CO, 16);
+    const int nt = tiles >= 8 ? 8 : tiles >= 4 ? 4 : tiles >= 2 ? 2 : 1;
+    dim3 grid(ceil_div(V, 64), ceil_div(tiles, nt), MODE == 0 ? 4 : 1);
+#define GO(NTV) hipLaunchKernelGGL((convt_f32mfma_kernel<T, MODE, NTV>), grid, dim3(256), 0, s, (const T*)in, ldin, w, bias, (T*)out, ldout, d)
+    switch (nt) { case 8: GO(8); break; case 4: GO(4); break; case 2: GO(2); break; default: GO(1); break; }
+#undef GO
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int launch_convt_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, CtDims d, hipStream_t s)
+{
+    const long V = (long)d.NT * d.H * d.W;
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 4 * (size_t)d.Cin * d.Cout, s);
+    if (e != hipSuccess) return (int)e;
+    const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
+    long want = 2048 / (4L * ci_tiles); if (want < 1) want = 1;
+    long vpb = (V + want - 1) / want; vpb = ((vpb + 15) / 16) * 16; if (vpb < 256) vpb = 256;
+    dim3 grid(ceil_div(V, vpb), 4, ci_tiles);
+    for (int base = 0; base < co_tiles;) {
+        const int rem = co_tiles - base;
+        const int nt = rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
+#define GO(NTV) hipLaunchKernelGGL((convt_wgrad_f32mfma_kernel<T, NTV>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy, dw, d, base, (int)vpb)
+        switch (nt) { case 8: GO(8); break; case 4: GO(4); break; case 2: GO(2); break; default: GO(1); break; }
+#undef GO
+        VVAE_LAUNCH_CHECK();
+        base += nt;
+    }
+    return 0;
+}
+
+}  // namespace
+
+#define POOL_DISPATCH(KERNEL, VOK, ...)                                                                       \
+    do {                                                                                                      \
+        if (dtype == VVAE_DT_F32) { typedef float T;                                                          \
+            if (VOK) hipLaunchKernelGGL((KERNEL<T, 4>), grid, dim3(256), 0, s, __VA_ARGS__);                  \
+            else hipLaunchKernelGGL((KERNEL<T, 1>), grid, dim3(256), 0, s, __VA_ARGS__);                      \
+        } else { typedef bf16_t T;                                                                            \
+            if (VOK) hipLaunchKernelGGL((KERNEL<T, 8>), grid, dim3(256), 0, s, __VA_ARGS__);                  \
+            else hipLaunchKernelGGL((KERNEL<T, 1>), grid, dim3(256), 0, s, __VA_ARGS__);                      \
+        }                                                                                                     \
+    } while (0)
+
+extern "C" int vvae_maxpool_1x2x2_fwd(const void* x, int ldx, void* y, int ldy, int NT, int H, int W, int C, int dtype, void* stream)
+{
+    if (!x || !y || NT <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || ldx < C || ldy < C ||
+        (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PoolDims d{NT, H, W, C};
+    const bool vok = dtype == VVAE_DT_F32 ? (vec_ok2<float>(x, ldx, C) && vec_ok2<float>(y, ldy, C))
+                                          : (vec_ok2<bf16_t>(x, ldx, C) && vec_ok2<bf16_t>(y, ldy, C));
+    const int vec = vok ? (dtype == VVAE_DT_F32 ? 4 : 8) : 1;
+    const long items = (long)NT * (H / 2) * (W / 2) * (C / vec);
+    dim3 grid((unsigned)(items / 256 + 1 > 8192 ? 8192 : items / 256 + 1));
+    POOL_DISPATCH(maxpool_fwd_kernel, vok, (const T*)x, ldx, (T*)y, ldy, d);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vvae_maxpool_1x2x2_bwd(const void* x, int ldx, const void* dpool, int lddp, const void* dskip, int ldds,
+                                      void* dx, int lddx, int NT, int H, int W, int C, int dtype, void* stream)
+{
+    if (!x || !dpool || !dx || NT <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || ldx < C || lddp < C ||
+        lddx < C || (dskip && ldds < C) || (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PoolDims d{NT, H, W, C};
+    bool vok;
+    if (dtype == VVAE_DT_F32)
+        vok = vec_ok2<float>(x, ldx, C) && vec_ok2<float>(dpool, lddp, C) && vec_ok2<float>(dx, lddx, C) && (!dskip || vec_ok2<float>(dskip, ldds, C));
+    else
+        vok = vec_ok2<bf16_t>(x, ldx, C) && vec_ok2<bf16_t>(dpool, lddp, C) && vec_ok2<bf16_t>(dx, lddx, C) && (!dskip || vec_ok2<bf16_t>(dskip, ldds, C));
+    const int vec = vok ? (dtype == VVAE_DT_F32 ? 4 : 8) : 1;
+    const long items = (long)NT * (H / 2) * (W / 2) * (C / vec);
+    dim3 grid((unsigned)(items / 256 + 1 > 8192 ? 8192 : items / 256 + 1));
+    POOL_DISPATCH(maxpool_bwd_kernel, vok, (const T*)x, ldx, (const T*)dpool, lddp, (const T*)dskip, ldds, (T*)dx, lddx, d);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// w: Flax ConvTranspose kernel (1,2,2,Cin,Cout) fp32.  y has spatial size 2H x 2W and row pitch ldy.
+extern "C" int vvae_convt_1x2x2_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                                    int NT, int H, int W, int Cin, int Cout, int dtype, void* stream)
+{
+    if (!x || !w || !y || NT <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldy < Cout) return VVAE_ERR_BAD_ARG;
+    CtDims d{NT, H, W, Cin, Cout};
+    if (dtype == VVAE_DT_F32) return launch_convt<float, 0>(x, ldx, w, bias, y, ldy, d, (hipStream_t)stream);
+    if (dtype == VVAE_DT_BF16) return launch_convt<bf16_t, 0>(x, ldx, w, bias, y, ldy, d, (hipStream_t)stream);
+    return VVAE_ERR_BAD_ARG;
+}
+
+extern "C" int vvae_convt_1x2x2_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx,
+                                      int NT, int H, int W, int Cin, int Cout, int dtype, void* stream)
+{
+    if (!dy || !w || !dx || NT <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || lddy < Cout || lddx < Cin) return VVAE_ERR_BAD_ARG;
+    CtDims d{NT, H, W, Cin, Cout};
+    if (dtype == VVAE_DT_F32) return launch_convt<float, 1>(dy, lddy, w, nullptr, dx, lddx, d, (hipStream_t)stream);
+    if (dtype == VVAE_DT_BF16) return launch_convt<bf16_t, 1>(dy, lddy, w, nullptr, dx, lddx, d, (hipStream_t)stream);
+    return VVAE_ERR_BAD_ARG;
+}
+
+// dw (1,2,2,Cin,Cout) fp32 overwritten.  (dbias = vvae_colsum(dy).)
+extern "C" int vvae_convt_1x2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw,
+                                      int NT, int H, int W, int Cin, int Cout, int dtype, void* stream)
+{
+    if (!x || !dy || !dw || NT <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || lddy < Cout) return VVAE_ERR_BAD_ARG;
+    CtDims d{NT, H, W, Cin, Cout};
+    if (dtype == VVAE_DT_F32) return launch_convt_wgrad<float>(x, ldx, dy, lddy, dw, d, (hipStream_t)stream);
+    if (dtype == VVAE_DT_BF16) return launch_convt_wgrad<bf16_t>(x, ldx, dy, lddy, dw, d, (hipStream_t)stream);
+    return VVAE_ERR_BAD_ARG;
+}

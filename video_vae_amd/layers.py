@@ -1,0 +1,225 @@
+"""Transformer-side layers with the reference's class surface (train/layers.py).
+
+Dense Linear / LayerNorm / spatial attention are glue on stock PyTorch-ROCm (hipBLASLt GEMMs, SDPA);
+the temporal attention core (q/k-norm + RoPE + masked softmax + PV over <= 64 frames) is the fused HIP
+kernel ``ops.temporal_attention_core``.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from einops import rearrange
+from torch import nn
+
+from . import ops
+from .rngs import truncated_normal_
+
+
+class Linear(nn.Module):
+    """nnx.Linear: y = x @ kernel + bias, kernel (in, out), lecun_normal init (variance_scaling(scale))."""
+
+    def __init__(self, in_features, out_features, rngs, dtype=torch.bfloat16, param_dtype=torch.float32, kernel_scale=1.0):
+        super().__init__()
+        k = truncated_normal_((in_features, out_features), in_features, rngs.params(), kernel_scale)
+        self.kernel = nn.Parameter(k.to(param_dtype))
+        self.bias = nn.Parameter(torch.zeros(out_features, dtype=param_dtype))
+        self.dtype = dtype
+
+    def forward(self, x):
+        x = x.to(self.dtype)
+        return torch.addmm(self.bias.to(self.dtype), x.reshape(-1, x.shape[-1]), self.kernel.to(self.dtype)).view(
+            *x.shape[:-1], self.kernel.shape[1])
+
+
+class LayerNorm(nn.Module):
+    """nnx.LayerNorm(eps=1e-6) over the last axis, fp32 statistics, optional bias."""
+
+    def __init__(self, num_features, dtype=torch.bfloat16, param_dtype=torch.float32, use_bias=True):
+        super().__init__()
+        self.scale = nn.Parameter(torch.ones(num_features, dtype=param_dtype))
+        self.bias = nn.Parameter(torch.zeros(num_features, dtype=param_dtype)) if use_bias else None
+        self.dtype = dtype
+
+    def forward(self, x):
+        x = x.to(self.dtype)
+        b = self.bias.to(self.dtype) if self.bias is not None else None
+        return F.layer_norm(x, (x.shape[-1],), self.scale.to(self.dtype), b, 1e-6)
+
+
+class PatchEmbedding(nn.Module):
+    """Reference train/layers.py:8-27: patchify -> LayerNorm -> Linear."""
+
+    def __init__(self, height, width, channels, patch_size, rngs, dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        self.patch_size = patch_size
+        self.dtype = dtype
+        d = patch_size * patch_size * channels
+        self.linear = Linear(d, d, rngs, dtype, param_dtype)
+        self.norm = LayerNorm(d, dtype, param_dtype)
+
+    def forward(self, x):
+        x = rearrange(x, "b t (h p1) (w p2) c -> b t (h w) (p1 p2 c)", p1=self.patch_size, p2=self.patch_size)
+        x = x.to(self.dtype)
+        return self.linear(self.norm(x))
+
+
+class PatchUnEmbedding(nn.Module):
+    """Reference train/layers.py:29-55 -> (conv features (b,t,H,W,c*u), coarse reconstruction (b,t,H,W,c))."""
+
+    def __init__(self, height, width, channels, patch_size, upsample_rate, rngs, dtype=torch.bfloat16,
+                 param_dtype=torch.float32):
+        super().__init__()
+        self.patch_size, self.height, self.width, self.upsample_rate = patch_size, height, width, upsample_rate
+        d = patch_size * patch_size * channels
+        self.upsample = Linear(d, d * upsample_rate, rngs, dtype, param_dtype)
+        self.downsample = Linear(channels * upsample_rate, channels, rngs, dtype, param_dtype)
+        self.linear = Linear(d, d, rngs, dtype, param_dtype)
+
+    def forward(self, x):
+        x = self.upsample(self.linear(x))
+        feat = rearrange(x, "b t (h w) (p1 p2 c u) -> b t (h p1) (w p2) (c u)", p1=self.patch_size, p2=self.patch_size,
+                         h=self.height // self.patch_size, w=self.width // self.patch_size, u=self.upsample_rate)
+        return feat, self.downsample(feat)
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class RotaryEmbedding(nn.Module):
+    """Reference train/layers.py:85-129: NTK base, cos/sin caches (max_len, head_dim), rotate-half convention."""
+
+    def __init__(self, head_dim, max_len=8192, alpha=1.0, base=10000.0):
+        super().__init__()
+        self.head_dim, self.max_len = head_dim, max_len
+        ntk_base = base * (alpha ** (head_dim / (head_dim - 2)))
+        inv_freq = 1.0 / (ntk_base ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+        freqs = torch.einsum("i,j->ij", torch.arange(max_len, dtype=torch.float32), inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        self.register_buffer("cos_cached", torch.cos(emb).contiguous(), persistent=False)
+        self.register_buffer("sin_cached", torch.sin(emb).contiguous(), persistent=False)
+
+    def rotate_queries_and_keys(self, q, k):
+        s = q.shape[1]
+        cos = self.cos_cached[:s].to(q.dtype)[None, :, None, :]
+        sin = self.sin_cached[:s].to(q.dtype)[None, :, None, :]
+        return q * cos + rotate_half(q) * sin, k * cos + rotate_half(k) * sin
+
+
+FUSED_CORE_MAX_SEQ = 64
+
+
+class Attention(nn.Module):
+    """Reference train/layers.py:131-171.  x (a, seq, dim); mask bool (a|b,1,1,seq) True = attend, or None."""
+
+    def __init__(self, in_features, num_heads, qkv_features, max_len, use_qk_norm, rngs, dtype=torch.bfloat16,
+                 param_dtype=torch.float32):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = qkv_features // num_heads
+        self.qkv_projection = Linear(in_features, qkv_features * 3, rngs, dtype, param_dtype)
+        self.out_projection = Linear(qkv_features, in_features, rngs, dtype, param_dtype, kernel_scale=1e-2)
+        self.input_norm = LayerNorm(in_features, dtype, param_dtype)
+        self.ROPE = RotaryEmbedding(head_dim=head_dim, max_len=max_len)
+        self.use_qk_norm = use_qk_norm      # legacy flag in the reference; q/k norm is always applied
+        self.q_norm = LayerNorm(head_dim, dtype, param_dtype, use_bias=False)
+        self.k_norm = LayerNorm(head_dim, dtype, param_dtype, use_bias=False)
+
+    def forward(self, x, mask=None):
+        x = self.input_norm(x)
+        qkv = self.qkv_projection(x)
+        a, s, _ = qkv.shape
+        if s <= FUSED_CORE_MAX_SEQ:
+            # temporal half: fused HIP core (no fallback: raises off-GPU)
+            m8, div = None, 1
+            if mask is not None:
+                m8 = mask.reshape(-1, s).to(torch.uint8).contiguous()
+                div = a // m8.shape[0]
+            o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached,
+                                            self.ROPE.sin_cached, m8, div, self.num_heads, 1e-6)
+        else:
+            q, k, v = torch.chunk(qkv, 3, dim=-1)
+            q = rearrange(q, "b s (h d) -> b s h d", h=self.num_heads)
+            k = rearrange(k, "b s (h d) -> b s h d", h=self.num_heads)
+            v = rearrange(v, "b s (h d) -> b s h d", h=self.num_heads)
+            q, k = self.ROPE.rotate_queries_and_keys(self.q_norm(q), self.k_norm(k))
+            am = None
+            if mask is not None:
+                am = mask.to(torch.bool).expand(a, 1, 1, s) if mask.shape[0] == a else \
+                    mask.to(torch.bool).repeat_interleave(a // mask.shape[0], dim=0)
+            o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=am)
+            o = rearrange(o, "b h s d -> b s (h d)")
+        return self.out_projection(o)
+
+
+class MLP(nn.Module):
+    """Reference train/layers.py:174-196: LN -> Linear -> SiLU -> Linear (small-init)."""
+
+    def __init__(self, in_features, mlp_dim, rngs, dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        self.norm = LayerNorm(in_features, dtype, param_dtype)
+        self.linear1 = Linear(in_features, mlp_dim, rngs, dtype, param_dtype)
+        self.linear2 = Linear(mlp_dim, in_features, rngs, dtype, param_dtype, kernel_scale=1e-2)
+
+    def forward(self, x):
+        return self.linear2(F.silu(self.linear1(self.norm(x))))
+
+
+class FactoredAttention(nn.Module):
+    """Reference train/layers.py:198-224: temporal attn+MLP on (b*hw, t, c), then spatial attn+MLP on (b*t, hw, c).
+
+    ``temporal_mask`` is (b*hw,1,1,t) as train_step builds it (rl_nonadversarial.py:190-192); the (b,1,1,t) form of
+    claude_distributed/layers.py:213-214 is accepted too.
+    """
+
+    def __init__(self, mlp_dim, in_features, num_heads, qkv_features, max_temporal_len, max_spatial_len, rngs,
+                 dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        self.SpatialAttention = Attention(in_features, num_heads, qkv_features, max_spatial_len, True, rngs, dtype, param_dtype)
+        self.SpatialMLP = MLP(in_features, mlp_dim, rngs, dtype, param_dtype)
+        self.TemporalAttention = Attention(in_features, num_heads, qkv_features, max_temporal_len, False, rngs, dtype, param_dtype)
+        self.TemporalMLP = MLP(in_features, mlp_dim, rngs, dtype, param_dtype)
+
+    def forward(self, x, temporal_mask):
+        b, t, hw, c = x.shape
+        tx = rearrange(x, "b t hw c -> (b hw) t c")
+        tx = tx + self.TemporalAttention(tx, mask=temporal_mask)
+        tx = tx + self.TemporalMLP(tx)
+        x = rearrange(tx, "(b hw) t c -> b t hw c", b=b, hw=hw)
+        sx = rearrange(x, "b t hw c -> (b t) hw c")
+        sx = sx + self.SpatialAttention(sx)
+        sx = sx + self.SpatialMLP(sx)
+        return rearrange(sx, "(b t) hw c -> b t hw c", b=b, t=t)
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return torch.round(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_ste(logits):
+    """round forward, identity backward (reference train/layers.py:226-236)."""
+    return _RoundSTE.apply(logits)
+
+
+class GumbelSigmoidSTE(nn.Module):
+    """Reference train/layers.py:238-252."""
+
+    def __init__(self, temperature=1.0):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, logits, rngs, train=True):
+        if train:
+            eps = 1e-20
+            u = rngs.draw("gumbel_u", "uniform", logits.shape, logits.device)
+            u = torch.clamp(u, eps, 1.0 - eps)
+            noise = torch.log(u / (1 - u))
+            return round_ste(torch.sigmoid((logits + noise) / self.temperature))
+        return torch.round(torch.sigmoid(logits / self.temperature))

@@ -1,0 +1,125 @@
+"""recon+KL losses and the train / eval step, counterparts of the reference's drivers.
+
+``loss_fn``        : train/rl_nonadversarial.py:100-186 (pair-doubled rl_model outputs, REINFORCE term).
+``loss_fn_plain``  : train/legacy/training_loop_adversarial.py:90-124 (model.py outputs: MSE + selection + KL).
+The heavy reductions (masked MSE/MAE over the clip, KL over the latent) are fused HIP kernels; the per-sample
+scalar algebra stays in torch.  The VGG16 perceptual term needs remote weights and is out of scope: callers pass
+``perceptual_loss_fn=None`` (zeros), as the reference's CPU test does (claude_distributed/test_training_loop.py:71).
+"""
+import torch
+from einops import rearrange, reduce, repeat
+
+from . import ops
+
+HPARAMS = {  # train/rl_nonadversarial.py:46-57,255-263
+    "gamma1": 0.2, "gamma2": 0.001, "gamma3": 0.1, "gamma4": 0.05,
+    "max_compression_rate": 2, "magnify_negatives_rate": 100, "rl_loss_weight": 0.01,
+}
+
+
+def per_sample_mean(x):
+    return x.mean(dim=tuple(range(1, x.ndim)))
+
+
+def magnify_negatives(x, magnification_rate):
+    return torch.where(x < 0, x * magnification_rate, x)
+
+
+def expand_mask(mask, hw):
+    """(b, t) -> (b*hw, 1, 1, t), as train_step does (rl_nonadversarial.py:190-192)."""
+    mask = rearrange(mask, "b time -> b 1 1 time")
+    mask = repeat(mask, "b 1 1 time -> b hw 1 1 time", hw=hw)
+    return rearrange(mask, "b hw 1 1 time -> (b hw) 1 1 time")
+
+
+def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn=None, vgg_params=None, train=True):
+    reconstruction, _comp, selection, selection_mask, logvar, mean = model(video, mask, rngs, train=train)
+    output_mask = original_mask.to(torch.float32).repeat_interleave(2, dim=0)
+    sequence_lengths = torch.clamp(reduce(output_mask, "b time -> b 1", "sum"), min=1.0)
+
+    per_sample_error, per_sample_MAE = ops.masked_mse_mae(video, reconstruction, output_mask, video_div=2)
+    if perceptual_loss_fn is None:
+        perceptual_loss = torch.zeros_like(per_sample_error)
+    else:
+        perceptual_loss = perceptual_loss_fn(vgg_params, reconstruction, video.repeat_interleave(2, dim=0))
+
+    kl_and_selection_mask = rearrange(output_mask, "b time -> b time 1 1")
+    selection_sum = reduce(selection_mask * kl_and_selection_mask, "b time 1 1 -> b 1", "sum")
+    kept_frame_density = selection_sum / sequence_lengths
+    density_compression_difference = kept_frame_density - (1 / hparams["max_compression_rate"])
+    selection_loss = per_sample_mean(torch.square(
+        magnify_negatives(density_compression_difference, hparams["magnify_negatives_rate"])))
+
+    kl_loss = ops.kl_per_sample(mean, logvar, output_mask)
+
+    per_sample_loss = (per_sample_error + hparams["gamma3"] * perceptual_loss + hparams["gamma1"] * selection_loss
+                       + hparams["gamma2"] * kl_loss + hparams["gamma4"] * per_sample_MAE)
+    pairs = rearrange(per_sample_loss, "(b p) -> b p", p=2)
+    means = rearrange(per_sample_mean(pairs), "b -> b 1")
+    stds = rearrange(pairs.std(dim=1, unbiased=False) + 1e-6, "b -> b 1")
+    disadvantages = (pairs - means) / stds
+    actions = rearrange(selection_mask, "(b p) time 1 1 -> b p time", p=2)
+    selection = rearrange(selection, "(b p) time 1 1 -> b p time", p=2).float()
+    raw_probs = torch.clamp(torch.abs(selection + actions - 1), 1e-6, 1.0 - 1e-6)
+    probs = raw_probs / raw_probs.detach()
+    rl_mask = rearrange(output_mask, "(b p) time -> b p time", p=2) > 0
+    one = torch.ones((), device=probs.device, dtype=probs.dtype)
+    probs = torch.where(rl_mask, probs, one)
+    raw_trajectory_probs = torch.where(rl_mask, raw_probs, one).prod(dim=2, keepdim=True)
+    probs = probs.prod(dim=2, keepdim=True)
+    rl_loss = probs * rearrange(disadvantages, "b p -> b p 1").detach()
+    loss = per_sample_loss.mean() + rl_loss.mean() * hparams["rl_loss_weight"]
+    return loss, {
+        "MSE": per_sample_error.mean(), "perceptual_loss": perceptual_loss.mean(), "selection_loss": selection_loss.mean(),
+        "kl_loss": kl_loss.mean(), "reconstruction": reconstruction, "kept_frame_density": kept_frame_density.mean(),
+        "mean_trajectory_prob": raw_trajectory_probs.mean(), "rl_loss": rl_loss.mean(), "per_sample_MAE": per_sample_MAE.mean(),
+    }
+
+
+def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
+    reconstruction, _comp, selection, logvar, mean = model(video, mask, rngs, train=train)
+    om = original_mask.to(torch.float32)
+    sequence_lengths = torch.clamp(reduce(om, "b time -> b 1", "sum"), min=1.0)
+    mse_ps, _ = ops.masked_mse_mae(video, reconstruction, om, video_div=1)
+    MSE = mse_ps.mean()
+    kl_and_selection_mask = rearrange(om, "b time -> b time 1 1")
+    selection_sum = reduce(selection * kl_and_selection_mask, "b time 1 1 -> b 1", "sum")
+    kept_frame_density = selection_sum / sequence_lengths
+    diff = kept_frame_density - (1 / hparams["max_compression_rate"])
+    selection_loss = torch.square(magnify_negatives(diff, hparams["magnify_negatives_rate"])).mean()
+    kl_loss = ops.kl_per_sample(mean, logvar, om).mean()
+    loss = MSE + hparams["gamma1"] * selection_loss + hparams["gamma2"] * kl_loss
+    return loss, {"MSE": MSE, "selection_loss": selection_loss, "kl_loss": kl_loss, "reconstruction": reconstruction,
+                  "kept_frame_density": kept_frame_density.mean()}
+
+
+def _is_rl(model):
+    return getattr(model.encoder, "flavour", "model") == "rl"
+
+
+def train_step(model, optimizer, video, mask, hparams, hw, rngs, perceptual_loss_fn=None, vgg_params=None):
+    """Counterpart of train_step (rl_nonadversarial.py:188-198): fwd + bwd + optimizer.update.
+
+    ``optimizer`` is a ``video_vae_amd.optim.Optimizer``; with a DDP-wrapped model the gradient all-reduce
+    overlaps this backward (see ddp.py).
+    """
+    original_mask = mask.clone()
+    emask = expand_mask(mask, hw)
+    optimizer.zero_grad()
+    if _is_rl(model):
+        loss, aux = loss_fn(model, video, emask, original_mask, rngs, hparams, perceptual_loss_fn, vgg_params)
+    else:
+        loss, aux = loss_fn_plain(model, video, emask, original_mask, rngs, hparams)
+    loss.backward()
+    optimizer.update()
+    return loss.detach(), aux
+
+
+@torch.no_grad()
+def eval_step(model, video, mask, hparams, hw, rngs, perceptual_loss_fn=None, vgg_params=None):
+    """eval_step calls the loss with train=True on purpose (rl_nonadversarial.py:200-208)."""
+    original_mask = mask.clone()
+    emask = expand_mask(mask, hw)
+    if _is_rl(model):
+        return loss_fn(model, video, emask, original_mask, rngs, hparams, perceptual_loss_fn, vgg_params, train=True)
+    return loss_fn_plain(model, video, emask, original_mask, rngs, hparams, train=True)

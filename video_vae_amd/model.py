@@ -1,0 +1,101 @@
+"""Encoder / Decoder / VideoVAE with the surface of the reference's train/model.py (5-tuple, Gumbel-STE gate)."""
+import torch
+import torch.nn.functional as F
+from einops import rearrange
+from torch import nn
+
+from . import ops
+from .layers import PatchEmbedding, FactoredAttention, GumbelSigmoidSTE, PatchUnEmbedding, Linear
+from .rngs import Rngs
+from .unet import UNet
+
+
+class Encoder(nn.Module):
+    """Reference train/model.py:14-60 -> (mean, log_variance, selection (b,t,1,1) in {0,1})."""
+
+    flavour = "model"
+
+    def __init__(self, height, width, channels, patch_size, depth, mlp_dim, num_heads, qkv_features, max_temporal_len,
+                 spatial_compression_rate, rngs, dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        max_spatial_len = height // patch_size * width // patch_size
+        self.last_dim = channels * patch_size * patch_size
+        self.dtype = dtype
+        self.patch_embedding = PatchEmbedding(height, width, channels, patch_size, rngs, dtype, param_dtype)
+        ld = self.last_dim // spatial_compression_rate
+        self.spatial_compression = Linear(self.last_dim, ld, rngs, dtype, param_dtype)
+        self.variance_estimator = Linear(self.last_dim, ld, rngs, dtype, param_dtype)
+        self.selection_layer1 = Linear(ld, 1, rngs, dtype, param_dtype)
+        self.selection_layer2 = Linear(max_spatial_len, 1, rngs, dtype, param_dtype)
+        self.gumbel_sigmoid = GumbelSigmoidSTE(temperature=1.0)
+        self.layers = nn.ModuleList([
+            FactoredAttention(mlp_dim, self.last_dim, num_heads, qkv_features, max_temporal_len, max_spatial_len, rngs,
+                              dtype, param_dtype) for _ in range(depth)])
+
+    def _trunk(self, x, mask):
+        x = self.patch_embedding(x)
+        for layer in self.layers:
+            x = layer(x, mask)
+        mean = self.spatial_compression(x)
+        variance = F.softplus(self.variance_estimator(x))
+        log_variance = torch.log(variance)
+        si = rearrange(self.selection_layer1(mean), "b t hw 1 -> b t hw")
+        return mean, log_variance, self.selection_layer2(si) + 1
+
+    def forward(self, x, mask, rngs, train=True):
+        mean, log_variance, logits = self._trunk(x, mask)
+        selection = self.gumbel_sigmoid(logits.float(), rngs, train=train)
+        return mean, log_variance, rearrange(selection, "b t 1 -> b t 1 1")
+
+
+class Decoder(nn.Module):
+    """Reference train/model.py:62-97: Linear -> depth x FactoredAttention -> un-patchify -> coarse + UNet(features)."""
+
+    def __init__(self, height, width, channels, patch_size, depth, mlp_dim, num_heads, qkv_features, max_temporal_len,
+                 spatial_compression_rate, unembedding_upsample_rate, rngs, dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        self.last_dim = channels * patch_size * patch_size
+        self.dtype = dtype
+        self.patch_unembedding = PatchUnEmbedding(height, width, channels, patch_size, unembedding_upsample_rate, rngs,
+                                                  dtype, param_dtype)
+        self.spatial_decompression = Linear(self.last_dim // spatial_compression_rate, self.last_dim, rngs, dtype, param_dtype)
+        max_spatial_len = height // patch_size * width // patch_size
+        self.layers = nn.ModuleList([
+            FactoredAttention(mlp_dim, self.last_dim, num_heads, qkv_features, max_temporal_len, max_spatial_len, rngs,
+                              dtype, param_dtype) for _ in range(depth)])
+        self.unet = UNet(channels=channels * unembedding_upsample_rate, base_features=16, num_levels=3,
+                         out_features=channels, rngs=rngs, dtype=dtype, param_dtype=param_dtype)
+
+    def forward(self, x, mask, rngs, train=True):
+        x = self.spatial_decompression(x)
+        for layer in self.layers:
+            x = layer(x, mask)
+        feat, x = self.patch_unembedding(x)
+        return x + self.unet(feat)
+
+
+class VideoVAE(nn.Module):
+    """Reference train/model.py:101-136 -> (reconstruction, compressed_representation, selection, log_variance, mean)."""
+
+    def __init__(self, height, width, channels, patch_size, encoder_depth, decoder_depth, mlp_dim, num_heads, qkv_features,
+                 max_temporal_len, spatial_compression_rate, unembedding_upsample_rate, rngs, dtype=torch.bfloat16,
+                 param_dtype=torch.float32):
+        super().__init__()
+        key = rngs.sampling()
+        self.encoder = Encoder(height, width, channels, patch_size, encoder_depth, mlp_dim, num_heads, qkv_features,
+                               max_temporal_len, spatial_compression_rate, rngs, dtype, param_dtype)
+        self.decoder = Decoder(height, width, channels, patch_size, decoder_depth, mlp_dim, num_heads, qkv_features,
+                               max_temporal_len, spatial_compression_rate, unembedding_upsample_rate, rngs, dtype, param_dtype)
+        ld = channels * patch_size * patch_size // spatial_compression_rate
+        self.fill_token = nn.Parameter(torch.randn((1, 1, 1, ld), generator=key.generator("cpu")) * 0.02)
+
+    def forward(self, x, mask, rngs, train=True):
+        mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
+        if train:
+            noise = rngs.draw("reparam_eps", "normal", log_variance.shape, log_variance.device)
+            sampled_latent = ops.reparameterise(mean, log_variance, noise)
+        else:
+            sampled_latent = mean
+        compressed_representation = self.fill_token * (1 - selection) + sampled_latent * selection
+        reconstruction = self.decoder(compressed_representation, mask, rngs, train=train)
+        return reconstruction, compressed_representation, selection, log_variance, mean

@@ -1,0 +1,419 @@
+"""torch.autograd.Function wrappers over the C ABI (include/vvae_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every op below
+runs a hand-written HIP kernel from libvvae_hip.so on the current stream.
+Tensors must live on a GPU -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, check, VvaeError
+
+DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if not t.is_cuda:
+        raise VvaeError("video_vae_amd ops need GPU tensors (no CPU fallback); got device " + str(t.device))
+    if t.dtype not in DT:
+        raise VvaeError(f"unsupported activation dtype {t.dtype} (float32 or bfloat16)")
+    return DT[t.dtype]
+
+
+def rows(t):
+    """(tensor, row pitch) with the tensor usable as (rows, C) with a uniform pitch; copies only if it must."""
+    if t.dim() < 2:
+        raise VvaeError("need at least 2 dims")
+    ok = t.stride(-1) == 1 and t.stride(-2) >= t.size(-1)
+    if ok:
+        for i in range(t.dim() - 2):
+            if t.size(i) != 1 and t.stride(i) != t.stride(i + 1) * t.size(i + 1):
+                ok = False
+                break
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(-2)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ws(nbytes, device):
+    if nbytes == 0:
+        return None, 0
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf, nbytes
+
+
+# --------------------------------------------------------------------------------------------- Conv3d
+def conv3d_fwd_raw(x, kernel, bias, out=None):
+    x, ldx = rows(x)
+    n, t, h, w, cin = x.shape
+    kt, kh, kw, cin2, cout = kernel.shape
+    assert cin == cin2, (cin, cin2)
+    if out is None:
+        out = torch.empty((n, t, h, w, cout), dtype=x.dtype, device=x.device)
+    ldy = out.stride(-2)
+    dt = _dt(x)
+    wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 0)
+    ws, wsb = _ws(wsb, x.device)
+    check(lib().vvae_conv3d_fwd(_p(x), ldx, _p(kernel), _p(bias), _p(out), ldy, n, t, h, w, cin, cout, kt, kh, kw, dt,
+                                _p(ws), wsb, _stream()), "vvae_conv3d_fwd")
+    return out
+
+
+def conv3d_dgrad_raw(dy, kernel, out=None):
+    dy, lddy = rows(dy)
+    n, t, h, w, cout = dy.shape
+    kt, kh, kw, cin, cout2 = kernel.shape
+    assert cout == cout2
+    if out is None:
+        out = torch.empty((n, t, h, w, cin), dtype=dy.dtype, device=dy.device)
+    dt = _dt(dy)
+    wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 1)
+    ws, wsb = _ws(wsb, dy.device)
+    check(lib().vvae_conv3d_dgrad(_p(dy), lddy, _p(kernel), _p(out), out.stride(-2), n, t, h, w, cin, cout, kt, kh, kw, dt,
+                                  _p(ws), wsb, _stream()), "vvae_conv3d_dgrad")
+    return out
+
+
+def conv3d_wgrad_raw(x, dy, kshape, want_bias=True):
+    x, ldx = rows(x)
+    dy, lddy = rows(dy)
+    n, t, h, w, cin = x.shape
+    kt, kh, kw, _, cout = kshape
+    dw = torch.empty(kshape, dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dt = _dt(x)
+    wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 2)
+    ws, wsb = _ws(wsb, x.device)
+    check(lib().vvae_conv3d_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), _p(db), n, t, h, w, cin, cout, kt, kh, kw, dt,
+                                  _p(ws), wsb, _stream()), "vvae_conv3d_wgrad")
+    return dw, db
+
+
+class _Conv3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        k32 = _f32(kernel)
+        b32 = _f32(bias) if bias is not None else None
+        ctx.save_for_backward(x, k32)
+        ctx.has_bias = bias is not None
+        ctx.kdtype = kernel.dtype
+        return conv3d_fwd_raw(x, k32, b32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, k32 = ctx.saved_tensors
+        dy = dy.to(x.dtype)
+        dx = conv3d_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv3d_wgrad_raw(x, dy, tuple(k32.shape), ctx.has_bias)
+            dw = dw.to(ctx.kdtype)
+        return dx, dw, db
+
+
+def conv3d(x, kernel, bias=None):
+    """NDHWC Conv3d, SAME, stride 1 (nnx.Conv; reference train/unet.py:13-21)."""
+    return _Conv3d.apply(x, kernel, bias)
+
+
+# --------------------------------------------------------------------------------------------- GroupNorm + SiLU
+def gn_stats_raw(x, groups):
+    x, ldx = rows(x)
+    n, c = x.shape[0], x.shape[-1]
+    s = x.numel() // (n * c)
+    sums = torch.empty((n, groups, 2), dtype=torch.float64, device=x.device)
+    check(lib().vvae_gn_stats(_p(x), ldx, n, s, c, groups, _p(sums), _dt(x), _stream()), "vvae_gn_stats")
+    return sums
+
+
+def gn_silu_fwd_raw(x, sums, scale, bias, groups, eps, out=None):
+    x, ldx = rows(x)
+    n, c = x.shape[0], x.shape[-1]
+    s = x.numel() // (n * c)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(lib().vvae_gn_silu_fwd(_p(x), ldx, _p(out), out.stride(-2), _p(sums), _p(scale), _p(bias), n, s, c, groups, eps,
+                                 _dt(x), _stream()), "vvae_gn_silu_fwd")
+    return out
+
+
+def gn_silu_bwd_raw(x, dy, sums, scale, bias, groups, eps, out=None):
+    x, ldx = rows(x)
+    dy, lddy = rows(dy)
+    n, c = x.shape[0], x.shape[-1]
+    s = x.numel() // (n * c)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    csum = torch.empty((n, c, 2), dtype=torch.float64, device=x.device)
+    dg = torch.empty((c,), dtype=torch.float32, device=x.device)
+    db = torch.empty((c,), dtype=torch.float32, device=x.device)
+    check(lib().vvae_gn_silu_bwd(_p(x), ldx, _p(dy), lddy, _p(out), out.stride(-2), _p(sums), _p(scale), _p(bias), _p(csum),
+                                 _p(dg), _p(db), n, s, c, groups, eps, _dt(x), _stream()), "vvae_gn_silu_bwd")
+    return out, dg, db
+
+
+class _GnSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, bias, groups, eps):
+        s32, b32 = _f32(scale), _f32(bias)
+        sums = gn_stats_raw(x, groups)
+        ctx.save_for_backward(x, sums, s32, b32)
+        ctx.groups, ctx.eps, ctx.pdtype = groups, eps, scale.dtype
+        return gn_silu_fwd_raw(x, sums, s32, b32, groups, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sums, s32, b32 = ctx.saved_tensors
+        dx, dg, db = gn_silu_bwd_raw(x, dy.to(x.dtype), sums, s32, b32, ctx.groups, ctx.eps)
+        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None
+
+
+def group_norm_silu(x, scale, bias, groups, eps=1e-6):
+    """silu(GroupNorm(x)) over (t,h,w,C/G) per sample (reference train/unet.py:22-23,28-29)."""
+    return _GnSilu.apply(x, scale, bias, groups, eps)
+
+
+# --------------------------------------------------------------------------------------------- max-pool (1,2,2)
+def maxpool_fwd_raw(x, out=None):
+    x, ldx = rows(x)
+    n, t, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, t, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    check(lib().vvae_maxpool_1x2x2_fwd(_p(x), ldx, _p(out), out.stride(-2), n * t, h, w, c, _dt(x), _stream()),
+          "vvae_maxpool_1x2x2_fwd")
+    return out
+
+
+def maxpool_bwd_raw(x, dpool, dskip=None, out=None):
+    x, ldx = rows(x)
+    dpool, lddp = rows(dpool)
+    ldds = 0
+    if dskip is not None:
+        dskip, ldds = rows(dskip)
+    n, t, h, w, c = x.shape
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(lib().vvae_maxpool_1x2x2_bwd(_p(x), ldx, _p(dpool), lddp, _p(dskip), ldds, _p(out), out.stride(-2), n * t, h, w, c,
+                                       _dt(x), _stream()), "vvae_maxpool_1x2x2_bwd")
+    return out
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return maxpool_fwd_raw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return maxpool_bwd_raw(x, dy.to(x.dtype))
+
+
+def max_pool_1x2x2(x):
+    """nnx.max_pool(x, (1,2,2), strides=(1,2,2)) (reference train/unet.py:50)."""
+    return _MaxPool.apply(x)
+
+
+# --------------------------------------------------------------------------------------------- ConvTranspose (1,2,2)
+def convt_fwd_raw(x, kernel, bias, out=None):
+    x, ldx = rows(x)
+    n, t, h, w, cin = x.shape
+    cout = kernel.shape[-1]
+    if out is None:
+        out = torch.empty((n, t, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device)
+    check(lib().vvae_convt_1x2x2_fwd(_p(x), ldx, _p(kernel), _p(bias), _p(out), out.stride(-2), n * t, h, w, cin, cout,
+                                     _dt(x), _stream()), "vvae_convt_1x2x2_fwd")
+    return out
+
+
+def convt_dgrad_raw(dy, kernel, out=None):
+    dy, lddy = rows(dy)
+    n, t, h2, w2, cout = dy.shape
+    cin = kernel.shape[-2]
+    if out is None:
+        out = torch.empty((n, t, h2 // 2, w2 // 2, cin), dtype=dy.dtype, device=dy.device)
+    check(lib().vvae_convt_1x2x2_dgrad(_p(dy), lddy, _p(kernel), _p(out), out.stride(-2), n * t, h2 // 2, w2 // 2, cin, cout,
+                                       _dt(dy), _stream()), "vvae_convt_1x2x2_dgrad")
+    return out
+
+
+def convt_wgrad_raw(x, dy, kshape):
+    x, ldx = rows(x)
+    dy, lddy = rows(dy)
+    n, t, h, w, cin = x.shape
+    cout = kshape[-1]
+    dw = torch.empty(kshape, dtype=torch.float32, device=x.device)
+    check(lib().vvae_convt_1x2x2_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), n * t, h, w, cin, cout, _dt(x), _stream()),
+          "vvae_convt_1x2x2_wgrad")
+    return dw
+
+
+def colsum_raw(x):
+    x, ld = rows(x)
+    c = x.shape[-1]
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    check(lib().vvae_colsum(_p(x), ld, x.numel() // c, c, _p(out), _dt(x), _stream()), "vvae_colsum")
+    return out
+
+
+class _ConvT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        k32, b32 = _f32(kernel), _f32(bias)
+        ctx.save_for_backward(x, k32)
+        ctx.kdtype = kernel.dtype
+        return convt_fwd_raw(x, k32, b32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, k32 = ctx.saved_tensors
+        dy = dy.to(x.dtype)
+        dx = convt_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
+        dw = convt_wgrad_raw(x, dy, tuple(k32.shape)).to(ctx.kdtype)
+        db = colsum_raw(dy).to(ctx.kdtype)
+        return dx, dw, db
+
+
+def conv_transpose_1x2x2(x, kernel, bias):
+    """nnx.ConvTranspose((1,2,2), strides (1,2,2)) (reference train/unet.py:61-69)."""
+    return _ConvT.apply(x, kernel, bias)
+
+
+# --------------------------------------------------------------------------------------------- temporal attention core
+class _TemporalAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, q_scale, k_scale, cos, sin, mask, mask_div, heads, eps):
+        qkv, ld = rows(qkv)
+        a, t, c3 = qkv.shape
+        d = c3 // (3 * heads)
+        qs, ks = _f32(q_scale), _f32(k_scale)
+        out = torch.empty((a, t, heads * d), dtype=qkv.dtype, device=qkv.device)
+        check(lib().vvae_temporal_attn_fwd(_p(qkv), ld, _p(out), heads * d, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div,
+                                           a, t, heads, d, eps, _dt(qkv), _stream()), "vvae_temporal_attn_fwd")
+        ctx.save_for_backward(qkv, qs, ks, cos, sin, mask)
+        ctx.args = (mask_div, heads, eps, q_scale.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qs, ks, cos, sin, mask = ctx.saved_tensors
+        mask_div, heads, eps, pdtype = ctx.args
+        qkv, ld = rows(qkv)
+        do, lddo = rows(do.to(qkv.dtype))
+        a, t, c3 = qkv.shape
+        d = c3 // (3 * heads)
+        dqkv = torch.empty((a, t, c3), dtype=qkv.dtype, device=qkv.device)
+        dqs = torch.empty((d,), dtype=torch.float32, device=qkv.device)
+        dks = torch.empty((d,), dtype=torch.float32, device=qkv.device)
+        check(lib().vvae_temporal_attn_bwd(_p(qkv), ld, _p(do), lddo, _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask),
+                                           mask_div, _p(dqs), _p(dks), a, t, heads, d, eps, _dt(qkv), _stream()),
+              "vvae_temporal_attn_bwd")
+        return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None, None, None
+
+
+def temporal_attention_core(qkv, q_scale, k_scale, cos, sin, mask_u8, mask_div, heads, eps=1e-6):
+    """q_norm/k_norm -> RoPE -> masked softmax(QK^T/sqrt(D)) V on (A, T, 3*heads*D) (reference train/layers.py:159-170).
+
+    mask_u8: uint8 (ceil(A/mask_div), T), 1 = attend, or None.  cos/sin: fp32 (>=T, D) RoPE tables.
+    """
+    return _TemporalAttn.apply(qkv, q_scale, k_scale, cos, sin, mask_u8, mask_div, heads, eps)
+
+
+# --------------------------------------------------------------------------------------------- reparameterise + KL
+class _ReparamKl(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, logvar, eps, mask, want_z, want_kl):
+        mean, logvar = mean.contiguous(), logvar.contiguous()
+        b, t = mean.shape[0], mean.shape[1]
+        per = mean.numel() // (b * t)
+        z = torch.empty(mean.shape, dtype=torch.float32, device=mean.device) if want_z else None
+        kl = torch.empty((b,), dtype=torch.float32, device=mean.device) if want_kl else None
+        eps = eps.to(torch.float32).contiguous() if eps is not None else None
+        mask = mask.to(torch.float32).contiguous() if mask is not None else None
+        check(lib().vvae_reparam_kl_fwd(_p(mean), _p(logvar), _p(eps), _p(mask), _p(z), _p(kl), b, t, per, _dt(mean), _stream()),
+              "vvae_reparam_kl_fwd")
+        ctx.save_for_backward(mean, logvar, eps, mask)
+        ctx.flags = (want_z, want_kl)
+        outs = tuple(o for o in (z, kl) if o is not None)
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        mean, logvar, eps, mask = ctx.saved_tensors
+        want_z, want_kl = ctx.flags
+        grads = list(grads)
+        dz = grads.pop(0) if want_z else None
+        gkl = grads.pop(0) if want_kl else None
+        dz = dz.to(torch.float32).contiguous() if dz is not None else None
+        gkl = gkl.to(torch.float32).contiguous() if gkl is not None else None
+        b, t = mean.shape[0], mean.shape[1]
+        per = mean.numel() // (b * t)
+        dmean, dlogvar = torch.empty_like(mean), torch.empty_like(logvar)
+        check(lib().vvae_reparam_kl_bwd(_p(mean), _p(logvar), _p(eps), _p(mask), _p(dz), _p(gkl), _p(dmean), _p(dlogvar), b, t,
+                                        per, _dt(mean), _stream()), "vvae_reparam_kl_bwd")
+        return dmean, dlogvar, None, None, None, None
+
+
+def reparameterise(mean, logvar, eps):
+    """z = mean + eps * exp(logvar / 2), fp32 out (reference train/model.py:124-128)."""
+    return _ReparamKl.apply(mean, logvar, eps, None, True, False)
+
+
+def kl_per_sample(mean, logvar, mask_bt):
+    """mean_{t,hw,c}[0.5 (e^lv - 1 - lv + mu^2) m_t / len] per sample (reference train/rl_nonadversarial.py:146-147)."""
+    return _ReparamKl.apply(mean, logvar, None, mask_bt, False, True)
+
+
+def reparameterise_kl(mean, logvar, eps, mask_bt):
+    """Both in one pass over (mean, logvar): -> (z, kl_per_sample)."""
+    return _ReparamKl.apply(mean, logvar, eps, mask_bt, True, True)
+
+
+# --------------------------------------------------------------------------------------------- masked MSE / MAE
+class _MaskedMseMae(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, video, recon, mask, video_div):
+        recon = recon.contiguous()
+        video = video.to(recon.dtype).contiguous()
+        mask = mask.to(torch.float32).contiguous()
+        b, t = recon.shape[0], recon.shape[1]
+        p = recon.numel() // (b * t)
+        assert video.shape[0] * video_div == b and video.shape[1:] == recon.shape[1:]
+        mse = torch.empty((b,), dtype=torch.float32, device=recon.device)
+        mae = torch.empty((b,), dtype=torch.float32, device=recon.device)
+        check(lib().vvae_masked_mse_mae_fwd(_p(video), _p(recon), _p(mask), _p(mse), _p(mae), b, t, p, video_div, _dt(recon),
+                                            _stream()), "vvae_masked_mse_mae_fwd")
+        ctx.save_for_backward(video, recon, mask)
+        ctx.video_div = video_div
+        return mse, mae
+
+    @staticmethod
+    def backward(ctx, gmse, gmae):
+        video, recon, mask = ctx.saved_tensors
+        b, t = recon.shape[0], recon.shape[1]
+        p = recon.numel() // (b * t)
+        gmse = gmse.to(torch.float32).contiguous()
+        gmae = gmae.to(torch.float32).contiguous()
+        dr = torch.empty_like(recon)
+        check(lib().vvae_masked_mse_mae_bwd(_p(video), _p(recon), _p(mask), _p(gmse), _p(gmae), _p(dr), b, t, p, ctx.video_div,
+                                            _dt(recon), _stream()), "vvae_masked_mse_mae_bwd")
+        return None, dr, None, None
+
+
+def masked_mse_mae(video, recon, mask_bt, video_div=1):
+    """Per-sample masked MSE and MAE (reference train/rl_nonadversarial.py:114-121); gradient flows to recon only."""
+    return _MaskedMseMae.apply(video, recon, mask_bt, video_div)

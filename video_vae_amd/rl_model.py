@@ -1,0 +1,54 @@
+"""Encoder / Decoder / VideoVAE with the surface of the reference's train/rl_model.py (6-tuple, Bernoulli pairs)."""
+import torch
+from einops import rearrange
+from torch import nn
+
+from . import ops
+from .model import Encoder as _Encoder, Decoder  # Decoder is identical in both flavours (rl_model.py:62-97)
+
+__all__ = ["Encoder", "Decoder", "VideoVAE"]
+
+
+class Encoder(_Encoder):
+    """Reference train/rl_model.py:15-60 -> (mean, log_variance, selection probability (b,t,1))."""
+
+    flavour = "rl"
+
+    def forward(self, x, mask, rngs, train=True):
+        mean, log_variance, logits = self._trunk(x, mask)
+        return mean, log_variance, torch.sigmoid(logits)
+
+
+class VideoVAE(nn.Module):
+    """Reference train/rl_model.py:101-147 -> (reconstruction, compressed_representation, selection, selection_mask,
+    log_variance, mean), every output pair-doubled along batch (samples 2k, 2k+1 share an input clip)."""
+
+    def __init__(self, height, width, channels, patch_size, encoder_depth, decoder_depth, mlp_dim, num_heads, qkv_features,
+                 max_temporal_len, spatial_compression_rate, unembedding_upsample_rate, rngs, dtype=torch.bfloat16,
+                 param_dtype=torch.float32):
+        super().__init__()
+        key = rngs.sampling()
+        self.encoder = Encoder(height, width, channels, patch_size, encoder_depth, mlp_dim, num_heads, qkv_features,
+                               max_temporal_len, spatial_compression_rate, rngs, dtype, param_dtype)
+        self.decoder = Decoder(height, width, channels, patch_size, decoder_depth, mlp_dim, num_heads, qkv_features,
+                               max_temporal_len, spatial_compression_rate, unembedding_upsample_rate, rngs, dtype, param_dtype)
+        ld = channels * patch_size * patch_size // spatial_compression_rate
+        self.fill_token = nn.Parameter(torch.randn((1, 1, 1, ld), generator=key.generator("cpu")) * 0.02)
+
+    def forward(self, x, mask, rngs, train=True):
+        mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
+        if train:
+            noise = rngs.draw("reparam_eps", "normal", log_variance.shape, log_variance.device)
+            sampled_latent = ops.reparameterise(mean, log_variance, noise)
+        else:
+            sampled_latent = mean
+        selection = rearrange(selection, "b t 1 -> b t 1 1").repeat_interleave(2, dim=0)
+        sampled_latent = sampled_latent.repeat_interleave(2, dim=0)
+        mean = mean.repeat_interleave(2, dim=0)
+        log_variance = log_variance.repeat_interleave(2, dim=0)
+        mask = mask.repeat_interleave(2, dim=0)
+        u = rngs.draw("bernoulli_u", "uniform", selection.shape, selection.device)
+        selection_mask = (u < selection).to(sampled_latent.dtype)
+        compressed_representation = self.fill_token * (1 - selection_mask) + sampled_latent * selection_mask
+        reconstruction = self.decoder(compressed_representation, mask, rngs, train=train)
+        return reconstruction, compressed_representation, selection, selection_mask, log_variance, mean

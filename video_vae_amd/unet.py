@@ -1,0 +1,135 @@
+"""3D-conv UNet with the reference's class surface (train/unet.py), running on the HIP kernels.
+
+Layout is (b, t, h, w, c) as in the reference; every conv / norm / pool / up-conv is a launch of
+libvvae_hip.so through ``ops``.  Parameters keep Flax names and layouts (``conv.kernel`` is
+(kt, kh, kw, Cin, Cout), ``norm.scale``/``norm.bias``) so checkpoints and the oracle share a key space.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .rngs import Rngs, truncated_normal_
+
+
+class Conv(nn.Module):
+    """nnx.Conv(padding='SAME'), kernel (kt,kh,kw,Cin,Cout), lecun_normal init, zero bias."""
+
+    def __init__(self, in_features, out_features, kernel_size, rngs, dtype=torch.bfloat16, param_dtype=torch.float32,
+                 zero_init=False):
+        super().__init__()
+        kt, kh, kw = kernel_size
+        shape = (kt, kh, kw, in_features, out_features)
+        k = torch.zeros(shape) if zero_init else truncated_normal_(shape, kt * kh * kw * in_features, rngs.params())
+        self.kernel = nn.Parameter(k.to(param_dtype))
+        self.bias = nn.Parameter(torch.zeros(out_features, dtype=param_dtype))
+        self.dtype = dtype
+
+    def forward(self, x):
+        return ops.conv3d(x.to(self.dtype), self.kernel, self.bias)
+
+
+class ConvTranspose(nn.Module):
+    """nnx.ConvTranspose(kernel (1,2,2), strides (1,2,2)), kernel (1,2,2,Cin,Cout)."""
+
+    def __init__(self, in_features, out_features, rngs, dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        shape = (1, 2, 2, in_features, out_features)
+        self.kernel = nn.Parameter(truncated_normal_(shape, 4 * in_features, rngs.params()).to(param_dtype))
+        self.bias = nn.Parameter(torch.zeros(out_features, dtype=param_dtype))
+        self.dtype = dtype
+
+    def forward(self, x):
+        return ops.conv_transpose_1x2x2(x.to(self.dtype), self.kernel, self.bias)
+
+
+class GroupNorm(nn.Module):
+    """nnx.GroupNorm(num_groups, C, eps=1e-6); applied fused with SiLU by ConvBlock3D."""
+
+    def __init__(self, num_groups, num_features, param_dtype=torch.float32):
+        super().__init__()
+        self.num_groups = num_groups
+        self.scale = nn.Parameter(torch.ones(num_features, dtype=param_dtype))
+        self.bias = nn.Parameter(torch.zeros(num_features, dtype=param_dtype))
+
+
+class ConvBlock3D(nn.Module):
+    """Conv(kt,k,k) SAME -> GroupNorm(min(8,C)) -> SiLU.  Reference train/unet.py:7-30."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, rngs, temporal_kernel=3,
+                 dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        self.conv = Conv(in_channels, out_channels, (temporal_kernel, kernel_size, kernel_size), rngs, dtype, param_dtype)
+        self.norm = GroupNorm(min(8, out_channels), out_channels, param_dtype)
+
+    def forward(self, x):
+        x = self.conv(x)
+        return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6)
+
+
+class DownBlock3D(nn.Module):
+    """Two ConvBlock3D then spatial max-pool; returns (pooled, skip).  Reference train/unet.py:33-51."""
+
+    def __init__(self, in_channels, out_channels, rngs, temporal_kernel=3, dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        self.conv1 = ConvBlock3D(in_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
+        self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
+
+    def forward(self, x):
+        x = self.conv2(self.conv1(x))
+        return ops.max_pool_1x2x2(x), x
+
+
+class UpBlock3D(nn.Module):
+    """ConvTranspose 2x spatial upsample, concat skip, two ConvBlock3D.  Reference train/unet.py:54-83."""
+
+    def __init__(self, in_channels, out_channels, rngs, temporal_kernel=3, dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        self.upsample = ConvTranspose(in_channels, out_channels, rngs, dtype, param_dtype)
+        self.conv1 = ConvBlock3D(out_channels * 2, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
+        self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
+
+    def forward(self, x, skip):
+        x = self.upsample(x)
+        x = torch.cat([x, skip], dim=-1)
+        return self.conv2(self.conv1(x))
+
+
+class UNet(nn.Module):
+    """Reference train/unet.py:86-188: 3x7x7 patch_mixer, num_levels down, 2 bottleneck blocks, num_levels up,
+    zero-initialised 1x1x1 final_conv.  Input/output (b, t, h, w, c)."""
+
+    def __init__(self, channels, base_features=32, num_levels=3, out_features=3, rngs=None, temporal_kernel=3,
+                 dtype=torch.bfloat16, param_dtype=torch.float32):
+        super().__init__()
+        rngs = rngs if rngs is not None else Rngs(0)
+        self.num_levels = num_levels
+        self.dtype = dtype
+        self.patch_mixer = Conv(channels, channels, (temporal_kernel, 7, 7), rngs, dtype, param_dtype)
+        self.encoders = nn.ModuleList()
+        in_ch = channels
+        for i in range(num_levels):
+            out_ch = base_features * (2 ** i)
+            self.encoders.append(DownBlock3D(in_ch, out_ch, rngs, temporal_kernel, dtype, param_dtype))
+            in_ch = out_ch
+        bottleneck_ch = base_features * (2 ** num_levels)
+        self.bottleneck1 = ConvBlock3D(in_ch, bottleneck_ch, 3, rngs, temporal_kernel, dtype, param_dtype)
+        self.bottleneck2 = ConvBlock3D(bottleneck_ch, bottleneck_ch, 3, rngs, temporal_kernel, dtype, param_dtype)
+        self.decoders = nn.ModuleList()
+        in_ch = bottleneck_ch
+        for i in range(num_levels - 1, -1, -1):
+            out_ch = base_features * (2 ** i)
+            self.decoders.append(UpBlock3D(in_ch, out_ch, rngs, temporal_kernel, dtype, param_dtype))
+            in_ch = out_ch
+        self.final_conv = Conv(base_features, out_features, (1, 1, 1), rngs, dtype, param_dtype, zero_init=True)
+
+    def forward(self, x):
+        x = x.to(self.dtype)
+        x = self.patch_mixer(x)
+        skips = []
+        for enc in self.encoders:
+            x, skip = enc(x)
+            skips.append(skip)
+        x = self.bottleneck2(self.bottleneck1(x))
+        for dec, skip in zip(self.decoders, reversed(skips)):
+            x = dec(x, skip)
+        return self.final_conv(x)
