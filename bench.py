@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- video frames/sec (fwd+bwd+optimizer) of the video-VAE training step on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one synthetic batch: VideoVAE forward (Encoder -> reparameterise -> Decoder with
+the 3D-conv UNet), masked recon+KL loss, backward, clip-by-global-norm + Adam.  Workload at every N = BASELINE.json
+config C3 per GPU: B=4 clips of 3x16x256x256 (written (B,T,H,W,C) = (4,16,256,256,3)), bf16 compute, fp32 parameters, the
+reference's production model (train/rl_nonadversarial.py:234-236) in the train/model.py flavour.  Weak scaling: per-GPU
+batch fixed, gradients all-reduced over RCCL overlapped with backward (video_vae_amd/ddp.py).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant Conv3d kernel: algorithmic bytes per launch / HIP-event duration measured inside the timed steps;
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's math) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROD = dict(height=256, width=256, channels=3, patch_size=16, encoder_depth=9, decoder_depth=12, mlp_dim=1536, num_heads=8,
+            qkv_features=512, max_temporal_len=64, spatial_compression_rate=8, unembedding_upsample_rate=4)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workload", default="vae", choices=["vae", "unet"],
+                    help="vae: full VideoVAE train step (the metric); unet: the Conv3d UNet stack alone (diagnostic)")
+    ap.add_argument("--flavour", default="model", choices=["model", "rl"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the bounded CPU sample")
+    return ap.parse_args()
+
+
+def build_model(args, dev, dtype):
+    import video_vae_amd as V
+    from video_vae_amd import rl_model
+    cfg = dict(PROD, height=args.size, width=args.size)
+    rngs = V.Rngs(2)                                            # nnx.Rngs(2), rl_nonadversarial.py:236
+    if args.workload == "unet":
+        m = V.UNet(channels=12, base_features=16, num_levels=3, out_features=3, rngs=rngs, dtype=dtype)
+        fc = m.final_conv
+    else:
+        cls = rl_model.VideoVAE if args.flavour == "rl" else V.VideoVAE
+        m = cls(rngs=rngs, dtype=dtype, **cfg)
+        fc = m.decoder.unet.final_conv
+    # final_conv is zero-initialised in the reference (unet.py:150), which makes the UNet a no-op and blocks its
+    # interior gradients; the bench re-initialises it non-zero so the conv stack does real work.
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(1234)
+        fc.kernel.copy_(torch.randn(fc.kernel.shape, generator=g) * (fc.kernel.shape[-2] ** -0.5))
+    return m.to(dev), cfg
+
+
+def cpu_baseline(args):
+    """The oracle's UNet + loss fwd+bwd on the host cores, fp32, on a bounded sample (1 clip x --cpu-frames frames)."""
+    from oracle import unet as OU
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    t, s = args.cpu_frames, args.size
+    p = OU.init_unet(12, 16, 3, 3, seed=5, zero_final=False)
+    for v in p.values():
+        v.requires_grad_(True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, t, s, s, 12), generator=g) * 0.5
+    t0 = time.perf_counter()
+    y = OU.unet(p, x)
+    y.square().mean().backward()
+    dt_s = time.perf_counter() - t0
+    return {"value": t / dt_s, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle UNet (Conv3d stack of the decoder) fwd+bwd, fp32, 1 clip x {t} frames x {s}x{s}x12 features, "
+                      f"1 step, {dt_s:.1f} s on {threads} threads (transformer trunk not included)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    import video_vae_amd as V
+    from video_vae_amd import ops, optim, ddp, loss as L
+    model, cfg = build_model(args, dev, dtype)
+    opt = optim.Optimizer(model, optim.reference_schedule(batch_size=args.batch * world))
+    reducer = None
+    if world > 1:
+        reducer = ddp.GradReducer(opt)
+        reducer.broadcast_parameters(0)
+    nparams = sum(p.numel() for p in model.parameters())
+
+    B, T, S = args.batch, args.frames, args.size
+    g = torch.Generator().manual_seed(0 + rank)                 # per-rank data seed = seed + rank
+    rngs = V.Rngs(3 + rank)
+    if args.workload == "unet":
+        feat = (torch.randn((B, T, S, S, 12), generator=g) * 0.5).to(dev, dtype)
+        tgt = torch.rand((B, T, S, S, 3), generator=g).to(dev, dtype)
+        mask = torch.ones((B, T), device=dev)
+
+        def step():
+            opt.zero_grad()
+            recon = model(feat)
+            mse, _ = ops.masked_mse_mae(tgt, recon, mask, 1)
+            loss = mse.mean()
+            loss.backward()
+            opt.update()
+            return loss
+    else:
+        video = torch.rand((B, T, S, S, 3), generator=g).to(dev, dtype)      # dataloader range [0,1), cast as :330
+        mask = torch.ones((B, T), device=dev)
+        hw = (S // cfg["patch_size"]) ** 2
+
+        def step():
+            loss, _aux = L.train_step(model, opt, video, mask, L.HPARAMS, hw, rngs)
+            return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer = ops.KernelTimer() if rank == 0 else None
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(loss).all(), "non-finite loss in the timed region"
+
+    if rank == 0:
+        frames = B * T * world * args.steps
+        out = {
+            "metric": "video frames/sec (fwd+bwd) at Bx3x16x256x256", "value": frames / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("C3: full VideoVAE (enc 9 / dec 12 FactoredAttention + 3D-conv UNet) train step, "
+                                    if args.workload == "vae" else "Conv3d UNet stack alone (diagnostic), ")
+                                   + f"B={B}/GPU x 3x{T}x{S}x{S}, {args.dtype} compute, fp32 params, recon+KL loss, clip+Adam",
+                       "flavour": args.flavour if args.workload == "vae" else "unet", "params": nparams,
+                       "global_batch": B * world, "frames_per_clip": T, "parallelism": f"dp{world}"},
+        }
+        summ = timer.summary()
+        conv = {k: v for k, v in summ.items() if k.startswith("conv3d")}
+        if conv:
+            tag, top = max(conv.items(), key=lambda kv: kv[1]["total_ms"])
+            ach = top["bytes"] / (top["avg_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "kernel": top["kernel"], "launch": tag, "avg_ms": top["avg_ms"],
+                               "launches_timed": top["n"], "alg_bytes_per_launch": top["bytes"],
+                               "tflops": top["flops"] / (top["avg_ms"] * 1e-3) / 1e12}
+            tot_ms = sum(v["total_ms"] for v in conv.values()) / args.steps
+            tot_b = sum(v["bytes"] * v["n"] for v in conv.values()) / args.steps
+            tot_f = sum(v["flops"] * v["n"] for v in conv.values()) / args.steps
+            out["conv_stack"] = {"ms_per_step": tot_ms, "alg_GB_per_step": tot_b / 1e9, "GBps": tot_b / tot_ms / 1e6,
+                                 "frac_hbm": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS, "tflops": tot_f / tot_ms / 1e9,
+                                 "frames_per_s_conv_only": B * T / (tot_ms * 1e-3)}
+            if os.environ.get("VVAE_BENCH_VERBOSE"):
+                for k, v in sorted(conv.items(), key=lambda kv: -kv[1]["total_ms"]):
+                    print(f"# {k:44s} n={v['n']:3d} avg {v['avg_ms']:8.3f} ms  {v['bytes'] / v['avg_ms'] / 1e6:8.1f} GB/s "
+                          f"{v['flops'] / v['avg_ms'] / 1e9:8.1f} TF/s", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

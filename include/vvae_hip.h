@@ -51,9 +51,11 @@ int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy, int lddy, 
                               int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
 int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out, int which, int flags);
 size_t vvae_conv3d_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int which);
+int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, int Cin, int Cout, int kt, int kh, int kw,
+                          int dgrad, void* stream);
 int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
                          int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
-                         void* ws, size_t ws_bytes, void* stream);
+                         int prepacked, void* ws, size_t ws_bytes, void* stream);
 int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
                            int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
                            void* ws, size_t ws_bytes, void* stream);

@@ -265,3 +265,60 @@ def test_masked_mse_mae(dev, dtype, div):
     assert_close(mse_g, mse_o, rtol=r, atol=1e-6, what="mse")
     assert_close(mae_g, mae_o, rtol=r, atol=1e-6, what="mae")
     assert_close_scaled(rg.grad, ro.grad, rel=r, what="drecon")
+
+
+# ------------------------------------------------------------------------------------------- bf16 MFMA fast path
+FAST_CASES = [
+    # cin, cout, kt, kh, kw, (n, t, h, w)
+    (16, 16, 3, 3, 3, (1, 3, 20, 24)), (16, 32, 3, 3, 3, (2, 2, 9, 17)), (32, 32, 3, 3, 3, (1, 4, 16, 16)),
+    (32, 64, 3, 3, 3, (1, 2, 12, 20)), (64, 64, 3, 3, 3, (1, 3, 8, 16)), (64, 128, 3, 3, 3, (1, 2, 8, 16)),
+    (128, 128, 3, 3, 3, (1, 2, 8, 8)), (128, 64, 3, 3, 3, (1, 2, 10, 16)), (64, 32, 3, 3, 3, (1, 2, 16, 16)),
+    (32, 16, 3, 3, 3, (1, 3, 16, 32)), (16, 16, 3, 7, 7, (1, 3, 20, 24)), (16, 16, 3, 7, 7, (2, 1, 5, 40)),
+]
+
+
+def _bf16_exact(shape, seed, scale):
+    return (rnd(shape, seed, scale)).to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("case", FAST_CASES)
+def test_conv3d_bf16_fast_path(dev, case):
+    """bf16 MFMA fwd/dgrad vs (a) the generic fp32-matrix-core path on the GPU and (b) the CPU oracle.
+
+    Weights are chosen bf16-representable so both GPU paths multiply identical operands and differ only in fp32
+    summation order (then one bf16 rounding of the output)."""
+    from video_vae_amd import ops
+    from video_vae_amd._lib import lib
+    ci, co, kt, kh, kw, (n, t, h, w) = case
+    x = _bf16_exact((n, t, h, w, ci), 50, 1.0)
+    k = _bf16_exact((kt, kh, kw, ci, co), 51, (kt * kh * kw * ci) ** -0.5)
+    b = rnd((co,), 52, 0.1)
+    gy = _bf16_exact((n, t, h, w, co), 53, 1.0)
+    assert lib().vvae_conv3d_bf16_supported(ci, co, kt, kh, kw, ci, co, 0, 0) == 1
+    assert lib().vvae_conv3d_bf16_supported(ci, co, kt, kh, kw, co, ci, 1, 0) == 1
+    xg, kg, bg, gyg = x.to(dev, torch.bfloat16), k.to(dev), b.to(dev), gy.to(dev, torch.bfloat16)
+    assert lib().vvae_conv3d_bf16_supported(ci, co, kt, kh, kw, ci, co, 2, 0) == 1
+    y_fast = ops.conv3d_fwd_raw(xg, kg, bg)
+    dx_fast = ops.conv3d_dgrad_raw(gyg, kg)
+    dw_fast, db_fast = ops.conv3d_wgrad_raw(xg, gyg, tuple(k.shape))
+    ops.force_generic_conv(True)
+    try:
+        y_gen = ops.conv3d_fwd_raw(xg, kg, bg)
+        dx_gen = ops.conv3d_dgrad_raw(gyg, kg)
+        dw_gen, db_gen = ops.conv3d_wgrad_raw(xg, gyg, tuple(k.shape))
+    finally:
+        ops.force_generic_conv(False)
+    # wgrad: identical bf16 operands, fp32 accumulation in both paths -> agreement to fp32 summation-order noise
+    assert_close_scaled(dw_fast, dw_gen, rel=2e-5, what="fast vs generic dw")
+    assert_close_scaled(db_fast, db_gen, rel=2e-5, what="fast vs generic db")
+    dw_again, _ = ops.conv3d_wgrad_raw(xg, gyg, tuple(k.shape))
+    assert torch.equal(dw_again, dw_fast), "slab-reduced wgrad must be bitwise reproducible"
+    assert_close(y_fast, y_gen, rtol=1e-2, atol=1e-2, what="fast vs generic y")
+    assert_close(dx_fast, dx_gen, rtol=1e-2, atol=1e-2 * float(dx_gen.float().abs().max()), what="fast vs generic dx")
+    frac = float((y_fast != y_gen).float().mean())
+    assert frac < 0.05, f"{frac:.3f} of outputs differ between the two GPU paths (expected only rare 1-ulp flips)"
+    xo = x.clone().requires_grad_(True)
+    yo = O.conv3d_same(xo, k, b, torch.bfloat16)
+    yo.backward(gy)
+    assert_close(y_fast, yo, rtol=2e-2, atol=2e-2, what="fast vs oracle y")
+    assert_close_scaled(dx_fast, xo.grad, rel=2e-2, what="fast vs oracle dx")

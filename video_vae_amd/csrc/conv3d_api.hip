@@ -5,7 +5,7 @@ extern "C" {
 int vvae_conv3d_fwd_generic(const void*, int, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*);
 int vvae_conv3d_dgrad_generic(const void*, int, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*);
 int vvae_conv3d_wgrad_generic(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, int, void*);
-int vvae_conv3d_fwd_bf16(const void*, int, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
+int vvae_conv3d_fwd_bf16(const void*, int, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
 int vvae_conv3d_wgrad_bf16(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
 size_t vvae_conv3d_bf16_ws_bytes(int, int, int, int, int, int, int, int, int, int);
 int vvae_conv3d_bf16_supported(int, int, int, int, int, int, int, int, int);
@@ -30,7 +30,7 @@ extern "C" int vvae_conv3d_fwd(const void* x, int ldx, const float* w, const flo
                                void* ws, size_t ws_bytes, void* stream)
 {
     if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, ldy, 0, 0))
-        return vvae_conv3d_fwd_bf16(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, 0, ws, ws_bytes, stream);
+        return vvae_conv3d_fwd_bf16(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, 0, 0, ws, ws_bytes, stream);
     return vvae_conv3d_fwd_generic(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
 }
 
@@ -40,7 +40,7 @@ extern "C" int vvae_conv3d_dgrad(const void* dy, int lddy, const float* w, void*
                                  void* ws, size_t ws_bytes, void* stream)
 {
     if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, lddx, lddy, 1, 0))
-        return vvae_conv3d_fwd_bf16(dy, lddy, w, nullptr, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, 1, ws, ws_bytes, stream);
+        return vvae_conv3d_fwd_bf16(dy, lddy, w, nullptr, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, 1, 0, ws, ws_bytes, stream);
     return vvae_conv3d_dgrad_generic(dy, lddy, w, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
 }
 

@@ -227,11 +227,17 @@ inline size_t packed_bytes(int CK, int CO, int kt, int kh, int kw)
 
 }  // namespace
 
-// which: 0 fwd (K = Cin, produced = Cout), 1 dgrad (K = Cout, produced = Cin), 2 wgrad (not on this path yet).
+extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw);
+
+// which: 0 fwd (K = Cin, produced = Cout), 1 dgrad (K = Cout, produced = Cin), 2 wgrad (ld_in = ldx, ld_out = lddy).
 extern "C" int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out, int which, int flags)
 {
     (void)flags;
-    if (which == 2) return 0;
+    if (which == 2) {
+        if (Cin % 16 || Cout % 16 || ld_in % 8 || ld_out % 8) return 0;
+        if (kt == 3 && kh == 3 && kw == 3) return 1;
+        return (kt == 3 && kh == 7 && kw == 7 && Cin == 16 && Cout == 16) ? 1 : 0;
+    }
     const int CK = which == 1 ? Cout : Cin, CO = which == 1 ? Cin : Cout;
     if (CK % 16 || CO % 16 || ld_in % 8 || ld_out % 4) return 0;
     if (kt == 3 && kh == 3 && kw == 3) return (CO == 16 || CO == 32 || CO % 64 == 0) ? 1 : 0;
@@ -241,19 +247,35 @@ extern "C" int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int
 
 extern "C" size_t vvae_conv3d_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int which)
 {
-    (void)N; (void)T; (void)H; (void)W;
-    if (which == 2) return 0;
+    if (which == 2) return vvae_conv3d_wgrad_bf16_ws_bytes(N, T, H, W, Cin, Cout, kt, kh, kw);
     if (!vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, 8, 8, which, 0)) return 0;
     const int CK = which == 1 ? Cout : Cin, CO = which == 1 ? Cin : Cout;
     return packed_bytes(CK, CO, kt, kh, kw);
 }
 
+// Pack the Flax kernel w (kt,kh,kw,Cin,Cout) fp32 into the bf16 fragment order the kernel streams (see pack_weights_kernel).
+// ws must hold vvae_conv3d_bf16_ws_bytes(.., which = dgrad) bytes.  Weights change once per optimizer step, so a caller
+// may pack once and pass prepacked = 1 to every vvae_conv3d_fwd_bf16 call of that step.
+extern "C" int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, int Cin, int Cout, int kt, int kh, int kw,
+                                     int dgrad, void* stream)
+{
+    if (!w || !ws || ((uintptr_t)ws % 16)) return VVAE_ERR_BAD_ARG;
+    if (!vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, 8, 8, dgrad ? 1 : 0, 0)) return VVAE_ERR_BAD_ARG;
+    const int CK = dgrad ? Cout : Cin, CO = dgrad ? Cin : Cout;
+    if (ws_bytes < packed_bytes(CK, CO, kt, kh, kw)) return VVAE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (kh == 7) return launch_pack<16, 3, 7, 7>(w, (uint4*)ws, Cin, Cout, dgrad, s);
+    if (chunk_of(CK) == 16) return launch_pack<16, 3, 3, 3>(w, (uint4*)ws, Cin, Cout, dgrad, s);
+    return launch_pack<32, 3, 3, 3>(w, (uint4*)ws, Cin, Cout, dgrad, s);
+}
+
 // dgrad = 0: y = conv(x, w) + bias.   dgrad = 1: "x" is dy (Cout channels), "y" is dx (Cin channels), bias ignored.
+// prepacked = 1: ws already holds the packed weights (w may be NULL).
 extern "C" int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
                                     int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
-                                    void* ws, size_t ws_bytes, void* stream)
+                                    int prepacked, void* ws, size_t ws_bytes, void* stream)
 {
-    if (!x || !w || !y || N <= 0 || T <= 0 || H <= 0 || W <= 0) return VVAE_ERR_BAD_ARG;
+    if (!x || (!w && !prepacked) || !y || N <= 0 || T <= 0 || H <= 0 || W <= 0) return VVAE_ERR_BAD_ARG;
     if (!vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, ldy, dgrad ? 1 : 0, 0)) return VVAE_ERR_BAD_ARG;
     if (((uintptr_t)x % 16) || ((uintptr_t)y % 8)) return VVAE_ERR_BAD_ARG;
     const int CK = dgrad ? Cout : Cin, CO = dgrad ? Cin : Cout;
@@ -266,25 +288,281 @@ extern "C" int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, cons
     bf16_t* yp = (bf16_t*)y;
     const float* bp = dgrad ? nullptr : bias;
     BfDims d{N, T, H, W, CK, CO, 0, 0};
-    int rc;
-    if (kh == 7) {
-        if ((rc = launch_pack<16, 3, 7, 7>(w, wp, Cin, Cout, dgrad, s))) return rc;
-        return launch_cfg<C377_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
+    if (!prepacked) {
+        const int rc = vvae_conv3d_pack_bf16(w, ws, ws_bytes, Cin, Cout, kt, kh, kw, dgrad, stream);
+        if (rc) return rc;
     }
+    if (kh == 7) return launch_cfg<C377_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
     if (chunk_of(CK) == 16) {
-        if ((rc = launch_pack<16, 3, 3, 3>(w, wp, Cin, Cout, dgrad, s))) return rc;
         if (CO == 16) return launch_cfg<C333_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
         if (CO == 32) return launch_cfg<C333_k16_o32>(xp, ldx, wp, bp, yp, ldy, d, s);
         return launch_cfg<C333_k16_o64>(xp, ldx, wp, bp, yp, ldy, d, s);
     }
-    if ((rc = launch_pack<32, 3, 3, 3>(w, wp, Cin, Cout, dgrad, s))) return rc;
     if (CO == 16) return launch_cfg<C333_k32_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
     if (CO == 32) return launch_cfg<C333_k32_o32>(xp, ldx, wp, bp, yp, ldy, d, s);
     return launch_cfg<C333_k32_o64>(xp, ldx, wp, bp, yp, ldy, d, s);
 }
 
-extern "C" int vvae_conv3d_wgrad_bf16(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int,
-                                      int, void*, size_t, void*)
+namespace {
+// =============================================================================================== weight gradient
+// dW[dt][dy][dx][ci][co] = sum_v X[v + off(dt,dy,dx)][ci] * dY[v][co]          (and dbias[co] = sum_v dY[v][co])
+//
+// GEMM view per tap: M = ci, N = co, K = voxels (millions).  Both operands are K-major in NDHWC memory, so the MFMA
+// fragments (8 consecutive k per lane) come from LDS through ds_read_b64_tr_b16 (hardware 4x16 transpose), with the
+// k -> voxel map chosen so that each 32-lane half reads 8 consecutive voxel rows = one conflict-free 256-byte bank row.
+//   * one workgroup = KT waves; wave `dt` owns the KH*KW taps of temporal offset dt for a CIB x COB block of the weight
+//     matrix, i.e. KH*KW*(CIB/16)*(COB/16) accumulator tiles that stay in registers for the block's whole life;
+//   * workgroups are PERSISTENT: each walks a contiguous run of (n, h-tile, w-tile, t) tiles, staging the X halo
+//     (KT x (TH+KH-1) x (32+KW-1) voxels) and the dY tile (TH x 32 voxels) in LDS, so the accumulators are written out
+//     once per workgroup (fp32 slab) and a second tiny kernel sums the slabs -- deterministic, no float atomics;
+//   * the X fragment read for halo row r and column shift dx serves the KH taps (dy, dx) of output rows r-dy, and the dY
+//     fragment of a row serves all KH*KW taps: ~0.5 LDS fragment reads per MFMA instead of 4.
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int row16_bytes)
 {
-    return VVAE_ERR_BAD_ARG;
+    // two transposed 4x16 reads: k elements 0..3 from voxel rows (4g+q), 4..7 from rows 16+(4g+q)
+    typedef __attribute__((address_space(3))) s16x4v* lds_ptr;
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + row16_bytes));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int CIB_, int COB_, int KH_, int KW_, int TH_>
+struct WgCfg {
+    static constexpr int CIB = CIB_, COB = COB_, KT = 3, KH = KH_, KW = KW_, TH = TH_, TW = 32;
+    static constexpr int CIT = CIB / 16, COT = COB / 16;
+    static constexpr int HR = TH + KH - 1, WR = TW + KW - 1;
+    static constexpr int PX = CIB == 16 ? 32 : 96, PY = COB == 16 ? 32 : 96;
+    static constexpr int XBYTES = KT * HR * WR * PX, YBYTES = TH * TW * PY;
+    static constexpr int LDS_BYTES = XBYTES + YBYTES;
+    static constexpr int SLAB_FLOATS = KT * KH * KW * CIB * COB + COB;     // + dbias partial
+};
+
+struct WgDims { int N, T, H, W, CI, CO, tiles_h, tiles_w, ntiles, tiles_per_block; };
+
+template <class C>
+__global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy,
+                                                                int lddy, float* __restrict__ slab, WgDims d)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CIB = C::CIB, COB = C::COB, KH = C::KH, KW = C::KW, TH = C::TH, TW = C::TW;
+    constexpr int CIT = C::CIT, COT = C::COT, HR = C::HR, WR = C::WR, PX = C::PX, PY = C::PY;
+    unsigned char* xs = smem;
+    unsigned char* ys = smem + C::XBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // wave = dt
+    const int co_subs = d.CO / COB;
+    const int ci0 = (blockIdx.y / co_subs) * CIB, co0 = (blockIdx.y % co_subs) * COB;
+    // transposed-read lane offsets: lane (g = l>>4, q = (l>>2)&3, p = l&3) addresses voxel row 4g+q, channels 4p..4p+3
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int loffx = (4 * g + qq) * PX + 8 * pp, loffy = (4 * g + qq) * PY + 8 * pp;
+
+    f32x4 acc[KH][KW][CIT][COT];
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+#pragma unroll
+            for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+    const int tile_beg = blockIdx.x * d.tiles_per_block;
+    int tile_end = tile_beg + d.tiles_per_block;
+    if (tile_end > d.ntiles) tile_end = d.ntiles;
+    for (int tile = tile_beg; tile < tile_end; ++tile) {
+        const int tt = tile % d.T; int q = tile / d.T;
+        const int tw = q % d.tiles_w; q /= d.tiles_w;
+        const int th = q % d.tiles_h; const int n = q / d.tiles_h;
+        const int h0 = th * TH, w0 = tw * TW;
+        if (tile != tile_beg) __syncthreads();
+        // ---- stage X halo (channels ci0..ci0+CIB) and dY tile (channels co0..co0+COB), zero filled ----
+        constexpr int XP = CIB / 8, YP = COB / 8;
+        for (int i = tid; i < 3 * HR * WR * XP; i += 192) {
+            const int part = i % XP, vox = i / XP;
+            const int wc = vox % WR; const int r2 = vox / WR; const int hr = r2 % HR, dt = r2 / HR;
+            const int ti = tt + dt - 1, hi = h0 + hr - KH / 2, wi = w0 + wc - KW / 2;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if ((unsigned)ti < (unsigned)d.T && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W)
+                val = *reinterpret_cast<const uint4*>(x + ((((long)n * d.T + ti) * d.H + hi) * d.W + wi) * ldx + ci0 + part * 8);
+            *reinterpret_cast<uint4*>(xs + vox * PX + part * 16) = val;
+        }
+        for (int i = tid; i < TH * TW * YP; i += 192) {
+            const int part = i % YP, vox = i / YP;
+            const int wc = vox % TW, hr = vox / TW;
+            const int hi = h0 + hr, wi = w0 + wc;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (hi < d.H && wi < d.W)
+                val = *reinterpret_cast<const uint4*>(dy + ((((long)n * d.T + tt) * d.H + hi) * d.W + wi) * lddy + co0 + part * 8);
+            *reinterpret_cast<uint4*>(ys + vox * PY + part * 16) = val;
+        }
+        __syncthreads();
+
+        bf16x8 bfr[KH][COT];                                  // rolling window of dY fragments: row h lives in slot h % KH
+        const unsigned char* xplane = xs + wave * HR * WR * PX + loffx;
+#pragma unroll
+        for (int hr = 0; hr < HR; ++hr) {
+            if (hr < TH) {
+#pragma unroll
+                for (int j = 0; j < COT; ++j) {
+                    bfr[hr % KH][j] = tr_frag(ys + hr * TW * PY + j * 32 + loffy, 16 * PY);
+                    if (wave == 0) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[hr % KH][j], accb[j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < KW; ++b) {
+                bf16x8 afr[CIT];
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) afr[i] = tr_frag(xplane + (hr * WR + b) * PX + i * 32, 16 * PX);
+#pragma unroll
+                for (int a = 0; a < KH; ++a) {
+                    const int h = hr - a;
+                    if (h >= 0 && h < TH) {
+#pragma unroll
+                        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                            for (int j = 0; j < COT; ++j)
+                                acc[a][b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[h % KH][j], acc[a][b][i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- write this workgroup's partial sums: slab[block][dt][dy][dx][ci_local][co_local] (+ COB dbias partials) ----
+    float* out = slab + ((long)blockIdx.x * gridDim.y + blockIdx.y) * C::SLAB_FLOATS;
+    const int col = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+#pragma unroll
+            for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                for (int j = 0; j < COT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ci = i * 16 + rg * 4 + e, co = j * 16 + col;
+                        out[(((wave * KH + a) * KW + b) * CIB + ci) * COB + co] = acc[a][b][i][j][e];
+                    }
+    if (wave == 0 && rg == 0) {
+#pragma unroll
+        for (int j = 0; j < COT; ++j) out[C::KT * KH * KW * CIB * COB + j * 16 + col] = accb[j][0];
+    }
+}
+
+// dw[tap][ci][co] = sum_b slab[b][sub(ci,co)][tap][ci%CIB][co%COB];  dbias[co] = sum_b (ci-sub 0) slab dbias part
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, float* __restrict__ dbias,
+                                                           int nblk, int taps, int CI, int CO, int CIB, int COB)
+{
+    const int co_subs = CO / COB, nsub = (CI / CIB) * co_subs;
+    const long slab_floats = (long)taps * CIB * COB + COB;
+    const long total = (long)taps * CI * CO;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        const int co = (int)(i % CO); const long r = i / CO; const int ci = (int)(r % CI); const int tap = (int)(r / CI);
+        const int sub = (ci / CIB) * co_subs + co / COB;
+        const long off = ((long)tap * CIB + ci % CIB) * COB + co % COB;
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += slab[((long)b * nsub + sub) * slab_floats + off];
+        dw[i] = s;
+    } else if (dbias && i < total + CO) {
+        const int co = (int)(i - total);
+        const int sub = co / COB;                              // ci-sub 0
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += slab[((long)b * nsub + sub) * slab_floats + (long)taps * CIB * COB + co % COB];
+        dbias[co] = s;
+    }
+}
+
+typedef WgCfg<16, 16, 3, 3, 4> W333_16_16;
+typedef WgCfg<16, 32, 3, 3, 4> W333_16_32;
+typedef WgCfg<32, 16, 3, 3, 4> W333_32_16;
+typedef WgCfg<32, 32, 3, 3, 4> W333_32_32;
+typedef WgCfg<16, 16, 7, 7, 4> W377_16_16;
+
+inline int wg_blocks_x(long ntiles, int nsub)
+{
+    long nb = 768 / nsub;                 // ~3 workgroups per CU over the whole chip
+    if (nb < 16) nb = 16;
+    if (nb > ntiles) nb = ntiles;
+    return (int)nb;
+}
+
+template <class C>
+size_t wg_ws_bytes(int N, int T, int H, int W, int CI, int CO)
+{
+    const long ntiles = (long)N * T * ceil_div(H, C::TH) * ceil_div(W, C::TW);
+    const int nsub = (CI / C::CIB) * (CO / C::COB);
+    return (size_t)wg_blocks_x(ntiles, nsub) * nsub * C::SLAB_FLOATS * sizeof(float);
+}
+
+template <class C>
+int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float* dw, float* dbias, int N, int T, int H, int W,
+                     int CI, int CO, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    WgDims d{N, T, H, W, CI, CO, ceil_div(H, C::TH), ceil_div(W, C::TW), 0, 0};
+    const long ntiles = (long)N * T * d.tiles_h * d.tiles_w;
+    const int nsub = (CI / C::CIB) * (CO / C::COB);
+    const int nbx = wg_blocks_x(ntiles, nsub);
+    d.ntiles = (int)ntiles;
+    d.tiles_per_block = ceil_div(ntiles, nbx);
+    const int nblk = ceil_div(ntiles, d.tiles_per_block);      // blocks that own at least one tile
+    if (!ws || ws_bytes < (size_t)nblk * nsub * C::SLAB_FLOATS * sizeof(float)) return VVAE_ERR_WORKSPACE;
+    auto k = conv3d_wgrad_bf16_kernel<C>;
+    if (C::LDS_BYTES > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(192), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d);
+    VVAE_LAUNCH_CHECK();
+    const int taps = C::KT * C::KH * C::KW;
+    const long total = (long)taps * CI * CO + CO;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)ws, dw, dbias, nblk, taps, CI,
+                       CO, C::CIB, C::COB);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+inline bool wgrad_shape_ok(int Cin, int Cout, int kt, int kh, int kw)
+{
+    if (Cin % 16 || Cout % 16) return false;
+    if (kt == 3 && kh == 3 && kw == 3) return true;
+    return kt == 3 && kh == 7 && kw == 7 && Cin == 16 && Cout == 16;
+}
+
+}  // namespace
+
+extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw)
+{
+    if (!wgrad_shape_ok(Cin, Cout, kt, kh, kw)) return 0;
+    if (kh == 7) return wg_ws_bytes<W377_16_16>(N, T, H, W, Cin, Cout);
+    const bool i32 = Cin % 32 == 0, o32 = Cout % 32 == 0;
+    if (i32 && o32) return wg_ws_bytes<W333_32_32>(N, T, H, W, Cin, Cout);
+    if (i32) return wg_ws_bytes<W333_32_16>(N, T, H, W, Cin, Cout);
+    if (o32) return wg_ws_bytes<W333_16_32>(N, T, H, W, Cin, Cout);
+    return wg_ws_bytes<W333_16_16>(N, T, H, W, Cin, Cout);
+}
+
+// dw (kt,kh,kw,Cin,Cout) fp32 and dbias (Cout, may be NULL) are overwritten.  ws: vvae_conv3d_wgrad_bf16_ws_bytes(...) bytes.
+extern "C" int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
+                                      int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                                      void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !dy || !dw || N <= 0 || T <= 0 || H <= 0 || W <= 0 || !wgrad_shape_ok(Cin, Cout, kt, kh, kw)) return VVAE_ERR_BAD_ARG;
+    if (ldx < Cin || lddy < Cout || ldx % 8 || lddy % 8 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bf16_t* xp = (const bf16_t*)x;
+    const bf16_t* dyp = (const bf16_t*)dy;
+    if (kh == 7) return launch_wgrad_cfg<W377_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+    const bool i32 = Cin % 32 == 0, o32 = Cout % 32 == 0;
+    if (i32 && o32) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+    if (i32) return launch_wgrad_cfg<W333_32_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+    if (o32) return launch_wgrad_cfg<W333_16_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+    return launch_wgrad_cfg<W333_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
 }

@@ -55,6 +55,86 @@ def _ws(nbytes, device):
     return buf, nbytes
 
 
+class KernelTimer:
+    """Per-launch HIP-event timing of tagged kernels on the current stream (bench.py's roofline leg).
+
+    ``records[tag] = [algorithmic_bytes, flops, kernel_name, [(start, end), ...]]``; durations are read after a sync.
+    """
+
+    def __init__(self):
+        self.records = {}
+
+    def launch(self, tag, alg_bytes, flops, kernel, fn):
+        rec = self.records.setdefault(tag, [alg_bytes, flops, kernel, []])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn()
+        b.record()
+        rec[3].append((a, b))
+        return rc
+
+    def summary(self):
+        """-> {tag: dict(n, avg_ms, total_ms, bytes, flops, kernel)} (call after torch.cuda.synchronize())."""
+        out = {}
+        for tag, (nbytes, flops, kernel, evs) in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[tag] = dict(n=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms), bytes=nbytes, flops=flops, kernel=kernel)
+        return out
+
+
+TIMER = None      # set to a KernelTimer to time tagged launches
+
+
+def _launch(tag, alg_bytes, flops, kernel, fn):
+    if TIMER is None:
+        return fn()
+    return TIMER.launch(tag, alg_bytes, flops, kernel, fn)
+
+
+def _bf16_fast(cin, cout, kt, kh, kw, ld_in, ld_out, which, dt):
+    return dt == 1 and not _FORCE_GENERIC[0] and lib().vvae_conv3d_bf16_supported(cin, cout, kt, kh, kw, ld_in, ld_out, which, 0)
+
+
+_FORCE_GENERIC = [False]
+
+
+def force_generic_conv(on):
+    """Test hook: route every conv through the generic fp32-matrix-core path."""
+    _FORCE_GENERIC[0] = bool(on)
+    lib().vvae_conv3d_force_generic(1 if on else 0)
+
+
+def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad):
+    """Shared by fwd (dgrad=0) and dgrad (dgrad=1): bf16 fast path with a separate pack launch, else the dispatcher."""
+    n, t, h, w, cin, cout, kt, kh, kw = dims
+    dt = _dt(x)
+    ldo = out.stride(-2)
+    esz = x.element_size()
+    ck, co = (cout, cin) if dgrad else (cin, cout)
+    vox = n * t * h * w
+    alg = vox * (ck + co) * esz
+    flops = 2 * vox * kt * kh * kw * cin * cout
+    name = "dgrad" if dgrad else "fwd"
+    tag = f"conv3d_{name} {ck}->{co} k{kt}{kh}{kw} @{h}x{w}"
+    if _bf16_fast(cin, cout, kt, kh, kw, ldx, ldo, 1 if dgrad else 0, dt):
+        wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, 1 if dgrad else 0)
+        ws, wsb = _ws(wsb, x.device)
+        check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, 1 if dgrad else 0, _stream()),
+              "vvae_conv3d_pack_bf16")
+        check(_launch(tag, alg, flops, "conv3d_bf16_kernel",
+                      lambda: lib().vvae_conv3d_fwd_bf16(_p(x), ldx, None, _p(bias), _p(out), ldo, n, t, h, w, cin, cout, kt, kh,
+                                                         kw, 1 if dgrad else 0, 1, _p(ws), wsb, _stream())),
+              "vvae_conv3d_fwd_bf16")
+        return out
+    fn = lib().vvae_conv3d_dgrad if dgrad else lib().vvae_conv3d_fwd
+    if dgrad:
+        call = lambda: fn(_p(x), ldx, _p(kernel), _p(out), ldo, n, t, h, w, cin, cout, kt, kh, kw, dt, None, 0, _stream())
+    else:
+        call = lambda: fn(_p(x), ldx, _p(kernel), _p(bias), _p(out), ldo, n, t, h, w, cin, cout, kt, kh, kw, dt, None, 0, _stream())
+    check(_launch(tag, alg, flops, "conv3d_f32mfma_kernel", call), "vvae_conv3d_" + name)
+    return out
+
+
 # --------------------------------------------------------------------------------------------- Conv3d
 def conv3d_fwd_raw(x, kernel, bias, out=None):
     x, ldx = rows(x)
@@ -63,13 +143,7 @@ def conv3d_fwd_raw(x, kernel, bias, out=None):
     assert cin == cin2, (cin, cin2)
     if out is None:
         out = torch.empty((n, t, h, w, cout), dtype=x.dtype, device=x.device)
-    ldy = out.stride(-2)
-    dt = _dt(x)
-    wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 0)
-    ws, wsb = _ws(wsb, x.device)
-    check(lib().vvae_conv3d_fwd(_p(x), ldx, _p(kernel), _p(bias), _p(out), ldy, n, t, h, w, cin, cout, kt, kh, kw, dt,
-                                _p(ws), wsb, _stream()), "vvae_conv3d_fwd")
-    return out
+    return _conv_fwd_like(x, ldx, kernel, bias, out, (n, t, h, w, cin, cout, kt, kh, kw), 0)
 
 
 def conv3d_dgrad_raw(dy, kernel, out=None):
@@ -79,12 +153,7 @@ def conv3d_dgrad_raw(dy, kernel, out=None):
     assert cout == cout2
     if out is None:
         out = torch.empty((n, t, h, w, cin), dtype=dy.dtype, device=dy.device)
-    dt = _dt(dy)
-    wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 1)
-    ws, wsb = _ws(wsb, dy.device)
-    check(lib().vvae_conv3d_dgrad(_p(dy), lddy, _p(kernel), _p(out), out.stride(-2), n, t, h, w, cin, cout, kt, kh, kw, dt,
-                                  _p(ws), wsb, _stream()), "vvae_conv3d_dgrad")
-    return out
+    return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1)
 
 
 def conv3d_wgrad_raw(x, dy, kshape, want_bias=True):
@@ -97,8 +166,11 @@ def conv3d_wgrad_raw(x, dy, kshape, want_bias=True):
     dt = _dt(x)
     wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 2)
     ws, wsb = _ws(wsb, x.device)
-    check(lib().vvae_conv3d_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), _p(db), n, t, h, w, cin, cout, kt, kh, kw, dt,
-                                  _p(ws), wsb, _stream()), "vvae_conv3d_wgrad")
+    vox = n * t * h * w
+    tag = f"conv3d_wgrad {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
+    check(_launch(tag, vox * (cin + cout) * x.element_size(), 2 * vox * kt * kh * kw * cin * cout, "conv3d_wgrad",
+                  lambda: lib().vvae_conv3d_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), _p(db), n, t, h, w, cin, cout, kt, kh, kw, dt,
+                                                  _p(ws), wsb, _stream())), "vvae_conv3d_wgrad")
     return dw, db
 
 
