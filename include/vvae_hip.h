@@ -97,6 +97,29 @@ int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, 
                            const uint8_t* mask, int mask_div, float* dq_scale, float* dk_scale,
                            int A, int T, int heads, int D, float eps, int dtype, void* stream);
 
+/* lane-per-frame form of the same core for head_dim D in {8,16,32,64} (the production path): forward also writes the
+ * row log-sum-exp `lse` (A*heads, T) fp32; backward consumes (out, lse) and writes per-workgroup partials of the
+ * q_norm / k_norm scale gradients: dscale_part (vvae_temporal_attn_fast_blocks(...), 2*D) fp32, summed by the caller. */
+int vvae_temporal_attn_fast_supported(int T, int D, int ld, int ldo, int dtype);
+int vvae_temporal_attn_fast_blocks(int A, int T, int heads);
+int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, int ldo, float* lse, const float* q_scale,
+                                const float* k_scale, const float* cos_table, const float* sin_table, const uint8_t* mask,
+                                int mask_div, int A, int T, int heads, int D, float eps, int dtype, void* stream);
+int vvae_temporal_attn_bwd_fast(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse,
+                                void* dqkv, int lddq, const float* q_scale, const float* k_scale, const float* cos_table,
+                                const float* sin_table, const uint8_t* mask, int mask_div, float* dscale_part,
+                                int A, int T, int heads, int D, float eps, int dtype, void* stream);
+
+/* ---- LayerNorm(eps, fast variance, fp32 stats): nnx.LayerNorm at train/layers.py:17,152,155-156,178.
+ *      x row r at x + (r / inner) * outer_pitch + (r % inner) * inner_pitch (elements); y, dy, dx contiguous (rows, C).
+ *      bwd writes per-workgroup partials part (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy]. ---- */
+int vvae_layernorm_supported(int C, int dtype);
+int vvae_layernorm_bwd_blocks(long rows, int C, int dtype);
+int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                       long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps, int dtype, void* stream);
+int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                       float* part, long rows, int C, int inner, long outer_pitch, long inner_pitch, int dtype, void* stream);
+
 /* ---- reparameterise + KL: train/model.py:124-128, train/rl_nonadversarial.py:146-147. ---- */
 int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, const float* mask, float* z, float* kl,
                         int B, int T, long per, int dtype, void* stream);

@@ -176,11 +176,15 @@ def _attn_ref(qkv, qs, ks, mask, heads, max_len, dtype):
     return OL.dot_product_attention(q, k, v, mask, dtype).reshape(a, t, -1)
 
 
-@pytest.mark.parametrize("a,t,heads,d", [(6, 16, 8, 64), (5, 5, 4, 32), (3, 32, 2, 64), (2, 64, 1, 64), (4, 7, 2, 16)])
+@pytest.mark.parametrize("a,t,heads,d", [(6, 16, 8, 64), (5, 5, 4, 32), (3, 32, 2, 64), (2, 64, 1, 64), (4, 7, 2, 16),
+                                         (9, 16, 4, 8), (3, 12, 2, 24)])
 @pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_temporal_attention_core(dev, a, t, heads, d, masked, dtype):
+@pytest.mark.parametrize("generic", [False, True])
+def test_temporal_attention_core(dev, a, t, heads, d, masked, dtype, generic):
+    """generic=False: lane-per-frame kernels (head_dim 8/16/32/64); generic=True (and head_dim 24): the any-shape kernels."""
     ops = _ops()
+    ops.ATTN_FORCE_GENERIC[0] = generic
     qkv = rnd((a, t, 3 * heads * d), 19).to(dtype).float()
     qs = 1 + 0.2 * rnd((d,), 20); ks = 1 + 0.2 * rnd((d,), 21)
     go = rnd((a, t, heads * d), 22).to(dtype).float()
@@ -194,8 +198,11 @@ def test_temporal_attention_core(dev, a, t, heads, d, masked, dtype):
     yo.backward(go)
     xg = qkv.to(dev, dtype).requires_grad_(True); qsg = qs.to(dev).requires_grad_(True); ksg = ks.to(dev).requires_grad_(True)
     m8 = mask.reshape(a, t).to(torch.uint8).to(dev) if masked else None
-    yg = ops.temporal_attention_core(xg, qsg, ksg, cos.to(dev), sin.to(dev), m8, 1, heads)
-    yg.backward(go.to(dev, dtype))
+    try:
+        yg = ops.temporal_attention_core(xg, qsg, ksg, cos.to(dev), sin.to(dev), m8, 1, heads)
+        yg.backward(go.to(dev, dtype))
+    finally:
+        ops.ATTN_FORCE_GENERIC[0] = False
     if dtype == torch.float32:
         assert_close(yg, yo, what="out")
         assert_close_scaled(xg.grad, xo.grad, what="dqkv")
@@ -322,3 +329,44 @@ def test_conv3d_bf16_fast_path(dev, case):
     yo.backward(gy)
     assert_close(y_fast, yo, rtol=2e-2, atol=2e-2, what="fast vs oracle y")
     assert_close_scaled(dx_fast, xo.grad, rel=2e-2, what="fast vs oracle dx")
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 768), (2, 5, 4, 64), (4, 9, 96), (1, 3, 1024), (5, 40)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("use_bias", [True, False])
+def test_layer_norm(dev, shape, dtype, use_bias):
+    ops = _ops()
+    c = shape[-1]
+    x = (rnd(shape, 60) * 1.3 + 0.2).to(dtype).float()
+    sc = 1 + 0.2 * rnd((c,), 61); bi = 0.1 * rnd((c,), 62) if use_bias else None
+    gy = rnd(shape, 63).to(dtype).float()
+    xo = x.clone().requires_grad_(True); so = sc.clone().requires_grad_(True)
+    bo = bi.clone().requires_grad_(True) if use_bias else None
+    yo = O.layer_norm(xo, so, bo, dtype)
+    yo.backward(gy)
+    xg = x.to(dev, dtype).requires_grad_(True); sg = sc.to(dev).requires_grad_(True)
+    bg = bi.to(dev).requires_grad_(True) if use_bias else None
+    assert ops.layer_norm_supported(xg)
+    yg = ops.layer_norm(xg, sg, bg)
+    yg.backward(gy.to(dev, dtype))
+    r = 1e-3 if dtype == torch.float32 else 2e-2
+    assert_close(yg, yo, rtol=r, atol=(1e-4 if dtype == torch.float32 else 2e-2), what="y")
+    assert_close_scaled(xg.grad, xo.grad, rel=r, what="dx")
+    assert_close_scaled(sg.grad, so.grad, rel=r, what="dscale")
+    if use_bias:
+        assert_close_scaled(bg.grad, bo.grad, rel=r, what="dbias")
+
+
+def test_layer_norm_strided_head_view(dev):
+    """q_norm on the q third of a fused QKV buffer, normalised in place of a gather copy (two-level row strides)."""
+    ops = _ops()
+    b, s, h, d = 2, 5, 4, 64
+    qkv = rnd((b, s, 3 * h * d), 64)
+    sc = 1 + 0.2 * rnd((d,), 65)
+    q = qkv[..., :h * d].reshape(b, s, h, d)
+    want = O.layer_norm(q, sc, None)
+    qg = qkv.to(dev)[..., h * d:2 * h * d].unflatten(-1, (h, d))           # k third: non-contiguous view
+    want = O.layer_norm(qkv[..., h * d:2 * h * d].reshape(b, s, h, d), sc, None)
+    assert not qg.is_contiguous()
+    got = ops.layer_norm(qg, sc.to(dev), None)
+    assert_close(got, want, what="strided LN")

@@ -460,23 +460,29 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, float* __restrict__ dbias,
                                                            int nblk, int taps, int CI, int CO, int CIB, int COB)
 {
+    // 256 threads = 32 output elements x 8 slab lanes; fixed summation order (lane-strided, then a fixed tree) => reproducible
+    __shared__ float red[8][32];
     const int co_subs = CO / COB, nsub = (CI / CIB) * co_subs;
     const long slab_floats = (long)taps * CIB * COB + COB;
     const long total = (long)taps * CI * CO;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int el = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + el;
+    long base = -1;
     if (i < total) {
         const int co = (int)(i % CO); const long r = i / CO; const int ci = (int)(r % CI); const int tap = (int)(r / CI);
-        const int sub = (ci / CIB) * co_subs + co / COB;
-        const long off = ((long)tap * CIB + ci % CIB) * COB + co % COB;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += slab[((long)b * nsub + sub) * slab_floats + off];
-        dw[i] = s;
+        base = (long)((ci / CIB) * co_subs + co / COB) * slab_floats + ((long)tap * CIB + ci % CIB) * COB + co % COB;
     } else if (dbias && i < total + CO) {
         const int co = (int)(i - total);
-        const int sub = co / COB;                              // ci-sub 0
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += slab[((long)b * nsub + sub) * slab_floats + (long)taps * CIB * COB + co % COB];
-        dbias[co] = s;
+        base = (long)(co / COB) * slab_floats + (long)taps * CIB * COB + co % COB;          // ci-sub 0
+    }
+    float s = 0.f;
+    if (base >= 0)
+        for (int b = bl; b < nblk; b += 8) s += slab[(long)b * nsub * slab_floats + base];
+    red[bl][el] = s;
+    __syncthreads();
+    if (bl == 0 && base >= 0) {
+        const float t = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+        if (i < total) dw[i] = t; else dbias[i - total] = t;
     }
 }
 
@@ -523,7 +529,7 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
     VVAE_LAUNCH_CHECK();
     const int taps = C::KT * C::KH * C::KW;
     const long total = (long)taps * CI * CO + CO;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)ws, dw, dbias, nblk, taps, CI,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 32)), dim3(256), 0, s, (const float*)ws, dw, dbias, nblk, taps, CI,
                        CO, C::CIB, C::COB);
     VVAE_LAUNCH_CHECK();
     return 0;

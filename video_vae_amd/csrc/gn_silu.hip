@@ -20,6 +20,32 @@ struct GnDims {
     int N; long S; int C, G; float eps;      // S = voxels per sample
 };
 
+// Sum (a, b) over the threads that share a channel column (tid % cvecs); threads tid < cvecs end with the block totals.
+// Power-of-two cvecs <= 64: xor-shuffles across the wave, then one LDS hop across the 4 waves.  Otherwise (odd channel
+// counts on the unvectorised path) a plain LDS gather by the column owners.  red: [256][2] floats.  Ends synchronised.
+__device__ __forceinline__ void column_reduce(float& a, float& b, int cvecs, int rows, float (*red)[2])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cvecs <= 64 && (cvecs & (cvecs - 1)) == 0) {
+        for (int o = 32; o >= cvecs; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        __syncthreads();                      // previous use of red is finished
+        if (lane < cvecs) { red[wave * 64 + lane][0] = a; red[wave * 64 + lane][1] = b; }
+        __syncthreads();
+        if (tid < cvecs) {
+            a = red[tid][0] + red[64 + tid][0] + red[128 + tid][0] + red[192 + tid][0];
+            b = red[tid][1] + red[64 + tid][1] + red[128 + tid][1] + red[192 + tid][1];
+        }
+    } else {
+        __syncthreads();
+        red[tid][0] = a; red[tid][1] = b;
+        __syncthreads();
+        if (tid < cvecs) {
+            a = 0.f; b = 0.f;
+            for (int r2 = 0; r2 < rows; ++r2) { a += red[r2 * cvecs + tid][0]; b += red[r2 * cvecs + tid][1]; }
+        }
+    }
+}
+
 // Thread layout shared by all kernels: cvecs = C/VEC lanes across channels, rows = 256/cvecs voxels per pass.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int ldx, GnDims d,
@@ -47,15 +73,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     // reduce over rows for each channel, one channel-of-the-vector at a time
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        red[threadIdx.x][0] = s[i]; red[threadIdx.x][1] = ss[i];
-        __syncthreads();
-        if (rl == 0) {
-            float a = 0.f, b = 0.f;
-            for (int r2 = 0; r2 < rows; ++r2) { a += red[r2 * cvecs + cl][0]; b += red[r2 * cvecs + cl][1]; }
-            chan[cl * VEC + i][0] = a; chan[cl * VEC + i][1] = b;
-        }
-        __syncthreads();
+        float a = s[i], b = ss[i];
+        column_reduce(a, b, cvecs, rows, red);
+        if (threadIdx.x < cvecs) { chan[cl * VEC + i][0] = a; chan[cl * VEC + i][1] = b; }
     }
+    __syncthreads();
     const int cpg = d.C / d.G;
     if (threadIdx.x < d.G) {
         double a = 0.0, b = 0.0;
@@ -164,16 +186,13 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __rest
         }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        red[threadIdx.x][0] = s1[i]; red[threadIdx.x][1] = s2[i];
-        __syncthreads();
-        if (rl == 0) {
-            double a = 0.0, b = 0.0;
-            for (int r2 = 0; r2 < rows; ++r2) { a += red[r2 * cvecs + cl][0]; b += red[r2 * cvecs + cl][1]; }
+        float a = s1[i], b = s2[i];
+        column_reduce(a, b, cvecs, rows, red);
+        if (threadIdx.x < cvecs) {
             const int c = cl * VEC + i;
-            atomicAdd(csum + ((long)n * d.C + c) * 2, a);
-            atomicAdd(csum + ((long)n * d.C + c) * 2 + 1, b);
+            atomicAdd(csum + ((long)n * d.C + c) * 2, (double)a);
+            atomicAdd(csum + ((long)n * d.C + c) * 2 + 1, (double)b);
         }
-        __syncthreads();
     }
 }
 
@@ -234,9 +253,10 @@ __global__ void gn_param_grad_kernel(const double* __restrict__ csum, int N, int
     dbeta[c] = (float)b;
 }
 
-inline int pick_vpb(long S, int N) {
-    // ~4096 blocks over the whole tensor, at least 128 voxels each
-    long want = 4096 / (N > 0 ? N : 1);
+inline int pick_vpb(long S, int N, int total_blocks = 4096) {
+    // ~total_blocks workgroups over the whole tensor, at least 128 voxels each.  The reducing kernels pay a fixed
+    // epilogue per workgroup (cross-wave folds + fp64 atomics), so they take fewer, longer workgroups (~4 per CU).
+    long want = total_blocks / (N > 0 ? N : 1);
     if (want < 1) want = 1;
     long vpb = (S + want - 1) / want;
     if (vpb < 128) vpb = 128;
@@ -275,7 +295,7 @@ extern "C" int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)N * G, s);
     if (e != hipSuccess) return (int)e;
-    const int vpb = pick_vpb(S, N);
+    const int vpb = pick_vpb(S, N, 1024);
     dim3 grid(ceil_div(S, vpb), N);
     const bool vok = dtype == VVAE_DT_F32 ? vec_ok<float>(x, ldx, C) : vec_ok<bf16_t>(x, ldx, C);
     if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
@@ -318,8 +338,12 @@ extern "C" int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy
         ? (vec_ok<float>(x, ldx, C) && vec_ok<float>(dy, lddy, C) && vec_ok<float>(dx, lddx, C))
         : (vec_ok<bf16_t>(x, ldx, C) && vec_ok<bf16_t>(dy, lddy, C) && vec_ok<bf16_t>(dx, lddx, C));
     if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
-    GN_DISPATCH(gn_silu_bwd_reduce_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, sums, gamma, beta, d, csum, vpb);
-    VVAE_LAUNCH_CHECK();
+    {
+        const int vpb_r = pick_vpb(S, N, 1024);
+        dim3 grid(ceil_div(S, vpb_r), N);
+        GN_DISPATCH(gn_silu_bwd_reduce_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, sums, gamma, beta, d, csum, vpb_r);
+        VVAE_LAUNCH_CHECK();
+    }
     GN_DISPATCH(gn_silu_bwd_apply_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, sums, csum, gamma, beta, d, vpb);
     VVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, csum, N, C, dgamma, dbeta);

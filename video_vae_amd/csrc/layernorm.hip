@@ -1,0 +1,248 @@
+// LayerNorm(eps=1e-6, fast variance, fp32 statistics) over the last axis, forward and backward.
+//
+// Replaces nnx.LayerNorm at /root/reference/train/layers.py:17,152,178 (PatchEmbedding.norm, Attention.input_norm,
+// MLP.norm) and :155-156 (q_norm / k_norm, use_bias=False) -- 127 LayerNorms per training step of the production model.
+// Pure HBM streams: a row lives in registers (16-byte vector loads, LPR lanes per row), statistics by xor-shuffles inside
+// the LPR-lane group, one read of x (+dy) and one write per pass.  Backward keeps per-lane column sums of dy*xhat and dy
+// across the rows a wave walks and emits ONE partial row per workgroup (the caller sums them): no atomics, deterministic.
+//
+// Rows may be strided in two levels (row r at base + (r / inner) * outer_pitch + (r % inner) * inner_pitch) so a per-head
+// slice of a fused QKV buffer is normalised in place without a gather copy.
+#include "common.hpp"
+
+namespace {
+
+struct LnDims { long rows; int C; int inner; long outer_pitch; long inner_pitch; float eps; };
+
+__device__ __forceinline__ long row_off(const LnDims& d, long r) { return (r / d.inner) * d.outer_pitch + (r % d.inner) * d.inner_pitch; }
+
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// y rows are written contiguously (pitch C).  mean / rstd: fp32 [rows] (saved for backward).
+template <typename T_, int LPR, int VPL>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict__ x, T_* __restrict__ y, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, LnDims d)
+{
+    constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;          // rows per wave-iteration
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, ll = lane % LPR;
+    const long rstride = (long)gridDim.x * 4 * RPW;
+    for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
+        const long r = r0 + sub;
+        const bool rv = r < d.rows;
+        const T_* xr = x + row_off(d, rv ? r : 0);
+        float v[VPL][V];
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = (k * LPR + ll) * V;
+            if (rv && c < d.C) {
+                VecIO<T_, V>::load(xr + c, v[k]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) { s += v[k][e]; ss += v[k][e] * v[k][e]; }
+            }
+        }
+        s = group_sum<LPR>(s); ss = group_sum<LPR>(ss);
+        const float mean = s / d.C;
+        float var = ss / d.C - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + d.eps);
+        if (rv && ll == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+        T_* yr = y + r * d.C;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = (k * LPR + ll) * V;
+            if (rv && c < d.C) {
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    o[e] = (v[k][e] - mean) * (rstd * gamma[c + e]);
+                    if (beta) o[e] += beta[c + e];
+                }
+                VecIO<T_, V>::store(yr + c, o);
+            }
+        }
+    }
+}
+
+// dy rows contiguous (pitch C); dx rows contiguous.  part: fp32 [gridDim.x][2][C] = per-workgroup (sum dy*xhat | sum dy).
+template <typename T_, int LPR, int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict__ x, const T_* __restrict__ dy, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            T_* __restrict__ dx, float* __restrict__ part, LnDims d)
+{
+    constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;
+    __shared__ float red[4][64][VPL * V];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, ll = lane % LPR;
+    float ag[VPL][V], ab[VPL][V];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+    const long rstride = (long)gridDim.x * 4 * RPW;
+    for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
+        const long r = r0 + sub;
+        const bool rv = r < d.rows;
+        const T_* xr = x + row_off(d, rv ? r : 0);
+        const T_* gr = dy + (rv ? r : 0) * d.C;
+        const float mean = rv ? mean_in[r] : 0.f, rstd = rv ? rstd_in[r] : 0.f;
+        float xh[VPL][V], g[VPL][V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = (k * LPR + ll) * V;
+            if (rv && c < d.C) {
+                VecIO<T_, V>::load(xr + c, xh[k]);
+                VecIO<T_, V>::load(gr + c, g[k]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    xh[k][e] = (xh[k][e] - mean) * rstd;
+                    ag[k][e] += g[k][e] * xh[k][e];
+                    ab[k][e] += g[k][e];
+                    g[k][e] *= gamma[c + e];
+                    s1 += g[k][e]; s2 += g[k][e] * xh[k][e];
+                }
+            }
+        }
+        s1 = group_sum<LPR>(s1) / d.C; s2 = group_sum<LPR>(s2) / d.C;
+        T_* dr = dx + r * d.C;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = (k * LPR + ll) * V;
+            if (rv && c < d.C) {
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = rstd * (g[k][e] - s1 - xh[k][e] * s2);
+                VecIO<T_, V>::store(dr + c, o);
+            }
+        }
+    }
+    // column partials: fold the RPW row-slots of a wave (lanes with equal ll), then the 4 waves, fixed order
+    float* pg = part + (long)blockIdx.x * 2 * d.C;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float t = pass ? ab[k][e] : ag[k][e];
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+                red[wave][lane][k * V + e] = t;
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) {
+            const int l2 = i / (VPL * V), kv = i % (VPL * V);
+            const int c = ((kv / V) * LPR + l2) * V + kv % V;
+            if (c < d.C) pg[pass * d.C + c] = (red[0][l2][kv] + red[1][l2][kv]) + (red[2][l2][kv] + red[3][l2][kv]);
+        }
+        __syncthreads();
+    }
+}
+
+inline int ln_blocks(long rows, int lpr)
+{
+    const long per = 4L * (64 / lpr);
+    long b = (rows + per - 1) / per;
+    if (b > 1024) b = 1024;
+    return (int)(b < 1 ? 1 : b);
+}
+
+// pick lanes-per-row: smallest power of two >= C/V capped at 64; vectors per lane up to 4
+inline bool ln_pick(int C, int V, int& lpr, int& vpl)
+{
+    if (C % V) return false;
+    const int nv = C / V;
+    lpr = 8;
+    while (lpr < 64 && lpr < nv) lpr <<= 1;
+    vpl = (nv + lpr - 1) / lpr;
+    return vpl <= 4;
+}
+
+template <typename T_>
+bool ln_ok(const LnDims& d, const void* x, int& lpr, int& vpl)
+{
+    constexpr int V = VecWidth<T_>::value;
+    if (d.rows <= 0 || d.C <= 0 || d.inner <= 0) return false;
+    if (!ln_pick(d.C, V, lpr, vpl)) return false;
+    return ((uintptr_t)x % 16) == 0 && d.outer_pitch % V == 0 && d.inner_pitch % V == 0;
+}
+
+}  // namespace
+
+#define LN_SWITCH(KERNEL, T_, ...)                                                                                                   \
+    do {                                                                                                                             \
+        switch (lpr * 8 + vpl) {                                                                                                     \
+            case 8 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 8, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                       \
+            case 16 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 16, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
+            case 32 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 32, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
+            case 64 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 64, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
+            case 64 * 8 + 2: hipLaunchKernelGGL((KERNEL<T_, 64, 2>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
+            case 64 * 8 + 3: hipLaunchKernelGGL((KERNEL<T_, 64, 3>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
+            default: hipLaunchKernelGGL((KERNEL<T_, 64, 4>), grid, dim3(256), 0, s, __VA_ARGS__); break;                             \
+        }                                                                                                                            \
+    } while (0)
+
+// 1 if vvae_layernorm_* take this shape (C a multiple of the 16-byte vector, C <= 2048 bf16 / 1024 fp32).
+extern "C" int vvae_layernorm_supported(int C, int dtype)
+{
+    int lpr, vpl;
+    return ln_pick(C, dtype == VVAE_DT_F32 ? 4 : 8, lpr, vpl) ? 1 : 0;
+}
+
+// Workgroups the backward kernel uses = rows of its partial buffer (each 2*C floats).
+extern "C" int vvae_layernorm_bwd_blocks(long rows, int C, int dtype)
+{
+    int lpr, vpl;
+    if (!ln_pick(C, dtype == VVAE_DT_F32 ? 4 : 8, lpr, vpl)) return 0;
+    return ln_blocks(rows, lpr);
+}
+
+// x: rows of C elements, row r at x + (r / inner) * outer_pitch + (r % inner) * inner_pitch (elements); y contiguous (rows, C).
+// gamma fp32 [C]; beta fp32 [C] or NULL; mean, rstd fp32 [rows] written.
+extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                                  long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps, int dtype, void* stream)
+{
+    if (!x || !y || !gamma || !mean || !rstd) return VVAE_ERR_BAD_ARG;
+    LnDims d{rows, C, inner, outer_pitch, inner_pitch, eps};
+    hipStream_t s = (hipStream_t)stream;
+    int lpr, vpl;
+    if (dtype == VVAE_DT_F32) {
+        if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
+        dim3 grid(ln_blocks(rows, lpr));
+        LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, d);
+    } else if (dtype == VVAE_DT_BF16) {
+        if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
+        dim3 grid(ln_blocks(rows, lpr));
+        LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, d);
+    } else return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dy, dx contiguous (rows, C).  part: fp32 (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy] per workgroup.
+extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                  float* part, long rows, int C, int inner, long outer_pitch, long inner_pitch, int dtype, void* stream)
+{
+    if (!x || !dy || !gamma || !mean || !rstd || !dx || !part) return VVAE_ERR_BAD_ARG;
+    LnDims d{rows, C, inner, outer_pitch, inner_pitch, 0.f};
+    hipStream_t s = (hipStream_t)stream;
+    int lpr, vpl;
+    if (dtype == VVAE_DT_F32) {
+        if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return VVAE_ERR_BAD_ARG;
+        dim3 grid(ln_blocks(rows, lpr));
+        LN_SWITCH(layernorm_bwd_kernel, float, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, part, d);
+    } else if (dtype == VVAE_DT_BF16) {
+        if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return VVAE_ERR_BAD_ARG;
+        dim3 grid(ln_blocks(rows, lpr));
+        LN_SWITCH(layernorm_bwd_kernel, bf16_t, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, part, d);
+    } else return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

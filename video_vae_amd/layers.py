@@ -42,6 +42,8 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         x = x.to(self.dtype)
+        if ops.layer_norm_supported(x):
+            return ops.layer_norm(x, self.scale, self.bias, 1e-6)          # HIP kernel, fp32 statistics and affine
         b = self.bias.to(self.dtype) if self.bias is not None else None
         return F.layer_norm(x, (x.shape[-1],), self.scale.to(self.dtype), b, 1e-6)
 
@@ -79,7 +81,14 @@ class PatchUnEmbedding(nn.Module):
         x = self.upsample(self.linear(x))
         feat = rearrange(x, "b t (h w) (p1 p2 c u) -> b t (h p1) (w p2) (c u)", p1=self.patch_size, p2=self.patch_size,
                          h=self.height // self.patch_size, w=self.width // self.patch_size, u=self.upsample_rate)
-        return feat, self.downsample(feat)
+        if feat.is_cuda:
+            # Linear(c*u -> c) over every voxel of the full-resolution volume = a 1x1x1 conv: HBM-bound, far too skinny
+            # for a BLAS GEMM (12 -> 3 channels over 4M rows), so it runs on the pointwise path of the conv kernels.
+            ds = self.downsample
+            coarse = ops.conv3d(feat.to(ds.dtype), ds.kernel.view(1, 1, 1, *ds.kernel.shape), ds.bias)
+        else:
+            coarse = self.downsample(feat)
+        return feat, coarse
 
 
 def rotate_half(x):

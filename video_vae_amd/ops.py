@@ -366,34 +366,61 @@ def conv_transpose_1x2x2(x, kernel, bias):
 
 
 # --------------------------------------------------------------------------------------------- temporal attention core
+ATTN_FORCE_GENERIC = [False]      # test hook: use the generic (any head_dim) kernels
+
+
 class _TemporalAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, q_scale, k_scale, cos, sin, mask, mask_div, heads, eps):
         qkv, ld = rows(qkv)
         a, t, c3 = qkv.shape
         d = c3 // (3 * heads)
+        dt = _dt(qkv)
         qs, ks = _f32(q_scale), _f32(k_scale)
         out = torch.empty((a, t, heads * d), dtype=qkv.dtype, device=qkv.device)
-        check(lib().vvae_temporal_attn_fwd(_p(qkv), ld, _p(out), heads * d, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div,
-                                           a, t, heads, d, eps, _dt(qkv), _stream()), "vvae_temporal_attn_fwd")
-        ctx.save_for_backward(qkv, qs, ks, cos, sin, mask)
-        ctx.args = (mask_div, heads, eps, q_scale.dtype)
+        fast = (not ATTN_FORCE_GENERIC[0]) and lib().vvae_temporal_attn_fast_supported(t, d, ld, heads * d, dt) == 1
+        lse = None
+        nbytes = a * t * heads * d * 4 * qkv.element_size()
+        if fast:
+            lse = torch.empty((a * heads, t), dtype=torch.float32, device=qkv.device)
+            check(_launch(f"temporal_attn_fwd T{t} D{d}", nbytes, 4 * a * heads * t * t * d, "tattn_fwd_fast",
+                          lambda: lib().vvae_temporal_attn_fwd_fast(_p(qkv), ld, _p(out), heads * d, _p(lse), _p(qs), _p(ks), _p(cos),
+                                                                    _p(sin), _p(mask), mask_div, a, t, heads, d, eps, dt, _stream())),
+                  "vvae_temporal_attn_fwd_fast")
+        else:
+            check(lib().vvae_temporal_attn_fwd(_p(qkv), ld, _p(out), heads * d, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div,
+                                               a, t, heads, d, eps, dt, _stream()), "vvae_temporal_attn_fwd")
+        ctx.save_for_backward(qkv, qs, ks, cos, sin, mask, out, lse)
+        ctx.args = (mask_div, heads, eps, q_scale.dtype, fast)
         return out
 
     @staticmethod
     def backward(ctx, do):
-        qkv, qs, ks, cos, sin, mask = ctx.saved_tensors
-        mask_div, heads, eps, pdtype = ctx.args
+        qkv, qs, ks, cos, sin, mask, out, lse = ctx.saved_tensors
+        mask_div, heads, eps, pdtype, fast = ctx.args
         qkv, ld = rows(qkv)
         do, lddo = rows(do.to(qkv.dtype))
         a, t, c3 = qkv.shape
         d = c3 // (3 * heads)
+        dt = _dt(qkv)
         dqkv = torch.empty((a, t, c3), dtype=qkv.dtype, device=qkv.device)
-        dqs = torch.empty((d,), dtype=torch.float32, device=qkv.device)
-        dks = torch.empty((d,), dtype=torch.float32, device=qkv.device)
-        check(lib().vvae_temporal_attn_bwd(_p(qkv), ld, _p(do), lddo, _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask),
-                                           mask_div, _p(dqs), _p(dks), a, t, heads, d, eps, _dt(qkv), _stream()),
-              "vvae_temporal_attn_bwd")
+        if fast:
+            nblk = lib().vvae_temporal_attn_fast_blocks(a, t, heads)
+            part = torch.empty((nblk, 2 * d), dtype=torch.float32, device=qkv.device)
+            nbytes = a * t * heads * d * 8 * qkv.element_size()
+            check(_launch(f"temporal_attn_bwd T{t} D{d}", nbytes, 10 * a * heads * t * t * d, "tattn_bwd_fast",
+                          lambda: lib().vvae_temporal_attn_bwd_fast(_p(qkv), ld, _p(out), heads * d, _p(do), lddo, _p(lse), _p(dqkv), c3,
+                                                                    _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div, _p(part),
+                                                                    a, t, heads, d, eps, dt, _stream())),
+                  "vvae_temporal_attn_bwd_fast")
+            tot = part.sum(0)
+            dqs, dks = tot[:d], tot[d:]
+        else:
+            dqs = torch.empty((d,), dtype=torch.float32, device=qkv.device)
+            dks = torch.empty((d,), dtype=torch.float32, device=qkv.device)
+            check(lib().vvae_temporal_attn_bwd(_p(qkv), ld, _p(do), lddo, _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask),
+                                               mask_div, _p(dqs), _p(dks), a, t, heads, d, eps, dt, _stream()),
+                  "vvae_temporal_attn_bwd")
         return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None, None, None
 
 
@@ -489,3 +516,71 @@ class _MaskedMseMae(torch.autograd.Function):
 def masked_mse_mae(video, recon, mask_bt, video_div=1):
     """Per-sample masked MSE and MAE (reference train/rl_nonadversarial.py:114-121); gradient flows to recon only."""
     return _MaskedMseMae.apply(video, recon, mask_bt, video_div)
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+def _rows2(x):
+    """x (..., C) as rows with two-level strides: row r at (r // inner) * outer_pitch + (r % inner) * inner_pitch.
+
+    Returns (tensor, rows, inner, outer_pitch, inner_pitch); copies only if the layout cannot be expressed that way."""
+    c = x.shape[-1]
+    n = x.numel() // c
+    if x.is_contiguous():
+        return x, n, 1, c, 0
+    if x.dim() >= 3 and x.stride(-1) == 1:
+        inner, ip = x.shape[-2], x.stride(-2)
+        lead = x.shape[:-2]
+        ok, pitch = True, None
+        # leading dims must collapse to one uniform outer pitch
+        strides = [x.stride(i) for i in range(len(lead))]
+        for i in range(len(lead) - 1):
+            if lead[i] != 1 and strides[i] != strides[i + 1] * lead[i + 1]:
+                ok = False
+        if ok and len(lead) >= 1:
+            pitch = strides[-1]
+            return x, n, inner, pitch, ip
+    x = x.contiguous()
+    return x, n, 1, c, 0
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, bias, eps):
+        x, n, inner, op, ip = _rows2(x)
+        c = x.shape[-1]
+        dt = _dt(x)
+        s32 = _f32(scale)
+        b32 = _f32(bias) if bias is not None else None
+        y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        mean = torch.empty((n,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((n,), dtype=torch.float32, device=x.device)
+        check(_launch(f"layernorm_fwd C{c}", 2 * x.numel() * x.element_size(), 0, "layernorm_fwd_kernel",
+                      lambda: lib().vvae_layernorm_fwd(_p(x), _p(y), _p(s32), _p(b32), _p(mean), _p(rstd), n, c, inner, op, ip, eps, dt,
+                                                       _stream())), "vvae_layernorm_fwd")
+        ctx.save_for_backward(x, s32, mean, rstd)
+        ctx.args = (n, c, inner, op, ip, scale.dtype, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s32, mean, rstd = ctx.saved_tensors
+        n, c, inner, op, ip, pdtype, has_bias = ctx.args
+        dt = _dt(x)
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        nblk = lib().vvae_layernorm_bwd_blocks(n, c, dt)
+        part = torch.empty((nblk, 2, c), dtype=torch.float32, device=x.device)
+        check(_launch(f"layernorm_bwd C{c}", 3 * x.numel() * x.element_size(), 0, "layernorm_bwd_kernel",
+                      lambda: lib().vvae_layernorm_bwd(_p(x), _p(dy), _p(s32), _p(mean), _p(rstd), _p(dx), _p(part), n, c, inner, op, ip,
+                                                       dt, _stream())), "vvae_layernorm_bwd")
+        tot = part.sum(0)
+        return dx, tot[0].to(pdtype), (tot[1].to(pdtype) if has_bias else None), None
+
+
+def layer_norm_supported(x):
+    return x.is_cuda and x.dtype in DT and lib().vvae_layernorm_supported(x.shape[-1], DT[x.dtype]) == 1
+
+
+def layer_norm(x, scale, bias=None, eps=1e-6):
+    """nnx.LayerNorm over the last axis, fp32 statistics (reference train/layers.py:17,152,155-156,178)."""
+    return _LayerNorm.apply(x, scale, bias, eps)

@@ -5,6 +5,7 @@ libvvae_hip.so through ``ops``.  Parameters keep Flax names and layouts (``conv.
 (kt, kh, kw, Cin, Cout), ``norm.scale``/``norm.bias``) so checkpoints and the oracle share a key space.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -61,8 +62,9 @@ class ConvBlock3D(nn.Module):
         self.conv = Conv(in_channels, out_channels, (temporal_kernel, kernel_size, kernel_size), rngs, dtype, param_dtype)
         self.norm = GroupNorm(min(8, out_channels), out_channels, param_dtype)
 
-    def forward(self, x):
-        x = self.conv(x)
+    def forward(self, x, kernel=None):
+        # ``kernel``: optional stand-in for self.conv.kernel (UNet passes a zero-padded view for 16-channel alignment)
+        x = ops.conv3d(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias)
         return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6)
 
 
@@ -74,8 +76,8 @@ class DownBlock3D(nn.Module):
         self.conv1 = ConvBlock3D(in_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
         self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
 
-    def forward(self, x):
-        x = self.conv2(self.conv1(x))
+    def forward(self, x, kernel1=None):
+        x = self.conv2(self.conv1(x, kernel1))
         return ops.max_pool_1x2x2(x), x
 
 
@@ -124,10 +126,20 @@ class UNet(nn.Module):
 
     def forward(self, x):
         x = x.to(self.dtype)
-        x = self.patch_mixer(x)
+        c = x.shape[-1]
+        pad = (-c) % 16 if (x.is_cuda and self.dtype == torch.bfloat16 and len(self.encoders) > 0) else 0
+        k1 = None
+        if pad:
+            # bf16 MFMA kernels want channel counts in multiples of 16: run the mixer and the first encoder conv on
+            # zero-padded channels (zero weights in the pad rows/columns => identical results, grads sliced by autograd)
+            x = F.pad(x, (0, pad))
+            x = ops.conv3d(x, F.pad(self.patch_mixer.kernel, (0, pad, 0, pad)), F.pad(self.patch_mixer.bias, (0, pad)))
+            k1 = F.pad(self.encoders[0].conv1.conv.kernel, (0, 0, 0, pad))
+        else:
+            x = self.patch_mixer(x)
         skips = []
-        for enc in self.encoders:
-            x, skip = enc(x)
+        for i, enc in enumerate(self.encoders):
+            x, skip = enc(x, k1 if i == 0 else None)
             skips.append(skip)
         x = self.bottleneck2(self.bottleneck1(x))
         for dec, skip in zip(self.decoders, reversed(skips)):
