@@ -56,6 +56,7 @@ int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, int Cin, in
 int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
                          int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
                          int prepacked, void* ws, size_t ws_bytes, void* stream);
+size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw);
 int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
                            int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
                            void* ws, size_t ws_bytes, void* stream);

@@ -140,9 +140,7 @@ def test_optimizer_steps_match_oracle(dev):
     po = p0
     for step in range(3):
         grads = {k: rnd(v.shape, 100 + step * 31 + i, 0.3 if step else 5.0) for i, (k, v) in enumerate(p0.items())}
-        opt.zero_grad()
-        for k, prm in m.named_parameters():
-            prm.grad.copy_(grads[k].to(dev))
+        opt.set_grads(grads)
         opt.update()
         po, gn, lr = OOpt.train_update(po, grads, adam, kw)
         assert abs(opt.grad_norm() - float(gn)) <= 1e-4 * float(gn)

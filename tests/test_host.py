@@ -1,0 +1,200 @@
+"""CPU: host logic of the product package -- C-ABI surface, Rngs stand-in, schedule, gradient bucketing, and the
+world_size=2 gloo rehearsal of the data-parallel reducer.  No HIP compute is called here (there is no GPU)."""
+import ctypes
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from video_vae_amd._lib import parse_header, LIB_PATH, lib
+    protos = parse_header()
+    assert len(protos) >= 35
+    assert os.path.exists(LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    raw = ctypes.CDLL(LIB_PATH)
+    for name in protos:
+        assert hasattr(raw, name), f"{name} declared in include/vvae_hip.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and "vvae_" in ln}
+    assert exported == set(protos), (exported ^ set(protos))
+    lib()      # argtypes bind
+
+
+def test_ops_fail_loudly_without_gpu():
+    """No CPU fallback: a CPU tensor must raise, not silently compute."""
+    import video_vae_amd as V
+    from video_vae_amd._lib import VvaeError
+    m = V.UNet(4, 8, 1, 3, V.Rngs(0), dtype=torch.float32)
+    with pytest.raises(VvaeError):
+        m(torch.zeros(1, 2, 8, 8, 4))
+    with pytest.raises(VvaeError):
+        V.ops.group_norm_silu(torch.zeros(1, 2, 4, 4, 8), torch.ones(8), torch.zeros(8), 8)
+
+
+def test_product_never_imports_oracle():
+    code = "import sys; import video_vae_amd; import bench; sys.exit(1 if any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules) else 0)"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-400:]
+
+
+def test_surface_matches_reference_signatures():
+    """constructor / call surface of the reference classes."""
+    import inspect
+    import video_vae_amd as V
+    from video_vae_amd import rl_model
+    assert list(inspect.signature(V.UNet.__init__).parameters)[1:] == [
+        "channels", "base_features", "num_levels", "out_features", "rngs", "temporal_kernel", "dtype", "param_dtype"]
+    vae = ["height", "width", "channels", "patch_size", "encoder_depth", "decoder_depth", "mlp_dim", "num_heads", "qkv_features",
+           "max_temporal_len", "spatial_compression_rate", "unembedding_upsample_rate", "rngs", "dtype", "param_dtype"]
+    assert list(inspect.signature(V.VideoVAE.__init__).parameters)[1:] == vae
+    assert list(inspect.signature(rl_model.VideoVAE.__init__).parameters)[1:] == vae
+    assert list(inspect.signature(V.VideoVAE.forward).parameters)[1:] == ["x", "mask", "rngs", "train"]
+    assert list(inspect.signature(V.load_checkpoint).parameters) == ["model", "optimizer", "path"]
+    assert list(inspect.signature(V.save_checkpoint).parameters) == ["model", "optimizer", "path"]
+    assert list(inspect.signature(V.FactoredAttention.__init__).parameters)[1:8] == [
+        "mlp_dim", "in_features", "num_heads", "qkv_features", "max_temporal_len", "max_spatial_len", "rngs"]
+    m = V.VideoVAE(32, 32, 3, 8, 1, 1, 64, 4, 32, 8, 4, 4, V.Rngs(2))
+    assert hasattr(m, "encoder") and hasattr(m, "decoder") and m.fill_token.shape == (1, 1, 1, 48)
+    assert sum(p.numel() for p in V.UNet(12, 16, 3, 3, V.Rngs(0)).parameters()) == 1_384_927
+    assert float(m.decoder.unet.final_conv.kernel.abs().max()) == 0.0                          # zero-init, unet.py:150
+
+
+def test_rngs_streams_and_injection():
+    import video_vae_amd as V
+    a, b = V.Rngs(3), V.Rngs(3)
+    x1 = a.draw("reparam_eps", "normal", (4, 5), "cpu")
+    x2 = b.draw("reparam_eps", "normal", (4, 5), "cpu")
+    assert torch.equal(x1, x2)
+    assert not torch.equal(a.draw("reparam_eps", "normal", (4, 5), "cpu"), x1)          # a fresh key per call
+    assert not torch.equal(V.Rngs(4).draw("reparam_eps", "normal", (4, 5), "cpu"), x1)  # seed matters
+    inj = torch.ones(4, 5)
+    a.inject("reparam_eps", inj)
+    assert torch.equal(a.draw("reparam_eps", "normal", (4, 5), "cpu"), inj)
+    u = V.Rngs(0).draw("u", "uniform", (1000,), "cpu")
+    assert 0 <= float(u.min()) and float(u.max()) < 1
+
+
+def test_schedule_matches_reference_constants():
+    from video_vae_amd import optim
+    s = optim.reference_schedule(batch_size=2)
+    assert s(0) == 0.0
+    assert abs(s(14142) - 2e-5) < 1e-10
+    assert abs(s(7071) - 1e-5) < 1e-9
+    assert abs(s(10_000_000) - 2e-6) < 1e-12
+    mid = 14142 + (1_000_000 - 14142) / 2
+    assert abs(s(mid) - (2e-6 + (2e-5 - 2e-6) * 0.5)) < 1e-9
+
+
+def _toy():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                               torch.nn.Linear(16, 3))
+
+
+def test_gradient_landing_in_flat_buffer():
+    """Bucketed landing: grads end up in the flat buffer in reverse registration order; unused params land zeros."""
+    from video_vae_amd import optim
+    m = _toy()
+    extra = torch.nn.Parameter(torch.ones(5))
+    m.register_parameter("unused", extra)
+    opt = optim.Optimizer(m, 1e-3, bucket_bytes=256)
+    assert opt.names[0] == "4.bias" and opt.names[-1] == "unused"          # reverse registration order
+    assert len(opt.buckets) > 2 and opt.buckets[0][0] == 0 and opt.buckets[-1][1] == opt.numel
+    x = torch.randn(9, 6)
+    ref = _toy()
+    ref(x).square().mean().backward()
+    opt.zero_grad()
+    m(x).square().mean().backward()
+    for b in range(len(opt.buckets)):
+        if not opt.landed[b]:
+            opt._land(b)
+    for n, p, gv in zip(opt.names, opt.params, opt.gviews):
+        if n == "unused":
+            assert float(gv.abs().max()) == 0.0
+        else:
+            assert torch.allclose(gv, dict(ref.named_parameters())[n].grad, atol=1e-7), n
+        assert p.grad is None
+    assert all(p.data_ptr() >= opt.p.data_ptr() for p in opt.params)         # parameters alias the flat buffer
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from video_vae_amd import optim, ddp
+        torch.set_num_threads(1)
+        m = _toy()
+        if rank == 1:                                   # replicas start different: broadcast must repair it
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(1.0)
+        opt = optim.Optimizer(m, 1e-2, bucket_bytes=256, bf16_shadow=False)
+        red = ddp.GradReducer(opt)
+        red.broadcast_parameters(0)
+        g = torch.Generator().manual_seed(100 + rank)   # per-rank shard: seed + rank
+        res = {}
+        for step in range(3):
+            x = torch.randn((5, 6), generator=g)
+            opt.zero_grad()
+            m(x).square().mean().backward()
+            for b in range(len(opt.buckets)):
+                if not opt.landed[b]:
+                    opt._land(b)
+            red.finish()
+            assert len(red.handles) == 0
+            res[f"g{step}"] = opt.g.clone()
+            res[f"x{step}"] = x
+            with torch.no_grad():                        # stand-in for the HIP Adam kernel: same update on every rank
+                opt.p.add_(opt.g, alpha=-0.05 / world)
+            res[f"p{step}"] = opt.p.clone()
+        (mean_loss,) = ddp.all_reduce_mean_scalars([torch.tensor(float(rank))])
+        res["mean"] = mean_loss
+        torch.save(res, os.path.join(out, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_gloo_world2(tmp_path):
+    """Replicas: distinct shard per rank, bucketed SUM all-reduce, bit-identical parameters after every update
+    (reference properties claude_distributed/test_distributed.py:75-97,159-163)."""
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert float(r0["mean"]) == 0.5 and float(r1["mean"]) == 0.5
+    from video_vae_amd import optim
+    m = _toy()
+    opt = optim.Optimizer(m, 1e-2, bucket_bytes=256, bf16_shadow=False)
+    for step in range(3):
+        assert not torch.equal(r0[f"x{step}"], r1[f"x{step}"])                  # shards differ
+        assert torch.equal(r0[f"g{step}"], r1[f"g{step}"])                      # all-reduced gradients identical
+        assert torch.equal(r0[f"p{step}"], r1[f"p{step}"])                      # replicas stay bit-identical
+        want = torch.zeros_like(opt.g)
+        for x in (r0[f"x{step}"], r1[f"x{step}"]):                              # = sum of the per-rank gradients
+            opt.zero_grad()
+            m(x).square().mean().backward()
+            for b in range(len(opt.buckets)):
+                if not opt.landed[b]:
+                    opt._land(b)
+            want += opt.g
+        assert torch.allclose(r0[f"g{step}"], want, rtol=1e-5, atol=1e-7)
+        with torch.no_grad():
+            opt.p.add_(want, alpha=-0.05 / 2)

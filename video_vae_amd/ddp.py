@@ -3,14 +3,15 @@
 Replaces the implicit XLA SPMD gradient all-reduce of the reference's TPU path
 (claude_distributed/distributed_train.py:107-109,378-382,412: params P() replicated, batch P('data')).
 One process per GPU; ``torch.distributed`` (backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests) is
-only the transport -- bucketing and overlap are owned here:
+only the transport -- bucketing and overlap are owned here and in optim.Optimizer:
 
-* gradients alias one flat fp32 buffer (optim.Optimizer.g) laid out in reverse registration order, so the
-  buckets are contiguous slices and fill front-to-back as backward proceeds (UNet first, encoder last);
-* a post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its slice is
-  all-reduced (SUM, async) at once -- RCCL runs on its own stream while the backward conv stack continues;
-* ``finish()`` (called by Optimizer.update) flushes any incomplete bucket and waits; the 1/world mean and
-  the global-norm clip are folded into the fused Adam kernel, so no extra pass touches the gradients.
+* gradients land in one flat fp32 buffer (Optimizer.g) laid out in reverse registration order, so the buckets are
+  contiguous slices that fill front-to-back as backward proceeds (UNet first, encoder last);
+* the optimizer's per-parameter hook counts arrivals; when a bucket is complete it is copied into the flat buffer and
+  ``launch(b)`` all-reduces that slice (SUM, async) at once -- RCCL runs on its own stream while the backward conv
+  stack and the remaining transformer layers continue;
+* ``finish()`` (called by Optimizer.update) waits for the outstanding collectives; the 1/world mean and the
+  global-norm clip are folded into the fused Adam kernel, so no extra pass touches the gradients.
 
 Replicas stay bit-identical: every rank applies the same update to the same all-reduced buffer
 (the property the reference checks at claude_distributed/test_distributed.py:159-163).
@@ -20,58 +21,22 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, optimizer, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, optimizer, process_group=None):
         self.opt = optimizer
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
-        cap = max(1, bucket_bytes // 4)
-        # bucket = [start, end) element range of the flat buffer, aligned to parameter boundaries
-        self.buckets, self.param_bucket = [], []
-        start, filled = 0, 0
-        ends = [o + (p.numel() + 3) // 4 * 4 for o, p in zip(optimizer.offsets, optimizer.params)]
-        for i, e in enumerate(ends):
-            self.param_bucket.append(len(self.buckets))
-            filled = e - start
-            if filled >= cap or i == len(ends) - 1:
-                self.buckets.append((start, e))
-                start = e
-        self.expected = [0] * len(self.buckets)
-        for b in self.param_bucket:
-            self.expected[b] += 1
-        self.arrived = [0] * len(self.buckets)
-        self.launched = [False] * len(self.buckets)
         self.handles = []
-        self.enabled = True
-        for i, p in enumerate(optimizer.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
         optimizer.reducer = self
 
-    def _make_hook(self, i):
-        def hook(param):
-            if not self.enabled:
-                return
-            b = self.param_bucket[i]
-            self.arrived[b] += 1
-            if self.arrived[b] == self.expected[b] and not self.launched[b]:
-                self._launch(b)
-        return hook
-
-    def _launch(self, b):
-        s, e = self.buckets[b]
-        self.launched[b] = True
+    def launch(self, b):
+        s, e = self.opt.buckets[b]
         self.handles.append(dist.all_reduce(self.opt.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reset(self):
-        self.arrived = [0] * len(self.buckets)
-        self.launched = [False] * len(self.buckets)
         self.handles = []
 
     def finish(self):
-        """Flush buckets that never filled (unused parameters keep zero grads), then wait for all of them."""
-        for b in range(len(self.buckets)):
-            if not self.launched[b]:
-                self._launch(b)
         for h in self.handles:
             h.wait()
         self.handles = []
@@ -80,6 +45,7 @@ class GradReducer:
         """Replicate rank ``src``'s parameters (the reference's device_put(state, P()) / resume broadcast,
         distributed_train.py:339,378-380)."""
         dist.broadcast(self.opt.p, src=src, group=self.group)
+        self.opt.refresh_shadow()
 
 
 def all_reduce_mean_scalars(values, process_group=None):

@@ -15,6 +15,52 @@ from . import ops
 from .rngs import truncated_normal_
 
 
+_MM_F32_OUT = [None]     # does torch.mm(bf16, bf16, out_dtype=float32) work on this build? decided on first use
+
+
+def _mm_f32(a, b):
+    """a @ b for bf16 operands with an fp32 result (weight gradients go straight to fp32, no bf16 round trip)."""
+    if _MM_F32_OUT[0] is None:
+        try:
+            torch.mm(a[:1], b[:, :1], out_dtype=torch.float32)
+            _MM_F32_OUT[0] = True
+        except Exception:
+            _MM_F32_OUT[0] = False
+    if _MM_F32_OUT[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
+
+
+class _LinearBf16(torch.autograd.Function):
+    """y = x @ W + b in bf16 on hipBLASLt with fp32 master weights: the forward reads the optimizer's bf16 shadow copy
+    (``param.bf16``, refreshed by the fused Adam kernel) so no per-call weight cast runs, and the backward returns
+    fp32 weight / bias gradients directly."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        wb = getattr(kernel, "bf16", None)
+        if wb is None:
+            wb = kernel.detach().to(torch.bfloat16)
+        bb = getattr(bias, "bf16", None)
+        if bb is None:
+            bb = bias.detach().to(torch.bfloat16)
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, wb)
+        ctx.xshape = x.shape
+        return torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wb = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != torch.bfloat16:
+            dy2 = dy2.to(torch.bfloat16)
+        dx = torch.mm(dy2, wb.t()).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = _mm_f32(x2.t(), dy2) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 class Linear(nn.Module):
     """nnx.Linear: y = x @ kernel + bias, kernel (in, out), lecun_normal init (variance_scaling(scale))."""
 
@@ -27,6 +73,8 @@ class Linear(nn.Module):
 
     def forward(self, x):
         x = x.to(self.dtype)
+        if self.dtype == torch.bfloat16 and x.is_cuda and self.kernel.dtype == torch.float32:
+            return _LinearBf16.apply(x, self.kernel, self.bias)
         return torch.addmm(self.bias.to(self.dtype), x.reshape(-1, x.shape[-1]), self.kernel.to(self.dtype)).view(
             *x.shape[:-1], self.kernel.shape[1])
 

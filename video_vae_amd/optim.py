@@ -1,10 +1,15 @@
 """optax.chain(clip_by_global_norm(1.0), adam(warmup_cosine_decay_schedule)) on flat fp32 buffers.
 
 Reference: train/rl_nonadversarial.py:241-253.  All parameters live in ONE flat fp32 buffer (params are views into
-it), and so do gradients, Adam moments: the whole update is two HIP launches (squared-norm reduction, fused
-clip+Adam) regardless of the parameter count, and a data-parallel reducer (ddp.py) all-reduces slices of the
-flat gradient buffer in place.  The buffer is laid out in REVERSE registration order so that the gradients that
-become ready first in backward (the UNet at the decoder tail) sit at the front of the first bucket.
+it), and so do the gradients and Adam moments: the whole update is two HIP launches (squared-norm reduction, fused
+clip+Adam, which also refreshes a bf16 shadow copy of the weights for the next forward) regardless of the parameter
+count.  The buffer is laid out in REVERSE registration order and cut into buckets, so the gradients that become ready
+first in backward (the UNet at the decoder tail) fill the first bucket.
+
+Gradients land in the flat buffer bucket by bucket: a post-accumulate hook per parameter counts arrivals; when a
+bucket is complete its gradients are copied (and widened to fp32) into their slots with one fused multi-tensor copy
+and the autograd-owned tensors are released -- no zero-fill of the buffer, no per-parameter accumulate kernels --
+and, under data parallelism, the bucket's slice is all-reduced right away (ddp.GradReducer).
 """
 import ctypes
 import math
@@ -35,10 +40,11 @@ def reference_schedule(batch_size=2, learning_rate=2e-5, decay_steps=1_000_000):
 class Optimizer:
     """Counterpart of ``nnx.Optimizer(model, optax.chain(clip_by_global_norm(max_norm), adam(schedule)))``.
 
-    ``update()`` applies one step from the gradients accumulated in ``.grad`` (which alias ``self.g``).
+    ``zero_grad()`` then backward then ``update()``.  After ``update()`` the gradients of the step are in ``self.g``.
     """
 
-    def __init__(self, model, schedule, max_norm=1.0, b1=0.9, b2=0.999, eps=1e-8, bf16_shadow=False):
+    def __init__(self, model, schedule, max_norm=1.0, b1=0.9, b2=0.999, eps=1e-8, bf16_shadow=True,
+                 bucket_bytes=64 << 20):
         self.model = model
         self.schedule = schedule if callable(schedule) else (lambda count, lr=schedule: lr)
         self.max_norm, self.b1, self.b2, self.eps = max_norm, b1, b2, eps
@@ -61,25 +67,86 @@ class Optimizer:
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if bf16_shadow else None
+        self.gviews = []
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.p[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.p[o:o + n].view(p.shape)
-            p.grad = self.g[o:o + n].view(p.shape)
+            p.grad = None
+            self.gviews.append(self.g[o:o + n].view(p.shape))
+            if self.shadow is not None:
+                p.bf16 = self.shadow[o:o + n].view(p.shape)       # read by layers.Linear: no per-call weight casts
+        if self.shadow is not None:
+            self.shadow.copy_(self.p)
+        # ---- buckets: contiguous [start, end) element ranges aligned to parameter slots ----
+        cap = max(1, bucket_bytes // 4)
+        ends = [o + (p.numel() + 3) // 4 * 4 for o, p in zip(self.offsets, self.params)]
+        self.buckets, self.param_bucket, self.bucket_params = [], [], []
+        start, members = 0, []
+        for i, e in enumerate(ends):
+            self.param_bucket.append(len(self.buckets))
+            members.append(i)
+            if e - start >= cap or i == len(ends) - 1:
+                self.buckets.append((start, e))
+                self.bucket_params.append(members)
+                start, members = e, []
+        self.arrived = [0] * len(self.buckets)
+        self.landed = [False] * len(self.buckets)
         self.reducer = None            # set by ddp.GradReducer
-        self.last_grad_norm = None
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    # ---- gradient landing -------------------------------------------------------------------------------
+    def _make_hook(self, i):
+        def hook(param):
+            b = self.param_bucket[i]
+            self.arrived[b] += 1
+            if self.arrived[b] == len(self.bucket_params[b]) and not self.landed[b]:
+                self._land(b)
+        return hook
+
+    @torch.no_grad()
+    def _land(self, b):
+        """Move bucket b's gradients into the flat buffer (missing ones = zeros) and hand the slice to the reducer."""
+        dsts, srcs = [], []
+        for i in self.bucket_params[b]:
+            p = self.params[i]
+            if p.grad is None:
+                self.gviews[i].zero_()
+            elif p.grad.data_ptr() != self.gviews[i].data_ptr():
+                dsts.append(self.gviews[i])
+                srcs.append(p.grad)
+            p.grad = None
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+        self.landed[b] = True
+        if self.reducer is not None:
+            self.reducer.launch(b)
 
     def zero_grad(self):
-        self.g.zero_()
-        for p, o in zip(self.params, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
-                p.grad = self.g[o:o + p.numel()].view(p.shape)
+        for p in self.params:
+            p.grad = None
+        self.arrived = [0] * len(self.buckets)
+        self.landed = [False] * len(self.buckets)
         if self.reducer is not None:
             self.reducer.reset()
+
+    def set_grads(self, grads):
+        """Test helper: install explicit gradients {name: tensor} as if backward had produced them."""
+        self.zero_grad()
+        by_name = dict(zip(self.names, range(len(self.names))))
+        for n, gr in grads.items():
+            i = by_name[n]
+            self.params[i].grad = gr.to(self.g.device)
+        for b in range(len(self.buckets)):
+            self._land(b)
 
     @torch.no_grad()
     def update(self):
         """optimizer.update(grads): clip by global norm, then Adam with lr = schedule(count)."""
+        for b in range(len(self.buckets)):
+            if not self.landed[b]:
+                self._land(b)                    # parameters that received no gradient this step contribute zeros
         gscale = 1.0
         if self.reducer is not None:
             self.reducer.finish()
@@ -98,6 +165,11 @@ class Optimizer:
               "vvae_adam_clip_step")
         self.last_lr = lr
         return lr
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 shadow after parameters were written from outside (checkpoint load, broadcast)."""
+        if self.shadow is not None:
+            self.shadow.copy_(self.p)
 
     def grad_norm(self):
         """||g|| of the last update (host sync)."""
@@ -119,3 +191,4 @@ class Optimizer:
             k = p.numel()
             self.m[o:o + k].copy_(state[f"mu.{n}"].reshape(-1))
             self.v[o:o + k].copy_(state[f"nu.{n}"].reshape(-1))
+        self.refresh_shadow()
