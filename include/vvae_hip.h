@@ -100,15 +100,17 @@ int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, 
 
 /* lane-per-frame form of the same core for head_dim D in {8,16,32,64} (the production path): forward also writes the
  * row log-sum-exp `lse` (A*heads, T) fp32; backward consumes (out, lse) and writes per-workgroup partials of the
- * q_norm / k_norm scale gradients: dscale_part (vvae_temporal_attn_fast_blocks(...), 2*D) fp32, summed by the caller. */
+ * q_norm / k_norm scale gradients: dscale_part (vvae_temporal_attn_fast_blocks(...), 2*D) fp32, summed by the caller.
+ * inner = 1: sequences contiguous (A,T,C).  inner = hw: tensors are (b,t,hw,C), sequence a = b*hw+i strides over frames
+ * (no transpose copies around the temporal half of FactoredAttention). */
 int vvae_temporal_attn_fast_supported(int T, int D, int ld, int ldo, int dtype);
 int vvae_temporal_attn_fast_blocks(int A, int T, int heads);
 int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, int ldo, float* lse, const float* q_scale,
                                 const float* k_scale, const float* cos_table, const float* sin_table, const uint8_t* mask,
-                                int mask_div, int A, int T, int heads, int D, float eps, int dtype, void* stream);
+                                int mask_div, int inner, int A, int T, int heads, int D, float eps, int dtype, void* stream);
 int vvae_temporal_attn_bwd_fast(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse,
                                 void* dqkv, int lddq, const float* q_scale, const float* k_scale, const float* cos_table,
-                                const float* sin_table, const uint8_t* mask, int mask_div, float* dscale_part,
+                                const float* sin_table, const uint8_t* mask, int mask_div, int inner, float* dscale_part,
                                 int A, int T, int heads, int D, float eps, int dtype, void* stream);
 
 /* ---- LayerNorm(eps, fast variance, fp32 stats): nnx.LayerNorm at train/layers.py:17,152,155-156,178.

@@ -370,3 +370,28 @@ def test_layer_norm_strided_head_view(dev):
     assert not qg.is_contiguous()
     got = ops.layer_norm(qg, sc.to(dev), None)
     assert_close(got, want, what="strided LN")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_temporal_attention_strided_layout(dev, dtype):
+    """inner = hw: (b, t, hw, C) in, same out, equal to the transposed contiguous form, forward and backward."""
+    from einops import rearrange
+    ops = _ops()
+    b, t, hw, heads, d = 2, 16, 6, 4, 64
+    qkv = rnd((b, t, hw, 3 * heads * d), 70).to(dev, dtype)
+    qs = (1 + 0.2 * rnd((d,), 71)).to(dev); ks = (1 + 0.2 * rnd((d,), 72)).to(dev)
+    go = rnd((b, t, hw, heads * d), 73).to(dev, dtype)
+    cos, sin = OL.rope_tables(d, 64)
+    cos, sin = cos.to(dev), sin.to(dev)
+    m8 = (torch.arange(t)[None, :] < torch.tensor([t, 9])[:, None]).to(torch.uint8).to(dev)       # (b, t)
+    x1 = qkv.clone().requires_grad_(True); q1 = qs.clone().requires_grad_(True); k1 = ks.clone().requires_grad_(True)
+    o1 = ops.temporal_attention_core(x1, q1, k1, cos, sin, m8, hw, heads, 1e-6, inner=hw)
+    o1.backward(go)
+    x2 = qkv.clone().requires_grad_(True); q2 = qs.clone().requires_grad_(True); k2 = ks.clone().requires_grad_(True)
+    o2 = ops.temporal_attention_core(rearrange(x2, "b t hw c -> (b hw) t c").contiguous(), q2, k2, cos, sin, m8, hw, heads)
+    o2 = rearrange(o2, "(b hw) t c -> b t hw c", b=b)
+    o2.backward(go)
+    assert torch.equal(o1, o2)
+    assert torch.equal(x1.grad, x2.grad)
+    assert_close_scaled(q1.grad, q2.grad, rel=1e-5)
+    assert_close_scaled(k1.grad, k2.grad, rel=1e-5)

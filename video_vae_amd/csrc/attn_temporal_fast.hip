@@ -13,7 +13,14 @@
 
 namespace {
 
-struct FAttnDims { int A, T, heads, mask_div; float eps; long items; };
+struct FAttnDims { int A, T, heads, mask_div; float eps; long items; int inner; };
+
+// Token (row of the (tokens, channels) matrix) of frame `row` of sequence `a`.  inner = 1: sequences are contiguous (A, T, C);
+// inner = hw: the tensor is (b, t, hw, C) and sequence a = b*hw + i walks frames with stride hw -- the FactoredAttention
+// layout, so the temporal half needs no "b t hw c -> (b hw) t c" transpose copies (reference train/layers.py:211,215).
+__device__ __forceinline__ long token_of(const FAttnDims& d, int a, int row) {
+    return (long)(a / d.inner) * d.T * d.inner + (long)row * d.inner + (a % d.inner);
+}
 
 template <typename T_> struct Vw;                                // elements per 16-byte vector
 template <> struct Vw<float> { static constexpr int n = 4; };
@@ -163,12 +170,13 @@ __global__ __launch_bounds__(64) void tattn_fwd_fast(const T_* __restrict__ qkv,
     const long gic = valid ? gi : 0;
     const int a = (int)(gic / d.heads), h = (int)(gic % d.heads);
     const int HD = d.heads * D;
+    const long tok = token_of(d, a, row);
     const int istride = item_stride_bytes<T_, D>(T);
     T_* Ks = reinterpret_cast<T_*>(smem + (valid ? item : 0) * istride);
     T_* Vs = reinterpret_cast<T_*>(smem + ipw * istride + (valid ? item : 0) * istride);
 
     float q[D], kv[D];
-    const T_* g = qkv + ((long)a * T + row) * ld + h * D;
+    const T_* g = qkv + tok * ld + h * D;
     float dummy[1], rs;
     if (valid) {
         load_row<T_, D>(g + HD, kv);
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(64) void tattn_fwd_fast(const T_* __restrict__ qkv,
         const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
         for (int i = 0; i < D; ++i) o[i] *= inv;
-        store_row<T_, D>(out + ((long)a * T + row) * ldo + h * D, o);
+        store_row<T_, D>(out + tok * ldo + h * D, o);
         lse[gi * T + row] = l > 0.f ? m + __logf(l) : 0.f;
     }
 }
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv,
     const long gic = valid ? gi : 0;
     const int a = (int)(gic / d.heads), h = (int)(gic % d.heads);
     const int HD = d.heads * D;
+    const long tok = token_of(d, a, row);
     const int istride = item_stride_bytes<T_, D>(T);
     const int it = valid ? item : 0;
     T_* Ks = reinterpret_cast<T_*>(smem + it * istride);
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv,
     float* Ps = reinterpret_cast<float*>(smem + 4 * ipw * istride) + it * T * (T + 1);
     float* Ss = reinterpret_cast<float*>(smem + 4 * ipw * istride) + (ipw + it) * T * (T + 1);
 
-    const T_* g = qkv + ((long)a * T + row) * ld + h * D;
+    const T_* g = qkv + tok * ld + h * D;
     const float* cosr = cosT + row * D;
     const float* sinr = sinT + row * D;
     float q[D], go[D], t0[D];
@@ -257,9 +266,9 @@ __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv,
         ln_row<T_, D, false>(q, q_scale, d.eps, dummy, rs);
         rope_row<T_, D>(q, cosr, sinr);
         store_row<T_, D>(Qs + row * D, q);
-        load_row<T_, D>(dout + ((long)a * T + row) * lddo + h * D, go);
+        load_row<T_, D>(dout + tok * lddo + h * D, go);
         store_row<T_, D>(Gs + row * D, go);
-        load_row<T_, D>(out + ((long)a * T + row) * ldo + h * D, t0);
+        load_row<T_, D>(out + tok * ldo + h * D, t0);
 #pragma unroll
         for (int i = 0; i < D; ++i) delta += go[i] * t0[i];
     } else {
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv,
         load_row<T_, D>(g, t0);
         rs = xhat_row<D>(t0, d.eps);
         rope_ln_bwd_row<T_, D>(dq, t0, rs, q_scale, cosr, sinr);
-        store_row<T_, D>(dqkv + ((long)a * T + row) * lddq + h * D, dq);
+        store_row<T_, D>(dqkv + tok * lddq + h * D, dq);
     } else {
 #pragma unroll
         for (int i = 0; i < D; ++i) t0[i] = 0.f;
@@ -320,11 +329,11 @@ __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv,
             axpy_lds<T_, D>(dk, dsij, Qs + i * D);
             axpy_lds<T_, D>(dv, pij, Gs + i * D);
         }
-        store_row<T_, D>(dqkv + ((long)a * T + row) * lddq + 2 * HD + h * D, dv);
+        store_row<T_, D>(dqkv + tok * lddq + 2 * HD + h * D, dv);
         load_row<T_, D>(g + HD, t0);
         rs = xhat_row<D>(t0, d.eps);
         rope_ln_bwd_row<T_, D>(dk, t0, rs, k_scale, cosr, sinr);
-        store_row<T_, D>(dqkv + ((long)a * T + row) * lddq + HD + h * D, dk);
+        store_row<T_, D>(dqkv + tok * lddq + HD + h * D, dk);
     } else {
 #pragma unroll
         for (int i = 0; i < D; ++i) t0[i] = 0.f;
@@ -400,12 +409,13 @@ extern "C" int vvae_temporal_attn_fast_blocks(int A, int T, int heads) { return 
 // lse: fp32 (A*heads, T) written.  Other arguments as vvae_temporal_attn_fwd.
 extern "C" int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, int ldo, float* lse, const float* q_scale,
                                            const float* k_scale, const float* cos_table, const float* sin_table, const uint8_t* mask,
-                                           int mask_div, int A, int T, int heads, int D, float eps, int dtype, void* stream)
+                                           int mask_div, int inner, int A, int T, int heads, int D, float eps, int dtype, void* stream)
 {
+    if (inner <= 0 || A % inner) return VVAE_ERR_BAD_ARG;
     if (!qkv || !out || !lse || !q_scale || !k_scale || !cos_table || !sin_table || A <= 0 || heads <= 0 || mask_div <= 0 ||
         ld < 3 * heads * D || ldo < heads * D || !fast_ok(T, D, ld, ldo, dtype) || ((uintptr_t)qkv % 16) || ((uintptr_t)out % 16))
         return VVAE_ERR_BAD_ARG;
-    FAttnDims d{A, T, heads, mask_div, eps, (long)A * heads};
+    FAttnDims d{A, T, heads, mask_div, eps, (long)A * heads, inner};
     hipStream_t s = (hipStream_t)stream;
     FATTN_DISPATCH(launch_fwd, qkv, ld, out, ldo, lse, q_scale, k_scale, cos_table, sin_table, mask, d, s);
 }
@@ -413,14 +423,15 @@ extern "C" int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, i
 // out, lse: forward results.  dscale_part: fp32 (vvae_temporal_attn_fast_blocks(...), 2*D) written; the caller sums rows.
 extern "C" int vvae_temporal_attn_bwd_fast(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse,
                                            void* dqkv, int lddq, const float* q_scale, const float* k_scale, const float* cos_table,
-                                           const float* sin_table, const uint8_t* mask, int mask_div, float* dscale_part,
+                                           const float* sin_table, const uint8_t* mask, int mask_div, int inner, float* dscale_part,
                                            int A, int T, int heads, int D, float eps, int dtype, void* stream)
 {
+    if (inner <= 0 || A % inner) return VVAE_ERR_BAD_ARG;
     if (!qkv || !out || !dout || !lse || !dqkv || !dscale_part || !q_scale || !k_scale || !cos_table || !sin_table || A <= 0 ||
         heads <= 0 || mask_div <= 0 || ld < 3 * heads * D || lddq < 3 * heads * D || ldo < heads * D || lddo < heads * D ||
         !fast_ok(T, D, ld, ldo, dtype) || !fast_ok(T, D, lddq, lddo, dtype) || ((uintptr_t)qkv % 16) || ((uintptr_t)out % 16) ||
         ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16)) return VVAE_ERR_BAD_ARG;
-    FAttnDims d{A, T, heads, mask_div, eps, (long)A * heads};
+    FAttnDims d{A, T, heads, mask_div, eps, (long)A * heads, inner};
     hipStream_t s = (hipStream_t)stream;
     FATTN_DISPATCH(launch_bwd, qkv, ld, out, ldo, dout, lddo, lse, dqkv, lddq, q_scale, k_scale, cos_table, sin_table, mask, dscale_part, d, s);
 }

@@ -183,6 +183,20 @@ class Attention(nn.Module):
         self.q_norm = LayerNorm(head_dim, dtype, param_dtype, use_bias=False)
         self.k_norm = LayerNorm(head_dim, dtype, param_dtype, use_bias=False)
 
+    def forward_temporal_strided(self, x, mask=None):
+        """Temporal attention on x laid out (b, t, hw, c) -- attention over t for every (b, hw) without the
+        "b t hw c -> (b hw) t c" transposes: LayerNorm and the projections are per-token, the fused core strides."""
+        b, t, hw, _ = x.shape
+        x = self.input_norm(x)
+        qkv = self.qkv_projection(x)
+        m8, div = None, 1
+        if mask is not None:
+            m8 = mask.reshape(-1, t).to(torch.uint8).contiguous()
+            div = (b * hw) // m8.shape[0]
+        o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
+                                        m8, div, self.num_heads, 1e-6, inner=hw)
+        return self.out_projection(o)
+
     def forward(self, x, mask=None):
         x = self.input_norm(x)
         qkv = self.qkv_projection(x)
@@ -240,6 +254,17 @@ class FactoredAttention(nn.Module):
 
     def forward(self, x, temporal_mask):
         b, t, hw, c = x.shape
+        ta = self.TemporalAttention
+        hd = ta.q_norm.scale.shape[0]
+        if x.is_cuda and t <= FUSED_CORE_MAX_SEQ and ops.temporal_attention_fast_supported(t, hd, 3 * hd * ta.num_heads, ta.qkv_projection.dtype):
+            # every op of the temporal half except the attention core is per-token, and the core strides over frames:
+            # stay in (b, t, hw, c) and skip both transpose copies (and their backward)
+            x = x + ta.forward_temporal_strided(x, mask=temporal_mask)
+            x = x + self.TemporalMLP(x)
+            sx = x.reshape(b * t, hw, c)
+            sx = sx + self.SpatialAttention(sx)
+            sx = sx + self.SpatialMLP(sx)
+            return sx.view(b, t, hw, c)
         tx = rearrange(x, "b t hw c -> (b hw) t c")
         tx = tx + self.TemporalAttention(tx, mask=temporal_mask)
         tx = tx + self.TemporalMLP(tx)

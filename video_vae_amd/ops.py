@@ -371,47 +371,55 @@ ATTN_FORCE_GENERIC = [False]      # test hook: use the generic (any head_dim) ke
 
 class _TemporalAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, q_scale, k_scale, cos, sin, mask, mask_div, heads, eps):
+    def forward(ctx, qkv, q_scale, k_scale, cos, sin, mask, mask_div, heads, eps, inner=1):
         qkv, ld = rows(qkv)
-        a, t, c3 = qkv.shape
-        d = c3 // (3 * heads)
         dt = _dt(qkv)
+        c3 = qkv.shape[-1]
+        d = c3 // (3 * heads)
+        if inner > 1:                      # (b, t, hw, C): sequences stride over frames, no transpose copies
+            bsz, t, hw = qkv.shape[:3]
+            assert hw == inner
+            a = bsz * hw
+        else:
+            a, t = qkv.shape[:2]
         qs, ks = _f32(q_scale), _f32(k_scale)
-        out = torch.empty((a, t, heads * d), dtype=qkv.dtype, device=qkv.device)
+        out = torch.empty(qkv.shape[:-1] + (heads * d,), dtype=qkv.dtype, device=qkv.device)
         fast = (not ATTN_FORCE_GENERIC[0]) and lib().vvae_temporal_attn_fast_supported(t, d, ld, heads * d, dt) == 1
+        if inner > 1 and not fast:
+            raise VvaeError("strided temporal attention needs the lane-per-frame kernels (head_dim 8/16/32/64)")
         lse = None
         nbytes = a * t * heads * d * 4 * qkv.element_size()
         if fast:
             lse = torch.empty((a * heads, t), dtype=torch.float32, device=qkv.device)
             check(_launch(f"temporal_attn_fwd T{t} D{d}", nbytes, 4 * a * heads * t * t * d, "tattn_fwd_fast",
                           lambda: lib().vvae_temporal_attn_fwd_fast(_p(qkv), ld, _p(out), heads * d, _p(lse), _p(qs), _p(ks), _p(cos),
-                                                                    _p(sin), _p(mask), mask_div, a, t, heads, d, eps, dt, _stream())),
+                                                                    _p(sin), _p(mask), mask_div, inner, a, t, heads, d, eps, dt, _stream())),
                   "vvae_temporal_attn_fwd_fast")
         else:
             check(lib().vvae_temporal_attn_fwd(_p(qkv), ld, _p(out), heads * d, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div,
                                                a, t, heads, d, eps, dt, _stream()), "vvae_temporal_attn_fwd")
         ctx.save_for_backward(qkv, qs, ks, cos, sin, mask, out, lse)
-        ctx.args = (mask_div, heads, eps, q_scale.dtype, fast)
+        ctx.args = (mask_div, heads, eps, q_scale.dtype, fast, inner, a, t)
         return out
 
     @staticmethod
     def backward(ctx, do):
         qkv, qs, ks, cos, sin, mask, out, lse = ctx.saved_tensors
-        mask_div, heads, eps, pdtype, fast = ctx.args
+        mask_div, heads, eps, pdtype, fast, inner, a, t = ctx.args
         qkv, ld = rows(qkv)
         do, lddo = rows(do.to(qkv.dtype))
-        a, t, c3 = qkv.shape
+        c3 = qkv.shape[-1]
         d = c3 // (3 * heads)
         dt = _dt(qkv)
-        dqkv = torch.empty((a, t, c3), dtype=qkv.dtype, device=qkv.device)
+        dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
         if fast:
             nblk = lib().vvae_temporal_attn_fast_blocks(a, t, heads)
             part = torch.empty((nblk, 2 * d), dtype=torch.float32, device=qkv.device)
             nbytes = a * t * heads * d * 8 * qkv.element_size()
             check(_launch(f"temporal_attn_bwd T{t} D{d}", nbytes, 10 * a * heads * t * t * d, "tattn_bwd_fast",
                           lambda: lib().vvae_temporal_attn_bwd_fast(_p(qkv), ld, _p(out), heads * d, _p(do), lddo, _p(lse), _p(dqkv), c3,
-                                                                    _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div, _p(part),
-                                                                    a, t, heads, d, eps, dt, _stream())),
+                                                                    _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div, inner,
+                                                                    _p(part), a, t, heads, d, eps, dt, _stream())),
                   "vvae_temporal_attn_bwd_fast")
             tot = part.sum(0)
             dqs, dks = tot[:d], tot[d:]
@@ -421,15 +429,21 @@ class _TemporalAttn(torch.autograd.Function):
             check(lib().vvae_temporal_attn_bwd(_p(qkv), ld, _p(do), lddo, _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask),
                                                mask_div, _p(dqs), _p(dks), a, t, heads, d, eps, dt, _stream()),
                   "vvae_temporal_attn_bwd")
-        return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None, None, None
+        return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None, None, None, None
 
 
-def temporal_attention_core(qkv, q_scale, k_scale, cos, sin, mask_u8, mask_div, heads, eps=1e-6):
-    """q_norm/k_norm -> RoPE -> masked softmax(QK^T/sqrt(D)) V on (A, T, 3*heads*D) (reference train/layers.py:159-170).
+def temporal_attention_core(qkv, q_scale, k_scale, cos, sin, mask_u8, mask_div, heads, eps=1e-6, inner=1):
+    """q_norm/k_norm -> RoPE -> masked softmax(QK^T/sqrt(D)) V (reference train/layers.py:159-170).
 
+    inner = 1: qkv is (A, T, 3*heads*D), one sequence per leading index.  inner = hw: qkv is (b, T, hw, 3*heads*D) and
+    sequence a = b*hw + i strides over frames (the FactoredAttention layout, no transposes).  Output has qkv's leading shape.
     mask_u8: uint8 (ceil(A/mask_div), T), 1 = attend, or None.  cos/sin: fp32 (>=T, D) RoPE tables.
     """
-    return _TemporalAttn.apply(qkv, q_scale, k_scale, cos, sin, mask_u8, mask_div, heads, eps)
+    return _TemporalAttn.apply(qkv, q_scale, k_scale, cos, sin, mask_u8, mask_div, heads, eps, inner)
+
+
+def temporal_attention_fast_supported(t, d, c3, dtype):
+    return dtype in DT and lib().vvae_temporal_attn_fast_supported(t, d, c3, c3 // 3, DT[dtype]) == 1
 
 
 # --------------------------------------------------------------------------------------------- reparameterise + KL
