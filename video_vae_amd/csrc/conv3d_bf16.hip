@@ -73,6 +73,45 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint4* __restri
     }
 }
 
+// Stage a KT x HR x WR halo of 16-byte channel parts into LDS, zero-filled outside the volume.  Every thread owns one
+// (column, part) of the tile and walks the (plane, row) pairs with a fully unrolled, predicated loop: the loop-invariant
+// column address, bounds and LDS offset are computed once, each step is a few integer adds + one 16-byte load, and the
+// compiler can issue all loads before the first LDS store.  (The div/mod-per-element form of this loop cost 2-3x the
+// MFMA time of the small-channel layers.)   src already points at the first channel of the chunk.
+template <int NTHREADS, int KT, int HR, int WR, int PARTS, int PITCH>
+__device__ __forceinline__ void stage_halo(const bf16_t* __restrict__ src, int ld, unsigned char* __restrict__ lds, int n, int t0, int h0,
+                                           int w0, int T, int H, int W, int tid)
+{
+    constexpr int ROW_ITEMS = WR * PARTS;
+    static_assert(ROW_ITEMS <= NTHREADS, "a halo row must fit one pass");
+    constexpr int RPP = NTHREADS / ROW_ITEMS;             // (plane, row) pairs per pass
+    constexpr int ROWS = KT * HR;
+    constexpr int ITERS = (ROWS + RPP - 1) / RPP;
+    const int rip = tid / ROW_ITEMS, item = tid - rip * ROW_ITEMS;
+    const int wc = item / PARTS, part = item - wc * PARTS;
+    const int wi = w0 + wc;
+    const bool col_ok = rip < RPP && (unsigned)wi < (unsigned)W;
+    int dt = rip / HR, hr = rip - dt * HR;
+    const bf16_t* col = src + (long)wi * ld + part * 8;
+    unsigned char* l = lds + (rip * WR + wc) * PITCH + part * 16;
+    const long plane = (long)W * ld;
+    uint4 v[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int ti = t0 + dt, hi = h0 + hr;
+        const bool ok = col_ok && (rip + it * RPP) < ROWS && (unsigned)ti < (unsigned)T && (unsigned)hi < (unsigned)H;
+        v[it] = make_uint4(0, 0, 0, 0);
+        if (ok) v[it] = *reinterpret_cast<const uint4*>(col + (((long)n * T + ti) * H + hi) * plane);
+        hr += RPP;
+#pragma unroll
+        for (int k = 0; k < (RPP + HR - 1) / HR; ++k)
+            if (hr >= HR) { hr -= HR; ++dt; }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+        if (rip < RPP && (rip + it * RPP) < ROWS) *reinterpret_cast<uint4*>(l + it * RPP * WR * PITCH) = v[it];
+}
+
 template <class C>
 __global__ __launch_bounds__(256) void conv3d_bf16_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wp,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, BfDims d)
@@ -105,19 +144,8 @@ __global__ __launch_bounds__(256) void conv3d_bf16_kernel(const bf16_t* __restri
     const int chunks = d.CK / CKB;
     for (int chunk = 0; chunk < chunks; ++chunk) {
         if (chunk) __syncthreads();
-        // ---- stage the halo tile of this channel chunk: 16-byte parts, zero fill outside the volume ----
-        constexpr int PARTS = CKB / 8;
-        for (int i = tid; i < C::NVOX * PARTS; i += 256) {
-            const int part = i % PARTS, vox = i / PARTS;
-            const int wc = vox % WR; const int qq = vox / WR; const int hr = qq % HR, dt = qq / HR;
-            const int ti = tt + dt - KT / 2, hi = h0 + hr - KH / 2, wi = w0 + wc - KW / 2;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if ((unsigned)ti < (unsigned)d.T && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W) {
-                const long v = (((long)n * d.T + ti) * d.H + hi) * d.W + wi;
-                val = *reinterpret_cast<const uint4*>(x + v * ldx + chunk * CKB + part * 8);
-            }
-            *reinterpret_cast<uint4*>(smem + vox * PITCH + part * 16) = val;
-        }
+        // ---- stage the halo tile of this channel chunk (zero fill outside the volume) ----
+        stage_halo<256, KT, HR, WR, CKB / 8, PITCH>(x + chunk * CKB, ldx, smem, n, tt - KT / 2, h0 - KH / 2, w0 - KW / 2, d.T, d.H, d.W, tid);
         __syncthreads();
 
         const uint4* wchunk = wp + (long)chunk * KH * KSTEPS * co_tiles * 64;
@@ -383,25 +411,8 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
         const int h0 = th * TH, w0 = tw * TW;
         if (tile != tile_beg) __syncthreads();
         // ---- stage X halo (channels ci0..ci0+CIB) and dY tile (channels co0..co0+COB), zero filled ----
-        constexpr int XP = CIB / 8, YP = COB / 8;
-        for (int i = tid; i < 3 * HR * WR * XP; i += 192) {
-            const int part = i % XP, vox = i / XP;
-            const int wc = vox % WR; const int r2 = vox / WR; const int hr = r2 % HR, dt = r2 / HR;
-            const int ti = tt + dt - 1, hi = h0 + hr - KH / 2, wi = w0 + wc - KW / 2;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if ((unsigned)ti < (unsigned)d.T && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W)
-                val = *reinterpret_cast<const uint4*>(x + ((((long)n * d.T + ti) * d.H + hi) * d.W + wi) * ldx + ci0 + part * 8);
-            *reinterpret_cast<uint4*>(xs + vox * PX + part * 16) = val;
-        }
-        for (int i = tid; i < TH * TW * YP; i += 192) {
-            const int part = i % YP, vox = i / YP;
-            const int wc = vox % TW, hr = vox / TW;
-            const int hi = h0 + hr, wi = w0 + wc;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (hi < d.H && wi < d.W)
-                val = *reinterpret_cast<const uint4*>(dy + ((((long)n * d.T + tt) * d.H + hi) * d.W + wi) * lddy + co0 + part * 8);
-            *reinterpret_cast<uint4*>(ys + vox * PY + part * 16) = val;
-        }
+        stage_halo<192, 3, HR, WR, CIB / 8, PX>(x + ci0, ldx, xs, n, tt - 1, h0 - KH / 2, w0 - KW / 2, d.T, d.H, d.W, tid);
+        stage_halo<192, 1, TH, TW, COB / 8, PY>(dy + co0, lddy, ys, n, tt, h0, w0, d.T, d.H, d.W, tid);
         __syncthreads();
 
         bf16x8 bfr[KH][COT];                                  // rolling window of dY fragments: row h lives in slot h % KH
