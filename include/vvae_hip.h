@@ -135,6 +135,13 @@ int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* m
 int vvae_masked_mse_mae_bwd(const void* video, const void* recon, const float* mask, const float* gmse, const float* gmae,
                             void* drecon, int B, int T, long P, int video_div, int dtype, void* stream);
 
+/* ---- weight-gradient GEMM of the dense layers (nnx.Linear under autodiff, train/layers.py:15,142-151,179-189):
+ *      C[M][N] fp32 = sum_k A[k][m] * B[k][n], db[n] = sum_k B[k][n]; A (K,M), B (K,N) bf16 token-major. ---- */
+int vvae_gemm_tn_supported(int M, int N, int K, int lda, int ldb);
+size_t vvae_gemm_tn_ws_bytes(int M, int N, int K);
+int vvae_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, float* db, int M, int N, int K,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam) at train/rl_nonadversarial.py:248-251. ---- */
 int vvae_sqnorm_accum(const float* g, long n, double* out, void* stream);
 int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_sq,

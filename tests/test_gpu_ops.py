@@ -395,3 +395,18 @@ def test_temporal_attention_strided_layout(dev, dtype):
     assert torch.equal(x1.grad, x2.grad)
     assert_close_scaled(q1.grad, q2.grad, rel=1e-5)
     assert_close_scaled(k1.grad, k2.grad, rel=1e-5)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 1000), (768, 1536, 4096), (512, 128, 33)])
+def test_gemm_tn_weight_gradient(dev, m, n, k):
+    """dW = X^T dY and db = colsum(dY) from the split-K HIP kernel vs fp32 torch on the same bf16 operands."""
+    ops = _ops()
+    a = rnd((k, m), 80).to(dev, torch.bfloat16)
+    b = rnd((k, n), 81).to(dev, torch.bfloat16)
+    assert ops.gemm_tn_supported(a, b)
+    c, db = ops.gemm_tn(a, b)
+    want = a.float().t() @ b.float()
+    assert_close_scaled(c, want, rel=1e-4, what="dW")
+    assert_close_scaled(db, b.float().sum(0), rel=1e-4, what="db")
+    c2, _ = ops.gemm_tn(a, b)
+    assert torch.equal(c, c2), "slab reduction must be bitwise reproducible"

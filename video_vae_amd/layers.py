@@ -56,8 +56,13 @@ class _LinearBf16(torch.autograd.Function):
         if dy2.dtype != torch.bfloat16:
             dy2 = dy2.to(torch.bfloat16)
         dx = torch.mm(dy2, wb.t()).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = _mm_f32(x2.t(), dy2) if ctx.needs_input_grad[1] else None
-        db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] and ops.gemm_tn_supported(x2, dy2):
+            # split-K weight-gradient GEMM on the HIP kernel (bias gradient rides along): K = tokens >> M, N
+            dw, db = ops.gemm_tn(x2, dy2, ctx.needs_input_grad[2])
+        else:
+            dw = _mm_f32(x2.t(), dy2) if ctx.needs_input_grad[1] else None
+            db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 

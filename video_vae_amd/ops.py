@@ -598,3 +598,24 @@ def layer_norm_supported(x):
 def layer_norm(x, scale, bias=None, eps=1e-6):
     """nnx.LayerNorm over the last axis, fp32 statistics (reference train/layers.py:17,152,155-156,178)."""
     return _LayerNorm.apply(x, scale, bias, eps)
+
+
+# --------------------------------------------------------------------------------------------- dense weight-gradient GEMM
+def gemm_tn_supported(a, b):
+    return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+            and a.stride(1) == 1 and b.stride(1) == 1
+            and lib().vvae_gemm_tn_supported(a.shape[1], b.shape[1], a.shape[0], a.stride(0), b.stride(0)) == 1)
+
+
+def gemm_tn(a, b, want_colsum=True):
+    """(a^T @ b, b.sum(0)) in fp32 for bf16 token-major a (K, M), b (K, N): dW and db of a Linear layer in one pass."""
+    k, m = a.shape
+    n = b.shape[1]
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    db = torch.empty((n,), dtype=torch.float32, device=a.device) if want_colsum else None
+    wsb = lib().vvae_gemm_tn_ws_bytes(m, n, k)
+    ws, wsb = _ws(wsb, a.device)
+    check(_launch(f"gemm_tn {m}x{n} K{k}", (k * (m + n)) * 2 + m * n * 4, 2 * m * n * k, "gemm_tn_bf16_kernel",
+                  lambda: lib().vvae_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(db), m, n, k, _p(ws), wsb, _stream())),
+          "vvae_gemm_tn_bf16")
+    return c, db
