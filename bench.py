@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--flavour", default="model", choices=["model", "rl"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the bounded CPU sample")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU sample")
     return ap.parse_args()
 
 
@@ -70,7 +70,7 @@ def build_model(args, dev, dtype):
 def cpu_baseline(args):
     """The oracle's UNet + loss fwd+bwd on the host cores, fp32, on a bounded sample (1 clip x --cpu-frames frames)."""
     from oracle import unet as OU
-    threads = os.cpu_count() or 1
+    threads = min(16, os.cpu_count() or 1)          # the box's CPU share for one GPU is 16 cores
     torch.set_num_threads(threads)
     t, s = args.cpu_frames, args.size
     p = OU.init_unet(12, 16, 3, 3, seed=5, zero_final=False)

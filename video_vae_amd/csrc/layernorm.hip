@@ -146,11 +146,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
     }
 }
 
-inline int ln_blocks(long rows, int lpr)
+inline int ln_blocks(long rows, int lpr, int cap = 1024)
 {
+    // backward: <= 1024 workgroups (each emits one partial row of dgamma/dbeta).  forward has no epilogue, so it takes one
+    // row-slot per wave (cap 16384): every row's loads are in flight at once instead of 4 rows queued behind each other.
     const long per = 4L * (64 / lpr);
     long b = (rows + per - 1) / per;
-    if (b > 1024) b = 1024;
+    if (b > cap) b = cap;
     return (int)(b < 1 ? 1 : b);
 }
 
@@ -215,11 +217,11 @@ extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, co
     int lpr, vpl;
     if (dtype == VVAE_DT_F32) {
         if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
-        dim3 grid(ln_blocks(rows, lpr));
+        dim3 grid(ln_blocks(rows, lpr, 16384));
         LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, d);
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
-        dim3 grid(ln_blocks(rows, lpr));
+        dim3 grid(ln_blocks(rows, lpr, 16384));
         LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
