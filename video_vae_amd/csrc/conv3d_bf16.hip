@@ -363,12 +363,46 @@ struct WgCfg {
     static constexpr int CIT = CIB / 16, COT = COB / 16;
     static constexpr int HR = TH + KH - 1, WR = TW + KW - 1;
     static constexpr int PX = CIB == 16 ? 32 : 96, PY = COB == 16 ? 32 : 96;
-    static constexpr int XBYTES = KT * HR * WR * PX, YBYTES = TH * TW * PY;
-    static constexpr int LDS_BYTES = XBYTES + YBYTES;
+    static constexpr int PLANE = HR * WR * PX, YBYTES = TH * TW * PY;      // one X halo plane, one dY tile
+    static constexpr int LDS_BYTES = 4 * PLANE + 2 * YBYTES;               // ring of 4 planes + double-buffered dY
     static constexpr int SLAB_FLOATS = KT * KH * KW * CIB * COB + COB;     // + dbias partial
 };
 
-struct WgDims { int N, T, H, W, CI, CO, tiles_h, tiles_w, ntiles, tiles_per_block; };
+struct WgDims { int N, T, H, W, CI, CO, tiles_h, tiles_w, ncols, cols_per_block; };
+
+// One HR x WR halo plane of 16-byte channel parts held in registers between its global fetch and its LDS store, so the
+// fetch of step t+1 can be in flight while step t computes (register-staged software pipeline).
+template <int NTHREADS, int HR, int WR, int PARTS, int PITCH>
+struct PlaneStager {
+    static constexpr int ROW_ITEMS = WR * PARTS;
+    static_assert(ROW_ITEMS <= NTHREADS, "a halo row must fit one pass");
+    static constexpr int RPP = NTHREADS / ROW_ITEMS;
+    static constexpr int ITERS = (HR + RPP - 1) / RPP;
+    uint4 v[ITERS];
+
+    __device__ __forceinline__ void fetch(const bf16_t* __restrict__ src, int ld, int n, int t, int h0, int w0, int T, int H, int W, int tid) {
+        const int rip = tid / ROW_ITEMS, item = tid - rip * ROW_ITEMS;
+        const int wc = item / PARTS, part = item - wc * PARTS;
+        const int wi = w0 + wc;
+        const bool ok0 = rip < RPP && (unsigned)wi < (unsigned)W && (unsigned)t < (unsigned)T;
+        const bf16_t* col = src + (((long)n * T + t) * H * (long)W + wi) * ld + part * 8;
+        const long rowstride = (long)W * ld;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int hr = rip + it * RPP, hi = h0 + hr;
+            v[it] = make_uint4(0, 0, 0, 0);
+            if (ok0 && hr < HR && (unsigned)hi < (unsigned)H) v[it] = *reinterpret_cast<const uint4*>(col + hi * rowstride);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* __restrict__ lds, int tid) const {
+        const int rip = tid / ROW_ITEMS, item = tid - rip * ROW_ITEMS;
+        const int wc = item / PARTS, part = item - wc * PARTS;
+        unsigned char* l = lds + (rip * WR + wc) * PITCH + part * 16;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            if (rip < RPP && rip + it * RPP < HR) *reinterpret_cast<uint4*>(l + it * RPP * WR * PITCH) = v[it];
+    }
+};
 
 template <class C>
 __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy,
@@ -377,8 +411,8 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CIB = C::CIB, COB = C::COB, KH = C::KH, KW = C::KW, TH = C::TH, TW = C::TW;
     constexpr int CIT = C::CIT, COT = C::COT, HR = C::HR, WR = C::WR, PX = C::PX, PY = C::PY;
-    unsigned char* xs = smem;
-    unsigned char* ys = smem + C::XBYTES;
+    unsigned char* ring = smem;                                   // 4 X halo planes: plane t lives in slot t & 3
+    unsigned char* ybuf = smem + 4 * C::PLANE;                    // dY tile of step t in buffer t & 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // wave = dt
     const int co_subs = d.CO / COB;
     const int ci0 = (blockIdx.y / co_subs) * CIB, co0 = (blockIdx.y % co_subs) * COB;
@@ -401,45 +435,63 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
     const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
-    const int tile_beg = blockIdx.x * d.tiles_per_block;
-    int tile_end = tile_beg + d.tiles_per_block;
-    if (tile_end > d.ntiles) tile_end = d.ntiles;
-    for (int tile = tile_beg; tile < tile_end; ++tile) {
-        const int tt = tile % d.T; int q = tile / d.T;
-        const int tw = q % d.tiles_w; q /= d.tiles_w;
+    PlaneStager<192, HR, WR, CIB / 8, PX> sx;
+    PlaneStager<192, TH, TW, COB / 8, PY> sy;
+    const bf16_t* xsrc = x + ci0;
+    const bf16_t* ysrc = dy + co0;
+
+    // A workgroup walks whole time-columns: for a fixed (n, h-tile, w-tile) it marches t = 0..T-1, so every X plane is
+    // fetched from memory once (not KT times) and lives in the LDS ring for the three steps that use it.
+    const int col_beg = blockIdx.x * d.cols_per_block;
+    int col_end = col_beg + d.cols_per_block;
+    if (col_end > d.ncols) col_end = d.ncols;
+    for (int colidx = col_beg; colidx < col_end; ++colidx) {
+        const int tw = colidx % d.tiles_w; const int q = colidx / d.tiles_w;
         const int th = q % d.tiles_h; const int n = q / d.tiles_h;
         const int h0 = th * TH, w0 = tw * TW;
-        if (tile != tile_beg) __syncthreads();
-        // ---- stage X halo (channels ci0..ci0+CIB) and dY tile (channels co0..co0+COB), zero filled ----
-        stage_halo<192, 3, HR, WR, CIB / 8, PX>(x + ci0, ldx, xs, n, tt - 1, h0 - KH / 2, w0 - KW / 2, d.T, d.H, d.W, tid);
-        stage_halo<192, 1, TH, TW, COB / 8, PY>(dy + co0, lddy, ys, n, tt, h0, w0, d.T, d.H, d.W, tid);
-        __syncthreads();
-
-        bf16x8 bfr[KH][COT];                                  // rolling window of dY fragments: row h lives in slot h % KH
-        const unsigned char* xplane = xs + wave * HR * WR * PX + loffx;
-#pragma unroll
-        for (int hr = 0; hr < HR; ++hr) {
-            if (hr < TH) {
-#pragma unroll
-                for (int j = 0; j < COT; ++j) {
-                    bfr[hr % KH][j] = tr_frag(ys + hr * TW * PY + j * 32 + loffy, 16 * PY);
-                    if (wave == 0) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[hr % KH][j], accb[j], 0, 0, 0);
-                }
+        const int hx = h0 - KH / 2, wx = w0 - KW / 2;
+        __syncthreads();                                          // previous column is done with the ring
+        sx.fetch(xsrc, ldx, n, -1, hx, wx, d.T, d.H, d.W, tid);   // plane -1 = zeros
+        sx.store(ring + 3 * C::PLANE, tid);
+        sx.fetch(xsrc, ldx, n, 0, hx, wx, d.T, d.H, d.W, tid);
+        sx.store(ring, tid);
+        sx.fetch(xsrc, ldx, n, 1, hx, wx, d.T, d.H, d.W, tid);
+        sy.fetch(ysrc, lddy, n, 0, h0, w0, d.T, d.H, d.W, tid);
+        for (int tt = 0; tt < d.T; ++tt) {
+            sx.store(ring + ((tt + 1) & 3) * C::PLANE, tid);      // plane tt+1 (zeros past the end)
+            sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
+            __syncthreads();
+            if (tt + 1 < d.T) {                                   // next step's operands fly while this step computes
+                sx.fetch(xsrc, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
+                sy.fetch(ysrc, lddy, n, tt + 1, h0, w0, d.T, d.H, d.W, tid);
             }
+            const unsigned char* ys = ybuf + (tt & 1) * C::YBYTES;
+            bf16x8 bfr[KH][COT];                                  // rolling window of dY fragments: row h lives in slot h % KH
+            const unsigned char* xplane = ring + ((tt + wave - 1) & 3) * C::PLANE + loffx;
 #pragma unroll
-            for (int b = 0; b < KW; ++b) {
-                bf16x8 afr[CIT];
+            for (int hr = 0; hr < HR; ++hr) {
+                if (hr < TH) {
 #pragma unroll
-                for (int i = 0; i < CIT; ++i) afr[i] = tr_frag(xplane + (hr * WR + b) * PX + i * 32, 16 * PX);
+                    for (int j = 0; j < COT; ++j) {
+                        bfr[hr % KH][j] = tr_frag(ys + hr * TW * PY + j * 32 + loffy, 16 * PY);
+                        if (wave == 0) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[hr % KH][j], accb[j], 0, 0, 0);
+                    }
+                }
 #pragma unroll
-                for (int a = 0; a < KH; ++a) {
-                    const int h = hr - a;
-                    if (h >= 0 && h < TH) {
+                for (int b = 0; b < KW; ++b) {
+                    bf16x8 afr[CIT];
 #pragma unroll
-                        for (int i = 0; i < CIT; ++i)
+                    for (int i = 0; i < CIT; ++i) afr[i] = tr_frag(xplane + (hr * WR + b) * PX + i * 32, 16 * PX);
 #pragma unroll
-                            for (int j = 0; j < COT; ++j)
-                                acc[a][b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[h % KH][j], acc[a][b][i][j], 0, 0, 0);
+                    for (int a = 0; a < KH; ++a) {
+                        const int h = hr - a;
+                        if (h >= 0 && h < TH) {
+#pragma unroll
+                            for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                                for (int j = 0; j < COT; ++j)
+                                    acc[a][b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[h % KH][j], acc[a][b][i][j], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -497,26 +549,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-typedef WgCfg<16, 16, 3, 3, 4> W333_16_16;
+typedef WgCfg<16, 16, 3, 3, 8> W333_16_16;
 typedef WgCfg<16, 32, 3, 3, 4> W333_16_32;
 typedef WgCfg<32, 16, 3, 3, 4> W333_32_16;
 typedef WgCfg<32, 32, 3, 3, 4> W333_32_32;
 typedef WgCfg<16, 16, 7, 7, 4> W377_16_16;
 
-inline int wg_blocks_x(long ntiles, int nsub)
+inline int wg_blocks_x(long ncols, int nsub)
 {
     long nb = 768 / nsub;                 // ~3 workgroups per CU over the whole chip
     if (nb < 16) nb = 16;
-    if (nb > ntiles) nb = ntiles;
+    if (nb > ncols) nb = ncols;
     return (int)nb;
 }
 
 template <class C>
 size_t wg_ws_bytes(int N, int T, int H, int W, int CI, int CO)
 {
-    const long ntiles = (long)N * T * ceil_div(H, C::TH) * ceil_div(W, C::TW);
+    (void)T;
+    const long ncols = (long)N * ceil_div(H, C::TH) * ceil_div(W, C::TW);
     const int nsub = (CI / C::CIB) * (CO / C::COB);
-    return (size_t)wg_blocks_x(ntiles, nsub) * nsub * C::SLAB_FLOATS * sizeof(float);
+    return (size_t)wg_blocks_x(ncols, nsub) * nsub * C::SLAB_FLOATS * sizeof(float);
 }
 
 template <class C>
@@ -524,12 +577,12 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
                      int CI, int CO, void* ws, size_t ws_bytes, hipStream_t s)
 {
     WgDims d{N, T, H, W, CI, CO, ceil_div(H, C::TH), ceil_div(W, C::TW), 0, 0};
-    const long ntiles = (long)N * T * d.tiles_h * d.tiles_w;
+    const long ncols = (long)N * d.tiles_h * d.tiles_w;
     const int nsub = (CI / C::CIB) * (CO / C::COB);
-    const int nbx = wg_blocks_x(ntiles, nsub);
-    d.ntiles = (int)ntiles;
-    d.tiles_per_block = ceil_div(ntiles, nbx);
-    const int nblk = ceil_div(ntiles, d.tiles_per_block);      // blocks that own at least one tile
+    const int nbx = wg_blocks_x(ncols, nsub);
+    d.ncols = (int)ncols;
+    d.cols_per_block = ceil_div(ncols, nbx);
+    const int nblk = ceil_div(ncols, d.cols_per_block);        // blocks that own at least one time-column
     if (!ws || ws_bytes < (size_t)nblk * nsub * C::SLAB_FLOATS * sizeof(float)) return VVAE_ERR_WORKSPACE;
     auto k = conv3d_wgrad_bf16_kernel<C>;
     if (C::LDS_BYTES > 65536) {
