@@ -86,6 +86,12 @@ int vvae_convt_1x2x2_dgrad(const void* dy, int lddy, const float* w, void* dx, i
                            int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
 int vvae_convt_1x2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw,
                            int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* bf16 MFMA path (weights in registers, no LDS) for the UNet decoder shapes 128->64, 64->32, 32->16:
+ * dgrad = 0: x -> y (+bias); dgrad = 1: "x" is dy (2H x 2W, Cout), "y" is dx (H x W, Cin).  ws: packed weights. */
+int vvae_convt_bf16_supported(int Cin, int Cout, int ld_in, int ld_out);
+size_t vvae_convt_bf16_ws_bytes(int Cin, int Cout);
+int vvae_convt_1x2x2_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                          int NT, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- temporal attention core: q_norm/k_norm + RoPE + masked softmax(QK^T/sqrt(D))V,
  *      train/layers.py:159-170 (called from FactoredAttention, layers.py:212-213).

@@ -81,6 +81,14 @@ def test_video_vae_loss_and_grads_fp32(dev, flavour):
     mask = torch.ones(b, t); mask[1, 6:] = 0
     noise = _noise(cfg, b, t, 7)
     emask = OLoss.expand_mask(mask.bool(), cfg.hw)
+    if flavour == "rl":
+        # the Bernoulli gate is a hard threshold u < p: keep every injected u at least 0.02 away from the oracle's p so
+        # that last-bit differences between the two paths cannot flip a frame (that would be a discrete, O(1) change)
+        with torch.no_grad():
+            sel = OM.video_vae_rl(p, cfg, video, emask, noise)[2]
+        u = noise["bernoulli_u"]
+        close = (u - sel).abs() < 0.02
+        noise["bernoulli_u"] = torch.where(close, torch.where(sel > 0.5, sel - 0.05, sel + 0.05), u)
     po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     if flavour == "model":
         out_o = OM.video_vae(po, cfg, video, emask, noise)

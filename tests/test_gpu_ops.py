@@ -410,3 +410,36 @@ def test_gemm_tn_weight_gradient(dev, m, n, k):
     assert_close_scaled(db, b.float().sum(0), rel=1e-4, what="db")
     c2, _ = ops.gemm_tn(a, b)
     assert torch.equal(c, c2), "slab reduction must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("ci,co,shape", [(32, 16, (2, 3, 6, 10)), (64, 32, (1, 2, 5, 7)), (128, 64, (1, 2, 4, 8))])
+def test_conv_transpose_bf16_fast_path(dev, ci, co, shape):
+    """bf16 MFMA ConvTranspose fwd/dgrad (weights in registers) vs the generic fp32-matrix-core path and the oracle."""
+    from video_vae_amd import ops
+    from video_vae_amd._lib import lib
+    n, t, h, w = shape
+    x = _bf16_exact((n, t, h, w, ci), 90, 1.0)
+    k = _bf16_exact((1, 2, 2, ci, co), 91, (4 * ci) ** -0.5)
+    b = rnd((co,), 92, 0.1)
+    gy = _bf16_exact((n, t, 2 * h, 2 * w, co), 93, 1.0)
+    assert lib().vvae_convt_bf16_supported(ci, co, ci, co) == 1
+    xg, kg, bg, gyg = x.to(dev, torch.bfloat16), k.to(dev), b.to(dev), gy.to(dev, torch.bfloat16)
+    y_fast = ops.convt_fwd_raw(xg, kg, bg)
+    dx_fast = ops.convt_dgrad_raw(gyg, kg)
+    ops.force_generic_conv(True)
+    try:
+        y_gen = ops.convt_fwd_raw(xg, kg, bg)
+        dx_gen = ops.convt_dgrad_raw(gyg, kg)
+    finally:
+        ops.force_generic_conv(False)
+    assert_close(y_fast, y_gen, rtol=1e-2, atol=1e-2, what="fast vs generic y")
+    assert_close(dx_fast, dx_gen, rtol=1e-2, atol=1e-2 * float(dx_gen.float().abs().max()), what="fast vs generic dx")
+    xo = x.clone().requires_grad_(True)
+    yo = O.conv_transpose_1x2x2(xo, k, b, torch.bfloat16)
+    yo.backward(gy)
+    assert_close(y_fast, yo, rtol=2e-2, atol=2e-2, what="fast vs oracle y")
+    assert_close_scaled(dx_fast, xo.grad, rel=2e-2, what="fast vs oracle dx")
+    # channel-slice destination (concat elision): write the up-sampled half of a 2*co buffer in place
+    buf = torch.zeros((n, t, 2 * h, 2 * w, 2 * co), dtype=torch.bfloat16, device=dev)
+    ops.convt_fwd_raw(xg, kg, bg, out=buf[..., :co])
+    assert torch.equal(buf[..., :co], y_fast) and float(buf[..., co:].abs().max()) == 0

@@ -294,3 +294,165 @@ extern "C" int vvae_convt_1x2x2_wgrad(const void* x, int ldx, const void* dy, in
     if (dtype == VVAE_DT_BF16) return launch_convt_wgrad<bf16_t>(x, ldx, dy, lddy, dw, d, (hipStream_t)stream);
     return VVAE_ERR_BAD_ARG;
 }
+
+// =========================================================================================== ConvTranspose, bf16 MFMA path
+// Pointwise GEMM + pixel shuffle on v_mfma_f32_16x16x32_bf16, no LDS at all: the voxel operand fragment (8 consecutive
+// channels of one voxel per lane) is a 16-byte global load straight from the NDHWC row, the weights (<= 64 KB) are packed
+// once into fragment order and held in REGISTERS for the life of the wave, and with the weights as the A operand a lane
+// ends up with 4 consecutive output channels of one voxel (8-byte stores into the pitched destination slice).
+//   MODE 0 (fwd)  : y[up(v,a,b)][co] = bias[co] + sum_ci x[v][ci] K[1-a][1-b][ci][co]      K dim = Cin,     tiles = 4*Cout/16
+//   MODE 1 (dgrad): dx[v][ci]        = sum_{a,b,co} dy[up(v,a,b)][co] K[1-a][1-b][ci][co]   K dim = 4*Cout,  tiles = Cin/16
+// WSPLIT waves share a voxel tile and split the output tiles (keeps <= 16 weight fragments = 64 VGPRs per wave).
+namespace {
+
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+
+template <int MODE, int CIN, int COUT> struct CtCfg {
+    static constexpr int KSTEPS = MODE == 0 ? CIN / 32 : (4 * COUT) / 32;
+    static constexpr int OT = MODE == 0 ? (4 * COUT) / 16 : CIN / 16;
+    static constexpr int WSPLIT = (OT * KSTEPS > 16) ? 4 : 1;
+    static constexpr int NTL = OT / WSPLIT;
+    static_assert(NTL * KSTEPS <= 16 && OT % WSPLIT == 0, "weight fragments must fit in registers");
+};
+
+// packed[(ot*KSTEPS + ks)*64 + lane] = 8 bf16: row = lane&15 (output channel in tile), k = 32ks + 8(lane>>4) + e
+template <int MODE, int CIN, int COUT>
+__global__ void convt_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp)
+{
+    typedef CtCfg<MODE, CIN, COUT> C;
+    const int total = C::OT * C::KSTEPS * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int l = i & 63, ks = (i >> 6) % C::KSTEPS, ot = (i >> 6) / C::KSTEPS;
+        const int row = l & 15, g = l >> 4;
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int a, b, ci, co;
+            if (MODE == 0) {
+                const int cot = ot % (COUT / 16), ab = ot / (COUT / 16);
+                a = ab >> 1; b = ab & 1; co = cot * 16 + row; ci = 32 * ks + 8 * g + e;
+            } else {
+                ci = ot * 16 + row;
+                int ab;
+                if (COUT >= 32) { ab = ks / (COUT / 32); co = (ks % (COUT / 32)) * 32 + 8 * g + e; }
+                else { ab = 2 * ks + (g >> 1); co = 8 * (g & 1) + e; }
+                a = ab >> 1; b = ab & 1;
+            }
+            const float v = w[((long)((1 - a) * 2 + (1 - b)) * CIN + ci) * COUT + co];
+            const uint32_t h = f2bf(v);
+            if (e & 1) pk[e >> 1] |= h << 16; else pk[e >> 1] = h;
+        }
+        wp[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
+template <int MODE, int CIN, int COUT>
+__global__ __launch_bounds__(256) void convt_bf16_kernel(const bf16_t* __restrict__ in, int ldin, const uint4* __restrict__ wp,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ out, int ldout, int NT, int H, int W)
+{
+    typedef CtCfg<MODE, CIN, COUT> C;
+    constexpr int KSTEPS = C::KSTEPS, NTL = C::NTL, WSPLIT = C::WSPLIT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wsub = wave % WSPLIT, vsub = wave / WSPLIT;          // which output tiles / which voxel tile of the group
+    constexpr int VT_PER_BLOCK = 4 / WSPLIT;
+    const long V = (long)NT * H * W;
+    const long nvt = (V + 15) / 16;
+
+    bf16x8c wfr[NTL][KSTEPS];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+            wfr[i][ks] = __builtin_bit_cast(bf16x8c, wp[((wsub + WSPLIT * i) * KSTEPS + ks) * 64 + lane]);
+
+    for (long vt = (long)blockIdx.x * VT_PER_BLOCK + vsub; vt < nvt; vt += (long)gridDim.x * VT_PER_BLOCK) {
+        const long v = vt * 16 + r;
+        const bool ok = v < V;
+        const long vc = ok ? v : 0;
+        const int wq = (int)(vc % W); const long q2 = vc / W; const int hq = (int)(q2 % H); const long pq = q2 / H;
+        const long up00 = (pq * (2 * H) + 2 * hq) * (2L * W) + 2 * wq;        // up(v, 0, 0); up(v,a,b) = up00 + a*2W + b
+        bf16x8c xf[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const bf16_t* p;
+            if (MODE == 0) p = in + vc * ldin + 32 * ks + 8 * g;
+            else {
+                int ab, ch;
+                if (COUT >= 32) { ab = ks / (COUT / 32); ch = (ks % (COUT / 32)) * 32 + 8 * g; }
+                else { ab = 2 * ks + (g >> 1); ch = 8 * (g & 1); }
+                p = in + (up00 + (ab >> 1) * 2L * W + (ab & 1)) * ldin + ch;
+            }
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (ok) t = *reinterpret_cast<const uint4*>(p);
+            xf[ks] = __builtin_bit_cast(bf16x8c, t);
+        }
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[i][ks], xf[ks], acc, 0, 0, 0);
+            const int ot = wsub + WSPLIT * i;
+            long dst; int ch;
+            if (MODE == 0) {
+                const int cot = ot % (COUT / 16), ab = ot / (COUT / 16);
+                dst = up00 + (ab >> 1) * 2L * W + (ab & 1); ch = cot * 16 + 4 * g;
+            } else { dst = vc; ch = ot * 16 + 4 * g; }
+            if (ok) {
+                float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+                if (MODE == 0 && bias) { b0 = bias[ch]; b1 = bias[ch + 1]; b2 = bias[ch + 2]; b3 = bias[ch + 3]; }
+                uint2 o;
+                o.x = (uint32_t)f2bf(acc[0] + b0) | ((uint32_t)f2bf(acc[1] + b1) << 16);
+                o.y = (uint32_t)f2bf(acc[2] + b2) | ((uint32_t)f2bf(acc[3] + b3) << 16);
+                *reinterpret_cast<uint2*>(out + dst * ldout + ch) = o;
+            }
+        }
+    }
+}
+
+template <int MODE, int CIN, int COUT>
+int launch_convt_bf16(const void* in, int ldin, const float* w, const float* bias, void* out, int ldout, int NT, int H, int W, void* ws,
+                      hipStream_t s)
+{
+    typedef CtCfg<MODE, CIN, COUT> C;
+    uint4* wp = (uint4*)ws;
+    hipLaunchKernelGGL((convt_pack_kernel<MODE, CIN, COUT>), dim3(ceil_div(C::OT * C::KSTEPS * 64, 256)), dim3(256), 0, s, w, wp);
+    VVAE_LAUNCH_CHECK();
+    const long nvt = ((long)NT * H * W + 15) / 16;
+    long blocks = (nvt + (4 / C::WSPLIT) - 1) / (4 / C::WSPLIT);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((convt_bf16_kernel<MODE, CIN, COUT>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)in, ldin, wp, bias,
+                       (bf16_t*)out, ldout, NT, H, W);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+inline bool convt_bf16_shape(int Cin, int Cout) { return (Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 32) || (Cin == 32 && Cout == 16); }
+
+}  // namespace
+
+// 1 if the bf16 MFMA ConvTranspose path takes this shape (the three UNet decoder levels), pitches in elements.
+extern "C" int vvae_convt_bf16_supported(int Cin, int Cout, int ld_in, int ld_out)
+{
+    return (convt_bf16_shape(Cin, Cout) && ld_in % 8 == 0 && ld_out % 4 == 0) ? 1 : 0;
+}
+
+extern "C" size_t vvae_convt_bf16_ws_bytes(int Cin, int Cout) { return convt_bf16_shape(Cin, Cout) ? (size_t)4 * Cin * Cout * 2 : 0; }
+
+// dgrad = 0: x (NT,H,W,Cin) -> y (NT,2H,2W,Cout) + bias.  dgrad = 1: "x" is dy (NT,2H,2W,Cout), "y" is dx (NT,H,W,Cin).
+extern "C" int vvae_convt_1x2x2_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                                     int NT, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !w || !y || NT <= 0 || H <= 0 || W <= 0 || !convt_bf16_shape(Cin, Cout)) return VVAE_ERR_BAD_ARG;
+    const int cin_side = dgrad ? Cout : Cin, cout_side = dgrad ? Cin : Cout;
+    if (ldx < cin_side || ldy < cout_side || ldx % 8 || ldy % 4 || ((uintptr_t)x % 16) || ((uintptr_t)y % 8)) return VVAE_ERR_BAD_ARG;
+    if (!ws || ws_bytes < vvae_convt_bf16_ws_bytes(Cin, Cout) || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+#define CT_GO(CI, CO)                                                                                                   \
+    if (Cin == CI && Cout == CO)                                                                                        \
+        return dgrad ? launch_convt_bf16<1, CI, CO>(x, ldx, w, nullptr, y, ldy, NT, H, W, ws, s)                        \
+                     : launch_convt_bf16<0, CI, CO>(x, ldx, w, bias, y, ldy, NT, H, W, ws, s);
+    CT_GO(128, 64) CT_GO(64, 32) CT_GO(32, 16)
+#undef CT_GO
+    return VVAE_ERR_BAD_ARG;
+}

@@ -301,12 +301,32 @@ def max_pool_1x2x2(x):
 
 
 # --------------------------------------------------------------------------------------------- ConvTranspose (1,2,2)
+def _convt_fast(x, cin, cout, ld_in, ld_out):
+    return (x.dtype == torch.bfloat16 and not _FORCE_GENERIC[0]
+            and lib().vvae_convt_bf16_supported(cin, cout, ld_in, ld_out) == 1)
+
+
+def _convt_bf16(x, ldx, kernel, bias, out, nt, h, w, cin, cout, dgrad):
+    """bf16 MFMA ConvTranspose (h, w = low resolution).  dgrad=1: x is dy at 2h x 2w, out is dx at h x w."""
+    wsb = lib().vvae_convt_bf16_ws_bytes(cin, cout)
+    ws, wsb = _ws(wsb, x.device)
+    vox = nt * h * w
+    alg = vox * (cin + 4 * cout) * 2
+    tag = f"convt_{'dgrad' if dgrad else 'fwd'} {cin}->{cout} @{h}x{w}"
+    check(_launch(tag, alg, 2 * vox * 4 * cin * cout, "convt_bf16_kernel",
+                  lambda: lib().vvae_convt_1x2x2_bf16(_p(x), ldx, _p(kernel), _p(bias), _p(out), out.stride(-2), nt, h, w, cin, cout,
+                                                      dgrad, _p(ws), wsb, _stream())), "vvae_convt_1x2x2_bf16")
+    return out
+
+
 def convt_fwd_raw(x, kernel, bias, out=None):
     x, ldx = rows(x)
     n, t, h, w, cin = x.shape
     cout = kernel.shape[-1]
     if out is None:
         out = torch.empty((n, t, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device)
+    if _convt_fast(x, cin, cout, ldx, out.stride(-2)):
+        return _convt_bf16(x, ldx, kernel, bias, out, n * t, h, w, cin, cout, 0)
     check(lib().vvae_convt_1x2x2_fwd(_p(x), ldx, _p(kernel), _p(bias), _p(out), out.stride(-2), n * t, h, w, cin, cout,
                                      _dt(x), _stream()), "vvae_convt_1x2x2_fwd")
     return out
@@ -318,6 +338,8 @@ def convt_dgrad_raw(dy, kernel, out=None):
     cin = kernel.shape[-2]
     if out is None:
         out = torch.empty((n, t, h2 // 2, w2 // 2, cin), dtype=dy.dtype, device=dy.device)
+    if _convt_fast(dy, cin, cout, lddy, out.stride(-2)):
+        return _convt_bf16(dy, lddy, kernel, None, out, n * t, h2 // 2, w2 // 2, cin, cout, 1)
     check(lib().vvae_convt_1x2x2_dgrad(_p(dy), lddy, _p(kernel), _p(out), out.stride(-2), n * t, h2 // 2, w2 // 2, cin, cout,
                                        _dt(dy), _stream()), "vvae_convt_1x2x2_dgrad")
     return out
