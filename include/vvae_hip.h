@@ -65,11 +65,12 @@ int vvae_colsum(const void* x, int ld, long V, int C, float* out, int dtype, voi
 
 /* ---- GroupNorm(G, eps) + SiLU: nnx.GroupNorm + nnx.silu at train/unet.py:22-23,28-29.
  *      sums: fp64 [N][G][2] (sum, sum of squares) produced by vvae_gn_stats; S = voxels per sample. ---- */
-int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, int dtype, void* stream);
+size_t vvae_gn_part_floats(int N, long S, int C);   /* fp32 scratch floats for `part` below (per-workgroup partial sums) */
+int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, float* part, int dtype, void* stream);
 int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const double* sums, const float* gamma, const float* beta,
                      int N, long S, int C, int G, float eps, int dtype, void* stream);
 int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const double* sums,
-                     const float* gamma, const float* beta, double* csum /* fp64 [N][C][2] scratch */,
+                     const float* gamma, const float* beta, double* csum /* fp64 [N][C][2] scratch */, float* part,
                      float* dgamma, float* dbeta, int N, long S, int C, int G, float eps, int dtype, void* stream);
 
 /* ---- max-pool (1,2,2)/(1,2,2): nnx.max_pool at train/unet.py:50.  NT = n*t planes; H, W = input size.

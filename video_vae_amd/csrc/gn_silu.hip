@@ -49,7 +49,7 @@ __device__ __forceinline__ void column_reduce(float& a, float& b, int cvecs, int
 // Thread layout shared by all kernels: cvecs = C/VEC lanes across channels, rows = 256/cvecs voxels per pass.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int ldx, GnDims d,
-                                                       double* __restrict__ sums, int voxels_per_block)
+                                                       float* __restrict__ part, int voxels_per_block)
 {
     __shared__ float red[256][2];
     __shared__ float chan[kMaxC][2];
@@ -63,13 +63,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     float s[VEC], ss[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s[i] = ss[i] = 0.f;
-    if (rl < rows)
-        for (long v = vbeg + rl; v < vend; v += rows) {
+    if (rl < rows) {
+        long v = vbeg + rl;
+        for (; v + rows < vend; v += 2 * rows) {                  // two rows per trip: 2 independent 16-byte loads in flight
+            float t[VEC], u[VEC];
+            VecIO<T, VEC>::load(xs + v * ldx + cl * VEC, t);
+            VecIO<T, VEC>::load(xs + (v + rows) * ldx + cl * VEC, u);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { s[i] += t[i] + u[i]; ss[i] += t[i] * t[i] + u[i] * u[i]; }
+        }
+        if (v < vend) {
             float t[VEC];
             VecIO<T, VEC>::load(xs + v * ldx + cl * VEC, t);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { s[i] += t[i]; ss[i] += t[i] * t[i]; }
         }
+    }
     // reduce over rows for each channel, one channel-of-the-vector at a time
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -79,11 +88,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
     __syncthreads();
     const int cpg = d.C / d.G;
-    if (threadIdx.x < d.G) {
-        double a = 0.0, b = 0.0;
+    if (threadIdx.x < d.G) {                     // one partial row per workgroup: part[n][block][g][2] (no atomics: fp64 atomics
+        float a = 0.f, b = 0.f;                  // on a handful of addresses cost 30-70 us per launch)
         for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { a += chan[c][0]; b += chan[c][1]; }
-        atomicAdd(sums + ((long)n * d.G + threadIdx.x) * 2, a);
-        atomicAdd(sums + ((long)n * d.G + threadIdx.x) * 2 + 1, b);
+        float* p = part + (((long)n * gridDim.x + blockIdx.x) * d.G + threadIdx.x) * 2;
+        p[0] = a; p[1] = b;
+    }
+}
+
+// out[n][j][2] (fp64) = sum over nblk workgroup partials part[n][blk][j][2] (fp32), fixed order.  grid = N, J = G or C.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, double* __restrict__ out, int nblk, int J)
+{
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * J; i += 256) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += (double)part[((long)n * nblk + b) * 2 * J + i];
+        out[(long)n * 2 * J + i] = s;
     }
 }
 
@@ -123,20 +143,24 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ 
     const long vbeg = (long)blockIdx.x * voxels_per_block;
     long vend = vbeg + voxels_per_block;
     if (vend > d.S) vend = d.S;
-    const long items = (vend - vbeg) * cvecs;
-    const T* xs = x + ((long)n * d.S + vbeg) * ldx;
-    T* ys = y + ((long)n * d.S + vbeg) * ldy;
-    for (long it = threadIdx.x; it < items; it += 256) {
-        const long v = it / cvecs; const int c0 = (int)(it % cvecs) * VEC;
-        float t[VEC];
-        VecIO<T, VEC>::load(xs + v * ldx + c0, t);
+    // thread = fixed channel vector cl, rows rl + k*rows: no per-item division, per-channel affine in registers
+    const int rows = 256 / cvecs, cl = threadIdx.x % cvecs, rl = threadIdx.x / cvecs, c0 = cl * VEC;
+    const T* xs = x + (long)n * d.S * ldx + c0;
+    T* ys = y + (long)n * d.S * ldy + c0;
+    float aa[VEC], bb[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float z = t[i] * ab[c0 + i][0] + ab[c0 + i][1];
-            t[i] = z * sigmoidf_(z);
+    for (int i = 0; i < VEC; ++i) { aa[i] = ab[c0 + i][0]; bb[i] = ab[c0 + i][1]; }
+    if (rl < rows)
+        for (long v = vbeg + rl; v < vend; v += rows) {
+            float t[VEC];
+            VecIO<T, VEC>::load(xs + v * ldx, t);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float z = t[i] * aa[i] + bb[i];
+                t[i] = z * sigmoidf_(z);
+            }
+            VecIO<T, VEC>::store(ys + v * ldy, t);
         }
-        VecIO<T, VEC>::store(ys + v * ldy + c0, t);
-    }
 }
 
 // dz = dy * silu'(z), silu'(z) = s*(1 + z*(1-s)), s = sigmoid(z)
@@ -148,7 +172,7 @@ __device__ __forceinline__ float dsilu(float z) {
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                                  const double* __restrict__ sums, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, GnDims d, double* __restrict__ csum,
+                                                                 const float* __restrict__ beta, GnDims d, float* __restrict__ part,
                                                                  int voxels_per_block)
 {
     __shared__ float ab[kMaxC][2];
@@ -170,28 +194,45 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __rest
         const int g = (cl * VEC + i) / cpg;
         mu[i] = mean_g[g]; rs[i] = rstd_g[g];
     }
-    if (rl < rows)
-        for (long v = vbeg + rl; v < vend; v += rows) {
+    float aa[VEC], bb[VEC];                                       // this thread's channels never change: affine in registers
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { aa[i] = ab[cl * VEC + i][0]; bb[i] = ab[cl * VEC + i][1]; }
+    if (rl < rows) {
+        long v = vbeg + rl;
+        for (; v + rows < vend; v += 2 * rows) {                  // two rows per trip: 4 independent 16-byte loads in flight
+            float t[VEC], g[VEC], t2[VEC], g2[VEC];
+            VecIO<T, VEC>::load(xs + v * ldx + cl * VEC, t);
+            VecIO<T, VEC>::load(dys + v * lddy + cl * VEC, g);
+            VecIO<T, VEC>::load(xs + (v + rows) * ldx + cl * VEC, t2);
+            VecIO<T, VEC>::load(dys + (v + rows) * lddy + cl * VEC, g2);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float dz = g[i] * dsilu(t[i] * aa[i] + bb[i]);
+                const float dz2 = g2[i] * dsilu(t2[i] * aa[i] + bb[i]);
+                s1[i] += (dz * (t[i] - mu[i]) + dz2 * (t2[i] - mu[i])) * rs[i];
+                s2[i] += dz + dz2;
+            }
+        }
+        if (v < vend) {
             float t[VEC], g[VEC];
             VecIO<T, VEC>::load(xs + v * ldx + cl * VEC, t);
             VecIO<T, VEC>::load(dys + v * lddy + cl * VEC, g);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                const int c = cl * VEC + i;
-                const float z = t[i] * ab[c][0] + ab[c][1];
-                const float dz = g[i] * dsilu(z);
+                const float dz = g[i] * dsilu(t[i] * aa[i] + bb[i]);
                 s1[i] += dz * (t[i] - mu[i]) * rs[i];
                 s2[i] += dz;
             }
         }
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         float a = s1[i], b = s2[i];
         column_reduce(a, b, cvecs, rows, red);
         if (threadIdx.x < cvecs) {
             const int c = cl * VEC + i;
-            atomicAdd(csum + ((long)n * d.C + c) * 2, (double)a);
-            atomicAdd(csum + ((long)n * d.C + c) * 2 + 1, (double)b);
+            float* p = part + (((long)n * gridDim.x + blockIdx.x) * d.C + c) * 2;       // part[n][block][c][2]
+            p[0] = a; p[1] = b;
         }
     }
 }
@@ -221,25 +262,33 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restr
     const long vbeg = (long)blockIdx.x * voxels_per_block;
     long vend = vbeg + voxels_per_block;
     if (vend > d.S) vend = d.S;
-    const long items = (vend - vbeg) * cvecs;
-    const T* xs = x + ((long)n * d.S + vbeg) * ldx;
-    const T* dys = dy + ((long)n * d.S + vbeg) * lddy;
-    T* dxs = dx + ((long)n * d.S + vbeg) * lddx;
-    for (long it = threadIdx.x; it < items; it += 256) {
-        const long v = it / cvecs; const int c0 = (int)(it % cvecs) * VEC;
-        float t[VEC], g[VEC];
-        VecIO<T, VEC>::load(xs + v * ldx + c0, t);
-        VecIO<T, VEC>::load(dys + v * lddy + c0, g);
+    const int rows = 256 / cvecs, cl = threadIdx.x % cvecs, rl = threadIdx.x / cvecs, c0 = cl * VEC;
+    const T* xs = x + (long)n * d.S * ldx + c0;
+    const T* dys = dy + (long)n * d.S * lddy + c0;
+    T* dxs = dx + (long)n * d.S * lddx + c0;
+    // per-channel constants in registers: z = x*aa+bb;  dx = k1*dz - k2 - x*k3  with xhat folded in
+    float aa[VEC], bb[VEC], k1[VEC], k2[VEC], k3[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const int c = c0 + i, gi = c / cpg;
-            const float z = t[i] * ab[c][0] + ab[c][1];
-            const float dz = g[i] * dsilu(z);
-            const float xh = (t[i] - mean_g[gi]) * rstd_g[gi];
-            t[i] = rstd_g[gi] * (gamma[c] * dz - m1_g[gi] - xh * m2_g[gi]);
-        }
-        VecIO<T, VEC>::store(dxs + v * lddx + c0, t);
+    for (int i = 0; i < VEC; ++i) {
+        const int c = c0 + i, gi = c / cpg;
+        aa[i] = ab[c][0]; bb[i] = ab[c][1];
+        const float rs = rstd_g[gi], mu = mean_g[gi];
+        k1[i] = rs * gamma[c];
+        k3[i] = rs * rs * m2_g[gi];                       // rstd * (xhat * m2) = rs*rs*m2 * (x - mu)
+        k2[i] = rs * m1_g[gi] - k3[i] * mu;
     }
+    if (rl < rows)
+        for (long v = vbeg + rl; v < vend; v += rows) {
+            float t[VEC], g[VEC];
+            VecIO<T, VEC>::load(xs + v * ldx, t);
+            VecIO<T, VEC>::load(dys + v * lddy, g);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float dz = g[i] * dsilu(t[i] * aa[i] + bb[i]);
+                t[i] = k1[i] * dz - k2[i] - t[i] * k3[i];
+            }
+            VecIO<T, VEC>::store(dxs + v * lddx, t);
+        }
 }
 
 __global__ void gn_param_grad_kernel(const double* __restrict__ csum, int N, int C, float* __restrict__ dgamma,
@@ -287,19 +336,26 @@ bool gn_ok(const GnDims& d) {
         }                                                                                                     \
     } while (0)
 
-// sums: fp64 [N][G][2], overwritten.
-extern "C" int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, int dtype, void* stream)
+// fp32 scratch floats vvae_gn_stats / vvae_gn_silu_bwd need in `part` (per-workgroup partial sums).
+extern "C" size_t vvae_gn_part_floats(int N, long S, int C)
+{
+    if (N <= 0 || S <= 0 || C <= 0) return 0;
+    return (size_t)N * ceil_div(S, pick_vpb(S, N, 1024)) * C * 2;
+}
+
+// sums: fp64 [N][G][2], overwritten.  part: fp32 scratch, >= vvae_gn_part_floats(N, S, C) floats.
+extern "C" int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, float* part, int dtype, void* stream)
 {
     GnDims d{N, S, C, G, 0.f};
-    if (!x || !sums || !gn_ok(d) || ldx < C || (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
+    if (!x || !sums || !part || !gn_ok(d) || ldx < C || (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)N * G, s);
-    if (e != hipSuccess) return (int)e;
     const int vpb = pick_vpb(S, N, 1024);
     dim3 grid(ceil_div(S, vpb), N);
     const bool vok = dtype == VVAE_DT_F32 ? vec_ok<float>(x, ldx, C) : vec_ok<bf16_t>(x, ldx, C);
     if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
-    GN_DISPATCH(gn_stats_kernel, vok, (const T*)x, ldx, d, sums, vpb);
+    GN_DISPATCH(gn_stats_kernel, vok, (const T*)x, ldx, d, part, vpb);
+    VVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, sums, (int)grid.x, G);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -323,15 +379,13 @@ extern "C" int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const 
 
 // csum: fp64 workspace [N][C][2] (overwritten).  dgamma/dbeta fp32 [C] (overwritten).
 extern "C" int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const double* sums,
-                                const float* gamma, const float* beta, double* csum, float* dgamma, float* dbeta,
+                                const float* gamma, const float* beta, double* csum, float* part, float* dgamma, float* dbeta,
                                 int N, long S, int C, int G, float eps, int dtype, void* stream)
 {
     GnDims d{N, S, C, G, eps};
-    if (!x || !dy || !dx || !sums || !gamma || !beta || !csum || !dgamma || !dbeta || !gn_ok(d) || ldx < C || lddy < C ||
+    if (!x || !dy || !dx || !sums || !gamma || !beta || !csum || !part || !dgamma || !dbeta || !gn_ok(d) || ldx < C || lddy < C ||
         lddx < C || (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(csum, 0, sizeof(double) * 2 * (size_t)N * C, s);
-    if (e != hipSuccess) return (int)e;
     const int vpb = pick_vpb(S, N);
     dim3 grid(ceil_div(S, vpb), N);
     const bool vok = dtype == VVAE_DT_F32
@@ -341,7 +395,9 @@ extern "C" int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy
     {
         const int vpb_r = pick_vpb(S, N, 1024);
         dim3 grid(ceil_div(S, vpb_r), N);
-        GN_DISPATCH(gn_silu_bwd_reduce_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, sums, gamma, beta, d, csum, vpb_r);
+        GN_DISPATCH(gn_silu_bwd_reduce_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, sums, gamma, beta, d, part, vpb_r);
+        VVAE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, csum, (int)grid.x, C);
         VVAE_LAUNCH_CHECK();
     }
     GN_DISPATCH(gn_silu_bwd_apply_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, sums, csum, gamma, beta, d, vpb);

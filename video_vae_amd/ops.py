@@ -207,7 +207,8 @@ def gn_stats_raw(x, groups):
     n, c = x.shape[0], x.shape[-1]
     s = x.numel() // (n * c)
     sums = torch.empty((n, groups, 2), dtype=torch.float64, device=x.device)
-    check(lib().vvae_gn_stats(_p(x), ldx, n, s, c, groups, _p(sums), _dt(x), _stream()), "vvae_gn_stats")
+    part = torch.empty((lib().vvae_gn_part_floats(n, s, c),), dtype=torch.float32, device=x.device)
+    check(lib().vvae_gn_stats(_p(x), ldx, n, s, c, groups, _p(sums), _p(part), _dt(x), _stream()), "vvae_gn_stats")
     return sums
 
 
@@ -230,10 +231,11 @@ def gn_silu_bwd_raw(x, dy, sums, scale, bias, groups, eps, out=None):
     if out is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     csum = torch.empty((n, c, 2), dtype=torch.float64, device=x.device)
+    part = torch.empty((lib().vvae_gn_part_floats(n, s, c),), dtype=torch.float32, device=x.device)
     dg = torch.empty((c,), dtype=torch.float32, device=x.device)
     db = torch.empty((c,), dtype=torch.float32, device=x.device)
     check(lib().vvae_gn_silu_bwd(_p(x), ldx, _p(dy), lddy, _p(out), out.stride(-2), _p(sums), _p(scale), _p(bias), _p(csum),
-                                 _p(dg), _p(db), n, s, c, groups, eps, _dt(x), _stream()), "vvae_gn_silu_bwd")
+                                 _p(part), _p(dg), _p(db), n, s, c, groups, eps, _dt(x), _stream()), "vvae_gn_silu_bwd")
     return out, dg, db
 
 
