@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--flavour", default="model", choices=["model", "rl"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU sample")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run the timed steps eagerly (default: forward+backward replayed from a captured hipGraph)")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames per clip of the bounded CPU sample")
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips of the bounded CPU sample (4 x 16 frames = one GPU batch)")
     return ap.parse_args()
 
 
@@ -72,18 +75,18 @@ def cpu_baseline(args):
     from oracle import unet as OU
     threads = min(16, os.cpu_count() or 1)          # the box's CPU share for one GPU is 16 cores
     torch.set_num_threads(threads)
-    t, s = args.cpu_frames, args.size
+    t, s, nb = args.cpu_frames, args.size, args.cpu_clips
     p = OU.init_unet(12, 16, 3, 3, seed=5, zero_final=False)
     for v in p.values():
         v.requires_grad_(True)
     g = torch.Generator().manual_seed(0)
-    x = torch.randn((1, t, s, s, 12), generator=g) * 0.5
+    x = torch.randn((nb, t, s, s, 12), generator=g) * 0.5
     t0 = time.perf_counter()
     y = OU.unet(p, x)
     y.square().mean().backward()
     dt_s = time.perf_counter() - t0
-    return {"value": t / dt_s, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle UNet (Conv3d stack of the decoder) fwd+bwd, fp32, 1 clip x {t} frames x {s}x{s}x12 features, "
+    return {"value": nb * t / dt_s, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle UNet (Conv3d stack of the decoder) fwd+bwd, fp32, {nb} clips x {t} frames x {s}x{s}x12 features, "
                       f"1 step, {dt_s:.1f} s on {threads} threads (transformer trunk not included)"}
 
 
@@ -114,6 +117,7 @@ def main():
     B, T, S = args.batch, args.frames, args.size
     g = torch.Generator().manual_seed(0 + rank)                 # per-rank data seed = seed + rank
     rngs = V.Rngs(3 + rank)
+    mode = "eager"
     if args.workload == "unet":
         feat = (torch.randn((B, T, S, S, 12), generator=g) * 0.5).to(dev, dtype)
         tgt = torch.rand((B, T, S, S, 3), generator=g).to(dev, dtype)
@@ -132,9 +136,23 @@ def main():
         mask = torch.ones((B, T), device=dev)
         hw = (S // cfg["patch_size"]) ** 2
 
-        def step():
+        def eager_step():
             loss, _aux = L.train_step(model, opt, video, mask, L.HPARAMS, hw, rngs)
             return loss
+
+        step, mode = eager_step, "eager"
+        if not args.no_graph:
+            try:
+                from video_vae_amd.graph import GraphedTrainStep
+                gstep = GraphedTrainStep(model, opt, video, mask, L.HPARAMS, hw, rngs)
+
+                def step():
+                    loss, _aux = gstep()
+                    return loss
+                mode = "hipgraph(fwd+bwd) + eager all-reduce/clip/Adam"
+            except Exception as e:                       # capture is an optimisation, never a requirement
+                print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                step, mode = eager_step, "eager"
 
     def barrier():
         if world > 1:
@@ -144,14 +162,26 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    graphed = mode.startswith("hipgraph")
     timer = ops.KernelTimer() if rank == 0 else None
-    ops.TIMER = timer
+    if not graphed:
+        ops.TIMER = timer                      # eager: per-launch HIP events inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    if graphed and rank == 0:
+        # a replayed graph cannot host event records: time the same kernels (same shapes, same data) in eager steps
+        # run right after the timed region, on the same stream
+        ops.TIMER = timer
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.TIMER = None
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -168,7 +198,7 @@ def main():
                                     if args.workload == "vae" else "Conv3d UNet stack alone (diagnostic), ")
                                    + f"B={B}/GPU x 3x{T}x{S}x{S}, {args.dtype} compute, fp32 params, recon+KL loss, clip+Adam",
                        "flavour": args.flavour if args.workload == "vae" else "unet", "params": nparams,
-                       "global_batch": B * world, "frames_per_clip": T, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "frames_per_clip": T, "parallelism": f"dp{world}", "launch_mode": mode},
         }
         summ = timer.summary()
         conv = {k: v for k, v in summ.items() if k.startswith("conv3d")}
@@ -178,10 +208,13 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": None, "kernel": top["kernel"], "launch": tag, "avg_ms": top["avg_ms"],
                                "launches_timed": top["n"], "alg_bytes_per_launch": top["bytes"],
+                               "timed_in": "eager steps right after the timed region (graph replay cannot host events)" if graphed
+                               else "the timed region",
                                "tflops": top["flops"] / (top["avg_ms"] * 1e-3) / 1e12}
-            tot_ms = sum(v["total_ms"] for v in conv.values()) / args.steps
-            tot_b = sum(v["bytes"] * v["n"] for v in conv.values()) / args.steps
-            tot_f = sum(v["flops"] * v["n"] for v in conv.values()) / args.steps
+            nsteps_timed = 3 if graphed else args.steps
+            tot_ms = sum(v["total_ms"] for v in conv.values()) / nsteps_timed
+            tot_b = sum(v["bytes"] * v["n"] for v in conv.values()) / nsteps_timed
+            tot_f = sum(v["flops"] * v["n"] for v in conv.values()) / nsteps_timed
             out["conv_stack"] = {"ms_per_step": tot_ms, "alg_GB_per_step": tot_b / 1e9, "GBps": tot_b / tot_ms / 1e6,
                                  "frac_hbm": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS, "tflops": tot_f / tot_ms / 1e9,
                                  "frames_per_s_conv_only": B * T / (tot_ms * 1e-3)}

@@ -264,11 +264,19 @@ extern "C" int vvae_temporal_attn_fwd(const void* qkv, int ld, void* out, int ld
     hipError_t e;
     if (dtype == VVAE_DT_F32) {
         auto k = temporal_attn_fwd_kernel<float>;
-        if (lds > 65536 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+        static size_t attr_lds = 65536;
+        if (lds > attr_lds) {
+            if ((e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+            attr_lds = lds;
+        }
         hipLaunchKernelGGL(k, grid, dim3(64 * wpb), lds, s, (const float*)qkv, ld, (float*)out, ldo, q_scale, k_scale, cos_table, sin_table, mask, d, wpb);
     } else if (dtype == VVAE_DT_BF16) {
         auto k = temporal_attn_fwd_kernel<bf16_t>;
-        if (lds > 65536 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+        static size_t attr_lds = 65536;
+        if (lds > attr_lds) {
+            if ((e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+            attr_lds = lds;
+        }
         hipLaunchKernelGGL(k, grid, dim3(64 * wpb), lds, s, (const bf16_t*)qkv, ld, (bf16_t*)out, ldo, q_scale, k_scale, cos_table, sin_table, mask, d, wpb);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
@@ -290,17 +298,25 @@ extern "C" int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout,
     if (wpb < 1) { wpb = 1; if (lds > kMaxLds) return VVAE_ERR_BAD_ARG; }
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if ((e = hipMemsetAsync(dq_scale, 0, sizeof(float) * D, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(dk_scale, 0, sizeof(float) * D, s)) != hipSuccess) return (int)e;
+    if ((e = vvae_zero_async(dq_scale, sizeof(float) * D, s)) != hipSuccess) return (int)e;
+    if ((e = vvae_zero_async(dk_scale, sizeof(float) * D, s)) != hipSuccess) return (int)e;
     dim3 grid(ceil_div((long)A * heads, wpb));
     if (dtype == VVAE_DT_F32) {
         auto k = temporal_attn_bwd_kernel<float>;
-        if (lds > 65536 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+        static size_t attr_lds = 65536;
+        if (lds > attr_lds) {
+            if ((e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+            attr_lds = lds;
+        }
         hipLaunchKernelGGL(k, grid, dim3(64 * wpb), lds, s, (const float*)qkv, ld, (const float*)dout, lddo, (float*)dqkv, lddq,
                            q_scale, k_scale, cos_table, sin_table, mask, dq_scale, dk_scale, d, wpb);
     } else if (dtype == VVAE_DT_BF16) {
         auto k = temporal_attn_bwd_kernel<bf16_t>;
-        if (lds > 65536 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+        static size_t attr_lds = 65536;
+        if (lds > attr_lds) {
+            if ((e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+            attr_lds = lds;
+        }
         hipLaunchKernelGGL(k, grid, dim3(64 * wpb), lds, s, (const bf16_t*)qkv, ld, (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddq,
                            q_scale, k_scale, cos_table, sin_table, mask, dq_scale, dk_scale, d, wpb);
     } else return VVAE_ERR_BAD_ARG;

@@ -352,9 +352,11 @@ int launch_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const fl
     const int ipw = 64 / d.T;
     const size_t lds = (size_t)2 * ipw * item_stride_bytes<T_, D>(d.T);
     auto k = tattn_fwd_fast<T_, D>;
-    if (lds > 65536) {
+    static size_t attr_lds = 65536;                // grow-only: the attribute is set once per (kernel, larger size)
+    if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+        attr_lds = lds;
     }
     hipLaunchKernelGGL(k, dim3(ceil_div(d.items, ipw)), dim3(64), lds, s, (const T_*)qkv, ld, (T_*)out, ldo, lse, qs, ks, cosT, sinT, mask, d);
     VVAE_LAUNCH_CHECK();
@@ -370,9 +372,11 @@ int launch_bwd(const void* qkv, int ld, const void* out, int ldo, const void* do
     const size_t lds = (size_t)4 * ipw * item_stride_bytes<T_, D>(d.T) + (size_t)2 * ipw * d.T * (d.T + 1) * sizeof(float);
     if (lds > 160 * 1024) return VVAE_ERR_BAD_ARG;
     auto k = tattn_bwd_fast<T_, D>;
-    if (lds > 65536) {
+    static size_t attr_lds = 65536;                // grow-only: the attribute is set once per (kernel, larger size)
+    if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+        attr_lds = lds;
     }
     hipLaunchKernelGGL(k, dim3(ceil_div(d.items, ipw)), dim3(64), lds, s, (const T_*)qkv, ld, (const T_*)out, ldo, (const T_*)dout, lddo, lse,
                        (T_*)dqkv, lddq, qs, ks, cosT, sinT, mask, part, d);

@@ -111,4 +111,21 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 
 // host-side helpers
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Zero `n` 32-bit words with a KERNEL (not hipMemsetAsync): inside a captured hipGraph a memset node followed by an
+// atomically-accumulating kernel was observed to race on ROCm 7.2 (stale words in ~1 of 3 replays); a fill kernel is an
+// ordinary kernel node with ordinary stream ordering.
+__global__ static void vvae_zero_words_kernel(uint32_t* __restrict__ p, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t vvae_zero_async(void* p, size_t bytes, hipStream_t s)
+{
+    const long n = (long)(bytes / 4);
+    if (n <= 0) return hipSuccess;
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(vvae_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, n);
+    return hipGetLastError();
+}
 #define VVAE_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -223,9 +223,11 @@ int launch_cfg(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf1
     d.tiles_w = ceil_div(d.W, C::TW);
     dim3 grid((unsigned)((long)d.N * d.T * d.tiles_h * d.tiles_w), d.CO / C::CO_BLK);
     auto k = conv3d_bf16_kernel<C>;
-    if (C::LDS_BYTES > 65536) {
+    static bool attr_done = false;                 // once per instantiation: keeps the launch path free of non-stream calls
+    if (C::LDS_BYTES > 65536 && !attr_done) {      // (hipGraph capture of the training step replays only stream work)
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
+        attr_done = true;
     }
     hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d);
     VVAE_LAUNCH_CHECK();
@@ -585,9 +587,11 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
     const int nblk = ceil_div(ncols, d.cols_per_block);        // blocks that own at least one time-column
     if (!ws || ws_bytes < (size_t)nblk * nsub * C::SLAB_FLOATS * sizeof(float)) return VVAE_ERR_WORKSPACE;
     auto k = conv3d_wgrad_bf16_kernel<C>;
-    if (C::LDS_BYTES > 65536) {
+    static bool attr_done = false;                 // once per instantiation: keeps the launch path free of non-stream calls
+    if (C::LDS_BYTES > 65536 && !attr_done) {      // (hipGraph capture of the training step replays only stream work)
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
+        attr_done = true;
     }
     hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(192), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d);
     VVAE_LAUNCH_CHECK();

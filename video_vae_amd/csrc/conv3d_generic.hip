@@ -206,7 +206,7 @@ int launch_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, fl
 {
     const long V = (long)d.N * d.T * d.H * d.W;
     const int taps = d.kt * d.kh * d.kw;
-    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)taps * d.Cin * d.Cout, s);
+    hipError_t e = vvae_zero_async(dw, sizeof(float) * (size_t)taps * d.Cin * d.Cout, s);
     if (e != hipSuccess) return (int)e;
     const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
     // aim for >= ~2048 blocks in total, chunk a multiple of 16 voxels
@@ -234,7 +234,7 @@ int launch_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, fl
         base += nt;
     }
     if (dbias) {
-        e = hipMemsetAsync(dbias, 0, sizeof(float) * d.Cout, s);
+        e = vvae_zero_async(dbias, sizeof(float) * d.Cout, s);
         if (e != hipSuccess) return (int)e;
         const int vb = 4096;
         hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(V, vb)), dim3(256), 0, s, dyp, lddy, V, d.Cout, dbias, vb);
@@ -295,7 +295,7 @@ extern "C" int vvae_colsum(const void* x, int ld, long V, int C, float* out, int
 {
     if (!x || !out || V <= 0 || C <= 0 || ld < C) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, s);
+    hipError_t e = vvae_zero_async(out, sizeof(float) * C, s);
     if (e != hipSuccess) return (int)e;
     const int vb = 4096;
     if (dtype == VVAE_DT_F32)

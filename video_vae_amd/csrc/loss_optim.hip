@@ -218,7 +218,7 @@ extern "C" int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const f
     if (!mean || !logvar || (!z && !kl) || (z && !eps) || B <= 0 || T <= 0 || per <= 0) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (kl && (e = hipMemsetAsync(kl, 0, sizeof(float) * B, s)) != hipSuccess) return (int)e;
+    if (kl && (e = vvae_zero_async(kl, sizeof(float) * B, s)) != hipSuccess) return (int)e;
     const long M = (long)T * per;
     const int epb = pick_epb(M, B);
     dim3 grid(ceil_div(M, epb), B);
@@ -256,8 +256,8 @@ extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, con
     if (!video || !recon || !mask || !mse || !mae || B <= 0 || T <= 0 || P <= 0 || video_div <= 0) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if ((e = hipMemsetAsync(mse, 0, sizeof(float) * B, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(mae, 0, sizeof(float) * B, s)) != hipSuccess) return (int)e;
+    if ((e = vvae_zero_async(mse, sizeof(float) * B, s)) != hipSuccess) return (int)e;
+    if ((e = vvae_zero_async(mae, sizeof(float) * B, s)) != hipSuccess) return (int)e;
     const long M = (long)T * P;
     const int epb = pick_epb(M, B);
     dim3 grid(ceil_div(M, epb), B);

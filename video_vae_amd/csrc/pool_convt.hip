@@ -196,7 +196,7 @@ template <typename T>
 int launch_convt_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, CtDims d, hipStream_t s)
 {
     const long V = (long)d.NT * d.H * d.W;
-    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 4 * (size_t)d.Cin * d.Cout, s);
+    hipError_t e = vvae_zero_async(dw, sizeof(float) * 4 * (size_t)d.Cin * d.Cout, s);
     if (e != hipSuccess) return (int)e;
     const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
     long want = 2048 / (4L * ci_tiles); if (want < 1) want = 1;

@@ -93,6 +93,7 @@ class Optimizer:
         self.arrived = [0] * len(self.buckets)
         self.landed = [False] * len(self.buckets)
         self.reducer = None            # set by ddp.GradReducer
+        self.defer_reduce = False      # graph mode: do not launch collectives from the landing hooks (see graph.py)
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -120,8 +121,22 @@ class Optimizer:
         if dsts:
             torch._foreach_copy_(dsts, srcs)
         self.landed[b] = True
-        if self.reducer is not None:
+        if self.reducer is not None and not self.defer_reduce:
             self.reducer.launch(b)
+
+    @torch.no_grad()
+    def land_all(self, grads):
+        """Install gradients given in ``self.params`` order (None = zero), e.g. from torch.autograd.grad (graph capture)."""
+        dsts, srcs = [], []
+        for gv, gr in zip(self.gviews, grads):
+            if gr is None:
+                gv.zero_()
+            else:
+                dsts.append(gv)
+                srcs.append(gr)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+        self.landed = [True] * len(self.buckets)
 
     def zero_grad(self):
         for p in self.params:
@@ -149,6 +164,10 @@ class Optimizer:
                 self._land(b)                    # parameters that received no gradient this step contribute zeros
         gscale = 1.0
         if self.reducer is not None:
+            if self.defer_reduce:
+                self.reducer.reset()
+                for b in range(len(self.buckets)):
+                    self.reducer.launch(b)
             self.reducer.finish()
             gscale = 1.0 / self.reducer.world_size
         if not self.p.is_cuda:

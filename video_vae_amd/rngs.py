@@ -29,6 +29,7 @@ class Rngs:
         self.seed = int(seed)
         self.counts = {}
         self.overrides = {}
+        self.recording = None          # dict: name -> (kind, shape, dtype) of every draw (used by graph.GraphedTrainStep)
 
     def _key(self, stream):
         c = self.counts.get(stream, 0)
@@ -57,6 +58,8 @@ class Rngs:
         A key is consumed either way so the stream position matches the reference's call order.
         """
         key = self.sampling()
+        if self.recording is not None:
+            self.recording[name] = (kind, tuple(shape), dtype)
         if name in self.overrides:
             t = self.overrides[name]
             assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
