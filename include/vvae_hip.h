@@ -111,7 +111,7 @@ int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, 
  * inner = 1: sequences contiguous (A,T,C).  inner = hw: tensors are (b,t,hw,C), sequence a = b*hw+i strides over frames
  * (no transpose copies around the temporal half of FactoredAttention). */
 int vvae_temporal_attn_fast_supported(int T, int D, int ld, int ldo, int dtype);
-int vvae_temporal_attn_fast_blocks(int A, int T, int heads);
+int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D);
 int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, int ldo, float* lse, const float* q_scale,
                                 const float* k_scale, const float* cos_table, const float* sin_table, const uint8_t* mask,
                                 int mask_div, int inner, int A, int T, int heads, int D, float eps, int dtype, void* stream);

@@ -177,7 +177,7 @@ def _attn_ref(qkv, qs, ks, mask, heads, max_len, dtype):
 
 
 @pytest.mark.parametrize("a,t,heads,d", [(6, 16, 8, 64), (5, 5, 4, 32), (3, 32, 2, 64), (2, 64, 1, 64), (4, 7, 2, 16),
-                                         (9, 16, 4, 8), (3, 12, 2, 24)])
+                                         (9, 16, 4, 8), (3, 12, 2, 24), (2, 40, 2, 32), (3, 20, 3, 64)])
 @pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("generic", [False, True])

@@ -1,13 +1,15 @@
-// Temporal-attention core, "one lane = one frame" form: the production path for head_dim D in {8,16,32,64}.
+// Temporal-attention core, "LPR lanes = one frame" form: the production path for head_dim D in {8,16,32,64}.
 //
 // Same math and reference lines as attn_temporal.hip (train/layers.py:159-170), restructured for CDNA4:
-//   * a wavefront carries 64/T whole (sequence, head) items; lane (item, t) keeps the q / k / v ROW of frame t in
-//     registers (16-byte vector loads of the contiguous head slice), so LayerNorm and RoPE (whose rotate-half partner is
-//     in the same row) need no cross-lane traffic at all;
+//   * a wavefront carries 64/(T*LPR) whole (sequence, head) items; the LPR adjacent lanes of frame t keep the q / k / v ROW
+//     of that frame in registers, DL = D/LPR channels each (LPR = D/16 where the wave has room: 16 channels per lane keeps
+//     the backward pass near 100 VGPRs, 4-5 waves per SIMD, instead of 256 VGPRs and one wave at D = 64).  Lane p owns
+//     channels [p*HL, (p+1)*HL) and [D/2 + p*HL, D/2 + (p+1)*HL), HL = DL/2, so the RoPE rotate-half partner of every
+//     channel sits in the SAME lane; LayerNorm sums and q.k dots finish with one or two quad-DPP adds;
 //   * keys and values go to LDS once (storage dtype); every lane then walks the T keys with broadcast ds_read_b128 and
 //     an online softmax -- q, k, v are read from HBM once and o written once;
 //   * forward also emits the row log-sum-exp; backward uses it plus delta = dO.O (no second softmax pass), computes
-//     dS/P row-wise (lane = query), parks them in LDS and accumulates dK/dV column-wise (lane = key);
+//     dS/P row-wise (lanes = query), parks them in LDS and accumulates dK/dV column-wise (lanes = key);
 //   * q/k-norm scale gradients are written as per-workgroup partials (summed by the caller): deterministic.
 #include "common.hpp"
 
@@ -26,127 +28,173 @@ template <typename T_> struct Vw;                                // elements per
 template <> struct Vw<float> { static constexpr int n = 4; };
 template <> struct Vw<bf16_t> { static constexpr int n = 8; };
 
-template <typename T_, int D>
-__device__ __forceinline__ void load_row(const T_* __restrict__ p, float (&r)[D]) {
-    constexpr int V = Vw<T_>::n;
-#pragma unroll
-    for (int c = 0; c < D / V; ++c) {
-        float t[V];
-        VecIO<T_, V>::load(p + c * V, t);
-#pragma unroll
-        for (int e = 0; e < V; ++e) r[c * V + e] = t[e];
-    }
+// Geometry of one lane's slice of a D-channel row.
+template <typename T_, int D, int LPR> struct Slice {
+    static constexpr int DL = D / LPR;                            // channels per lane
+    static constexpr int HL = DL / 2;                             // ... per half (lo / hi)
+    static constexpr int H = D / 2;
+    static constexpr int V = Vw<T_>::n < HL ? Vw<T_>::n : HL;     // vector width of the global / LDS accesses
+    static_assert(HL % V == 0 && HL >= 4, "slice halves must be whole vectors");
+    // channel of register r for lane p
+    static __device__ __forceinline__ int ch(int r, int p) { return r < HL ? p * HL + r : H + p * HL + (r - HL); }
+    static __device__ __forceinline__ int lo(int p) { return p * HL; }
+    static __device__ __forceinline__ int hi(int p) { return H + p * HL; }
+};
+
+// sum over the LPR lanes of a frame (adjacent lanes: quad_perm DPP, no LDS traffic)
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
 }
-template <typename T_, int D>
-__device__ __forceinline__ void store_row(T_* __restrict__ p, const float (&r)[D]) {
-    constexpr int V = Vw<T_>::n;
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+}
+template <int LPR> __device__ __forceinline__ float lpr_sum(float v) {
+    static_assert(LPR == 1 || LPR == 2 || LPR == 4, "frames are split over at most a lane quad");
+    if (LPR >= 2) v += dpp_xor1(v);
+    if (LPR >= 4) v += dpp_xor2(v);
+    return v;
+}
+// sum over the lanes that hold the SAME channels (every LPR-th lane of the wave)
+template <int LPR> __device__ __forceinline__ float frames_sum(float v) {
 #pragma unroll
-    for (int c = 0; c < D / V; ++c) {
-        float t[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) t[e] = r[c * V + e];
-        VecIO<T_, V>::store(p + c * V, t);
-    }
+    for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
-// y = round(xhat * scale); optionally returns xhat and rstd (for backward).
-template <typename T_, int D, bool KEEP>
-__device__ __forceinline__ void ln_row(float (&x)[D], const float* __restrict__ scale, float eps, float (&xhat)[KEEP ? D : 1], float& rstd) {
-    float s = 0.f, ss = 0.f;
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void load_row(const T_* __restrict__ row, int p, float (&r)[D / LPR]) {
+    using S = Slice<T_, D, LPR>;
 #pragma unroll
-    for (int i = 0; i < D; ++i) { s += x[i]; ss += x[i] * x[i]; }
-    const float mean = s / D;
-    float var = ss / D - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    rstd = rsqrtf(var + eps);
+    for (int half = 0; half < 2; ++half) {
+        const T_* src = row + (half ? S::hi(p) : S::lo(p));
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float xh = (x[i] - mean) * rstd;
-        if (KEEP) xhat[i] = xh;
-        x[i] = round_to<T_>(xh * scale[i]);
+        for (int c = 0; c < S::HL / S::V; ++c) {
+            float t[S::V];
+            VecIO<T_, S::V>::load(src + c * S::V, t);
+#pragma unroll
+            for (int e = 0; e < S::V; ++e) r[half * S::HL + c * S::V + e] = t[e];
+        }
     }
 }
-
-template <typename T_, int D>
-__device__ __forceinline__ void rope_row(float (&x)[D], const float* __restrict__ cosr, const float* __restrict__ sinr) {
-    constexpr int H = D / 2;
-    float y[D];
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void store_row(T_* __restrict__ row, int p, const float (&r)[D / LPR]) {
+    using S = Slice<T_, D, LPR>;
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float rx = i < H ? -x[i + H] : x[i - H];
-        const float c = round_to<T_>(cosr[i]), s = round_to<T_>(sinr[i]);
-        y[i] = round_to<T_>(round_to<T_>(x[i] * c) + round_to<T_>(rx * s));
+    for (int half = 0; half < 2; ++half) {
+        T_* dst = row + (half ? S::hi(p) : S::lo(p));
+#pragma unroll
+        for (int c = 0; c < S::HL / S::V; ++c) {
+            float t[S::V];
+#pragma unroll
+            for (int e = 0; e < S::V; ++e) t[e] = r[half * S::HL + c * S::V + e];
+            VecIO<T_, S::V>::store(dst + c * S::V, t);
+        }
     }
-#pragma unroll
-    for (int i = 0; i < D; ++i) x[i] = y[i];
 }
-
-// dy (w.r.t. the RoPE output) -> dx (w.r.t. the raw q/k row), through RoPE and the bias-free LayerNorm.
-// dsc[i] receives dy_ln[i] * xhat[i] (this row's contribution to the scale gradient).
-// In place, register-lean: g: dy_rot -> dx;  xh: xhat -> this row's scale-gradient contribution dy_ln * xhat.
-template <typename T_, int D>
-__device__ __forceinline__ void rope_ln_bwd_row(float (&g)[D], float (&xh)[D], float rstd, const float* __restrict__ scale,
-                                                const float* __restrict__ cosr, const float* __restrict__ sinr) {
-    constexpr int H = D / 2;
+// fp32 table slice (scale / cos / sin rows), same channel mapping
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void load_tab(const float* __restrict__ row, int p, float (&r)[D / LPR]) {
+    using S = Slice<T_, D, LPR>;
 #pragma unroll
-    for (int i = 0; i < H; ++i) {                       // RoPE transpose on the (i, i+H) pair
-        const float lo = g[i], hi = g[i + H];
-        g[i] = lo * round_to<T_>(cosr[i]) + hi * round_to<T_>(sinr[i + H]);
-        g[i + H] = hi * round_to<T_>(cosr[i + H]) - lo * round_to<T_>(sinr[i]);
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float dxh = g[i] * scale[i];
-        s1 += dxh; s2 += dxh * xh[i];
-    }
-    s1 /= D; s2 /= D;
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float dy = g[i], x = xh[i];
-        g[i] = rstd * (dy * scale[i] - s1 - x * s2);
-        xh[i] = dy * x;
-    }
+    for (int i = 0; i < S::DL; ++i) r[i] = row[S::ch(i, p)];
 }
 
 // x -> xhat in place; returns rstd.
-template <int D>
-__device__ __forceinline__ float xhat_row(float (&x)[D], float eps) {
+template <int DL, int LPR, int D>
+__device__ __forceinline__ float xhat_row(float (&x)[DL], float eps) {
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < D; ++i) { s += x[i]; ss += x[i] * x[i]; }
+    for (int i = 0; i < DL; ++i) { s += x[i]; ss += x[i] * x[i]; }
+    s = lpr_sum<LPR>(s); ss = lpr_sum<LPR>(ss);
     const float mean = s / D;
     float var = ss / D - mean * mean;
     var = var < 0.f ? 0.f : var;
     const float rstd = rsqrtf(var + eps);
 #pragma unroll
-    for (int i = 0; i < D; ++i) x[i] = (x[i] - mean) * rstd;
+    for (int i = 0; i < DL; ++i) x[i] = (x[i] - mean) * rstd;
     return rstd;
 }
 
-// dot(reg row, LDS row) and axpy(reg row += a * LDS row), LDS row in the storage dtype, 16-byte broadcast reads.
-template <typename T_, int D>
-__device__ __forceinline__ float dot_lds(const float (&r)[D], const T_* row) {
-    constexpr int V = Vw<T_>::n;
+// q/k-norm (bias-free LayerNorm, y = round(xhat * scale)) followed by RoPE, in place on the lane's slice.
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void ln_rope_row(float (&x)[D / LPR], int p, const float* __restrict__ scale, float eps,
+                                            const float* __restrict__ cosr, const float* __restrict__ sinr) {
+    using S = Slice<T_, D, LPR>;
+    xhat_row<S::DL, LPR, D>(x, eps);
+#pragma unroll
+    for (int i = 0; i < S::DL; ++i) x[i] = round_to<T_>(x[i] * scale[S::ch(i, p)]);
+#pragma unroll
+    for (int i = 0; i < S::HL; ++i) {                    // rotate-half pair (i, i + HL) = channels (c, c + D/2)
+        const float lo = x[i], hi = x[i + S::HL];
+        const int cl = S::ch(i, p), chh = S::ch(i + S::HL, p);
+        x[i] = round_to<T_>(round_to<T_>(lo * round_to<T_>(cosr[cl])) + round_to<T_>(-hi * round_to<T_>(sinr[cl])));
+        x[i + S::HL] = round_to<T_>(round_to<T_>(hi * round_to<T_>(cosr[chh])) + round_to<T_>(lo * round_to<T_>(sinr[chh])));
+    }
+}
+
+// dy (w.r.t. the RoPE output) -> dx (w.r.t. the raw q/k row), through RoPE and the bias-free LayerNorm.
+// In place, register-lean: g: dy_rot -> dx;  xh: xhat -> this row's scale-gradient contribution dy_ln * xhat.
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void rope_ln_bwd_row(float (&g)[D / LPR], float (&xh)[D / LPR], int p, float rstd,
+                                                const float* __restrict__ scale, const float* __restrict__ cosr,
+                                                const float* __restrict__ sinr) {
+    using S = Slice<T_, D, LPR>;
+#pragma unroll
+    for (int i = 0; i < S::HL; ++i) {                    // RoPE transpose on the (i, i+HL) pair
+        const float lo = g[i], hi = g[i + S::HL];
+        const int cl = S::ch(i, p), chh = S::ch(i + S::HL, p);
+        g[i] = lo * round_to<T_>(cosr[cl]) + hi * round_to<T_>(sinr[chh]);
+        g[i + S::HL] = hi * round_to<T_>(cosr[chh]) - lo * round_to<T_>(sinr[cl]);
+    }
+    float sc[S::DL];
+    load_tab<T_, D, LPR>(scale, p, sc);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < S::DL; ++i) {
+        const float dxh = g[i] * sc[i];
+        s1 += dxh; s2 += dxh * xh[i];
+    }
+    s1 = lpr_sum<LPR>(s1) / D; s2 = lpr_sum<LPR>(s2) / D;
+#pragma unroll
+    for (int i = 0; i < S::DL; ++i) {
+        const float dy = g[i], x = xh[i];
+        g[i] = rstd * (dy * sc[i] - s1 - x * s2);
+        xh[i] = dy * x;
+    }
+}
+
+// partial dot(reg slice, LDS row slice) and axpy(reg slice += a * LDS row slice); LDS rows hold all D channels in the
+// storage dtype, read with 16-byte broadcast loads.
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ float dot_lds(const float (&r)[D / LPR], const T_* row, int p) {
+    using S = Slice<T_, D, LPR>;
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < D / V; ++c) {
-        float t[V];
-        VecIO<T_, V>::load(row + c * V, t);
+    for (int half = 0; half < 2; ++half) {
+        const T_* src = row + (half ? S::hi(p) : S::lo(p));
 #pragma unroll
-        for (int e = 0; e < V; ++e) s += r[c * V + e] * t[e];
+        for (int c = 0; c < S::HL / S::V; ++c) {
+            float t[S::V];
+            VecIO<T_, S::V>::load(src + c * S::V, t);
+#pragma unroll
+            for (int e = 0; e < S::V; ++e) s += r[half * S::HL + c * S::V + e] * t[e];
+        }
     }
     return s;
 }
-template <typename T_, int D>
-__device__ __forceinline__ void axpy_lds(float (&r)[D], float a, const T_* row) {
-    constexpr int V = Vw<T_>::n;
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void axpy_lds(float (&r)[D / LPR], float a, const T_* row, int p) {
+    using S = Slice<T_, D, LPR>;
 #pragma unroll
-    for (int c = 0; c < D / V; ++c) {
-        float t[V];
-        VecIO<T_, V>::load(row + c * V, t);
+    for (int half = 0; half < 2; ++half) {
+        const T_* src = row + (half ? S::hi(p) : S::lo(p));
 #pragma unroll
-        for (int e = 0; e < V; ++e) r[c * V + e] += a * t[e];
+        for (int c = 0; c < S::HL / S::V; ++c) {
+            float t[S::V];
+            VecIO<T_, S::V>::load(src + c * S::V, t);
+#pragma unroll
+            for (int e = 0; e < S::V; ++e) r[half * S::HL + c * S::V + e] += a * t[e];
+        }
     }
 }
 
@@ -155,16 +203,18 @@ constexpr int kItemPad = 16;     // bytes between items in an LDS array: two ite
 template <typename T_, int D>
 __host__ __device__ inline int item_stride_bytes(int T) { return T * D * (int)sizeof(T_) + kItemPad; }
 
-template <typename T_, int D>
+template <typename T_, int D, int LPR>
 __global__ __launch_bounds__(64) void tattn_fwd_fast(const T_* __restrict__ qkv, int ld, T_* __restrict__ out, int ldo, float* __restrict__ lse,
                                                      const float* __restrict__ q_scale, const float* __restrict__ k_scale,
                                                      const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                      const uint8_t* __restrict__ mask, FAttnDims d)
 {
+    constexpr int DL = D / LPR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = d.T, lane = threadIdx.x;
-    const int ipw = 64 / T;
-    const int item = lane / T, row = lane - item * T;
+    const int p = lane % LPR, fr = lane / LPR;
+    const int ipw = 64 / (T * LPR);
+    const int item = fr / T, row = fr - item * T;
     const long gi = (long)blockIdx.x * ipw + item;
     const bool valid = item < ipw && gi < d.items;
     const long gic = valid ? gi : 0;
@@ -175,22 +225,19 @@ __global__ __launch_bounds__(64) void tattn_fwd_fast(const T_* __restrict__ qkv,
     T_* Ks = reinterpret_cast<T_*>(smem + (valid ? item : 0) * istride);
     T_* Vs = reinterpret_cast<T_*>(smem + ipw * istride + (valid ? item : 0) * istride);
 
-    float q[D], kv[D];
+    float q[DL], kv[DL];
     const T_* g = qkv + tok * ld + h * D;
-    float dummy[1], rs;
     if (valid) {
-        load_row<T_, D>(g + HD, kv);
-        ln_row<T_, D, false>(kv, k_scale, d.eps, dummy, rs);
-        rope_row<T_, D>(kv, cosT + row * D, sinT + row * D);
-        store_row<T_, D>(Ks + row * D, kv);
-        load_row<T_, D>(g + 2 * HD, kv);
-        store_row<T_, D>(Vs + row * D, kv);
-        load_row<T_, D>(g, q);
-        ln_row<T_, D, false>(q, q_scale, d.eps, dummy, rs);
-        rope_row<T_, D>(q, cosT + row * D, sinT + row * D);
+        load_row<T_, D, LPR>(g + HD, p, kv);
+        ln_rope_row<T_, D, LPR>(kv, p, k_scale, d.eps, cosT + row * D, sinT + row * D);
+        store_row<T_, D, LPR>(Ks + row * D, p, kv);
+        load_row<T_, D, LPR>(g + 2 * HD, p, kv);
+        store_row<T_, D, LPR>(Vs + row * D, p, kv);
+        load_row<T_, D, LPR>(g, p, q);
+        ln_rope_row<T_, D, LPR>(q, p, q_scale, d.eps, cosT + row * D, sinT + row * D);
     } else {
 #pragma unroll
-        for (int i = 0; i < D; ++i) q[i] = 0.f;
+        for (int i = 0; i < DL; ++i) q[i] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
@@ -198,31 +245,31 @@ __global__ __launch_bounds__(64) void tattn_fwd_fast(const T_* __restrict__ qkv,
 
     const uint8_t* mrow = mask ? mask + (long)(a / d.mask_div) * T : nullptr;
     const float scale = rsqrtf((float)D);
-    float o[D];
+    float o[DL];
 #pragma unroll
-    for (int i = 0; i < D; ++i) o[i] = 0.f;
+    for (int i = 0; i < DL; ++i) o[i] = 0.f;
     float m = -3.0e38f, l = 0.f;
     for (int j = 0; j < T; ++j) {
-        if (mrow && !mrow[j]) continue;
-        const float s = dot_lds<T_, D>(q, Ks + j * D) * scale;
+        if (mrow && !mrow[j]) continue;           // per item, hence uniform over the lanes of a frame
+        const float s = lpr_sum<LPR>(dot_lds<T_, D, LPR>(q, Ks + j * D, p)) * scale;
         const float mn = fmaxf(m, s);
-        const float alpha = __expf(m - mn), p = __expf(s - mn);
-        l = l * alpha + p;
+        const float alpha = __expf(m - mn), pr = __expf(s - mn);
+        l = l * alpha + pr;
 #pragma unroll
-        for (int i = 0; i < D; ++i) o[i] *= alpha;
-        axpy_lds<T_, D>(o, p, Vs + j * D);
+        for (int i = 0; i < DL; ++i) o[i] *= alpha;
+        axpy_lds<T_, D, LPR>(o, pr, Vs + j * D, p);
         m = mn;
     }
     if (valid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
-        for (int i = 0; i < D; ++i) o[i] *= inv;
-        store_row<T_, D>(out + tok * ldo + h * D, o);
-        lse[gi * T + row] = l > 0.f ? m + __logf(l) : 0.f;
+        for (int i = 0; i < DL; ++i) o[i] *= inv;
+        store_row<T_, D, LPR>(out + tok * ldo + h * D, p, o);
+        if (p == 0) lse[gi * T + row] = l > 0.f ? m + __logf(l) : 0.f;
     }
 }
 
-template <typename T_, int D>
+template <typename T_, int D, int LPR>
 __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv, int ld, const T_* __restrict__ out, int ldo,
                                                      const T_* __restrict__ dout, int lddo, const float* __restrict__ lse,
                                                      T_* __restrict__ dqkv, int lddq, const float* __restrict__ q_scale,
@@ -230,10 +277,13 @@ __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv,
                                                      const float* __restrict__ sinT, const uint8_t* __restrict__ mask,
                                                      float* __restrict__ dscale_part, FAttnDims d)
 {
+    using S = Slice<T_, D, LPR>;
+    constexpr int DL = D / LPR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = d.T, lane = threadIdx.x;
-    const int ipw = 64 / T;
-    const int item = lane / T, row = lane - item * T;
+    const int p = lane % LPR, fr = lane / LPR;
+    const int ipw = 64 / (T * LPR);
+    const int item = fr / T, row = fr - item * T;
     const long gi = (long)blockIdx.x * ipw + item;
     const bool valid = item < ipw && gi < d.items;
     const long gic = valid ? gi : 0;
@@ -252,106 +302,115 @@ __global__ __launch_bounds__(64) void tattn_bwd_fast(const T_* __restrict__ qkv,
     const T_* g = qkv + tok * ld + h * D;
     const float* cosr = cosT + row * D;
     const float* sinr = sinT + row * D;
-    float q[D], go[D], t0[D];
-    float dummy[1], rs;
+    float q[DL], go[DL], t0[DL];
+    float rs;
     float delta = 0.f;
     if (valid) {
-        load_row<T_, D>(g + HD, t0);
-        ln_row<T_, D, false>(t0, k_scale, d.eps, dummy, rs);
-        rope_row<T_, D>(t0, cosr, sinr);
-        store_row<T_, D>(Ks + row * D, t0);
-        load_row<T_, D>(g + 2 * HD, t0);
-        store_row<T_, D>(Vs + row * D, t0);
-        load_row<T_, D>(g, q);
-        ln_row<T_, D, false>(q, q_scale, d.eps, dummy, rs);
-        rope_row<T_, D>(q, cosr, sinr);
-        store_row<T_, D>(Qs + row * D, q);
-        load_row<T_, D>(dout + tok * lddo + h * D, go);
-        store_row<T_, D>(Gs + row * D, go);
-        load_row<T_, D>(out + tok * ldo + h * D, t0);
+        load_row<T_, D, LPR>(g + HD, p, t0);
+        ln_rope_row<T_, D, LPR>(t0, p, k_scale, d.eps, cosr, sinr);
+        store_row<T_, D, LPR>(Ks + row * D, p, t0);
+        load_row<T_, D, LPR>(g + 2 * HD, p, t0);
+        store_row<T_, D, LPR>(Vs + row * D, p, t0);
+        load_row<T_, D, LPR>(g, p, q);
+        ln_rope_row<T_, D, LPR>(q, p, q_scale, d.eps, cosr, sinr);
+        store_row<T_, D, LPR>(Qs + row * D, p, q);
+        load_row<T_, D, LPR>(dout + tok * lddo + h * D, p, go);
+        store_row<T_, D, LPR>(Gs + row * D, p, go);
+        load_row<T_, D, LPR>(out + tok * ldo + h * D, p, t0);
 #pragma unroll
-        for (int i = 0; i < D; ++i) delta += go[i] * t0[i];
+        for (int i = 0; i < DL; ++i) delta += go[i] * t0[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < D; ++i) { q[i] = 0.f; go[i] = 0.f; }
+        for (int i = 0; i < DL; ++i) { q[i] = 0.f; go[i] = 0.f; }
     }
+    delta = lpr_sum<LPR>(delta);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
-    // ---- phase A: lane = query row.  dq_rot, and P / dS rows into LDS ----
+    // ---- phase A: lanes = query row.  dq_rot, and P / dS rows into LDS ----
     const uint8_t* mrow = mask ? mask + (long)(a / d.mask_div) * T : nullptr;
     const float scale = rsqrtf((float)D);
     const float lse_i = valid ? lse[gi * T + row] : 0.f;
-    float dq[D];
+    float dq[DL];
 #pragma unroll
-    for (int i = 0; i < D; ++i) dq[i] = 0.f;
+    for (int i = 0; i < DL; ++i) dq[i] = 0.f;
     for (int j = 0; j < T; ++j) {
-        float p = 0.f, ds = 0.f;
-        if (valid && !(mrow && !mrow[j])) {
-            const float s = dot_lds<T_, D>(q, Ks + j * D) * scale;
-            p = __expf(s - lse_i);
-            const float dp = dot_lds<T_, D>(go, Vs + j * D);
-            ds = p * (dp - delta) * scale;
-            axpy_lds<T_, D>(dq, ds, Ks + j * D);
+        float pr = 0.f, ds = 0.f;
+        if (valid && !(mrow && !mrow[j])) {          // per item: uniform over the lanes of a frame
+            const float s = lpr_sum<LPR>(dot_lds<T_, D, LPR>(q, Ks + j * D, p)) * scale;
+            pr = __expf(s - lse_i);
+            const float dp = lpr_sum<LPR>(dot_lds<T_, D, LPR>(go, Vs + j * D, p));
+            ds = pr * (dp - delta) * scale;
+            axpy_lds<T_, D, LPR>(dq, ds, Ks + j * D, p);
         }
-        if (valid) {
-            Ps[row * (T + 1) + j] = round_to<T_>(p);   // the reference multiplies V by probabilities cast to the value dtype
+        if (valid && p == 0) {
+            Ps[row * (T + 1) + j] = round_to<T_>(pr);  // the reference multiplies V by probabilities cast to the value dtype
             Ss[row * (T + 1) + j] = ds;
         }
     }
     if (valid) {                                        // dq through RoPE and q_norm (recompute xhat from the raw row)
-        load_row<T_, D>(g, t0);
-        rs = xhat_row<D>(t0, d.eps);
-        rope_ln_bwd_row<T_, D>(dq, t0, rs, q_scale, cosr, sinr);
-        store_row<T_, D>(dqkv + tok * lddq + h * D, dq);
+        load_row<T_, D, LPR>(g, p, t0);
+        rs = xhat_row<DL, LPR, D>(t0, d.eps);
+        rope_ln_bwd_row<T_, D, LPR>(dq, t0, p, rs, q_scale, cosr, sinr);
+        store_row<T_, D, LPR>(dqkv + tok * lddq + h * D, p, dq);
     } else {
 #pragma unroll
-        for (int i = 0; i < D; ++i) t0[i] = 0.f;
+        for (int i = 0; i < DL; ++i) t0[i] = 0.f;
     }
     float* part = dscale_part + (long)blockIdx.x * 2 * D;
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float tot = wave_sum(t0[i]);
-        if (lane == (i & 63)) part[i] = tot;
+    for (int i = 0; i < DL; ++i) {
+        const float tot = frames_sum<LPR>(t0[i]);
+        if (lane < LPR) part[S::ch(i, p)] = tot;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
-    // ---- phase B: lane = key row.  dk_rot = sum_i dS[i][j] q_i ; dv = sum_i P[i][j] dO_i ----
-    float dk[D], dv[D];
+    // ---- phase B: lanes = key row.  dk_rot = sum_i dS[i][j] q_i ; dv = sum_i P[i][j] dO_i ----
+    float dk[DL], dv[DL];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+    for (int i = 0; i < DL; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
     if (valid) {
         for (int i = 0; i < T; ++i) {
             const float pij = Ps[i * (T + 1) + row], dsij = Ss[i * (T + 1) + row];
-            axpy_lds<T_, D>(dk, dsij, Qs + i * D);
-            axpy_lds<T_, D>(dv, pij, Gs + i * D);
+            axpy_lds<T_, D, LPR>(dk, dsij, Qs + i * D, p);
+            axpy_lds<T_, D, LPR>(dv, pij, Gs + i * D, p);
         }
-        store_row<T_, D>(dqkv + tok * lddq + 2 * HD + h * D, dv);
-        load_row<T_, D>(g + HD, t0);
-        rs = xhat_row<D>(t0, d.eps);
-        rope_ln_bwd_row<T_, D>(dk, t0, rs, k_scale, cosr, sinr);
-        store_row<T_, D>(dqkv + tok * lddq + HD + h * D, dk);
+        store_row<T_, D, LPR>(dqkv + tok * lddq + 2 * HD + h * D, p, dv);
+        load_row<T_, D, LPR>(g + HD, p, t0);
+        rs = xhat_row<DL, LPR, D>(t0, d.eps);
+        rope_ln_bwd_row<T_, D, LPR>(dk, t0, p, rs, k_scale, cosr, sinr);
+        store_row<T_, D, LPR>(dqkv + tok * lddq + HD + h * D, p, dk);
     } else {
 #pragma unroll
-        for (int i = 0; i < D; ++i) t0[i] = 0.f;
+        for (int i = 0; i < DL; ++i) t0[i] = 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float tot = wave_sum(t0[i]);
-        if (lane == (i & 63)) part[D + i] = tot;
+    for (int i = 0; i < DL; ++i) {
+        const float tot = frames_sum<LPR>(t0[i]);
+        if (lane < LPR) part[D + S::ch(i, p)] = tot;
     }
 }
 
-template <typename T_, int D>
+// lanes per frame: 16 channels per lane where the wave has room for a whole sequence.
+int pick_lpr(int T, int D)
+{
+    int lpr = D / 16;
+    if (lpr < 1) lpr = 1;
+    if (lpr > 4) lpr = 4;
+    while (lpr > 1 && T * lpr > 64) lpr /= 2;
+    return lpr;
+}
+
+template <typename T_, int D, int LPR>
 int launch_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const float* qs, const float* ks, const float* cosT,
                const float* sinT, const uint8_t* mask, FAttnDims d, hipStream_t s)
 {
-    const int ipw = 64 / d.T;
+    const int ipw = 64 / (d.T * LPR);
     const size_t lds = (size_t)2 * ipw * item_stride_bytes<T_, D>(d.T);
-    auto k = tattn_fwd_fast<T_, D>;
+    auto k = tattn_fwd_fast<T_, D, LPR>;
     static size_t attr_lds = 65536;                // grow-only: the attribute is set once per (kernel, larger size)
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -363,15 +422,15 @@ int launch_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const fl
     return 0;
 }
 
-template <typename T_, int D>
+template <typename T_, int D, int LPR>
 int launch_bwd(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse, void* dqkv, int lddq,
                const float* qs, const float* ks, const float* cosT, const float* sinT, const uint8_t* mask, float* part, FAttnDims d,
                hipStream_t s)
 {
-    const int ipw = 64 / d.T;
+    const int ipw = 64 / (d.T * LPR);
     const size_t lds = (size_t)4 * ipw * item_stride_bytes<T_, D>(d.T) + (size_t)2 * ipw * d.T * (d.T + 1) * sizeof(float);
     if (lds > 160 * 1024) return VVAE_ERR_BAD_ARG;
-    auto k = tattn_bwd_fast<T_, D>;
+    auto k = tattn_bwd_fast<T_, D, LPR>;
     static size_t attr_lds = 65536;                // grow-only: the attribute is set once per (kernel, larger size)
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -393,22 +452,33 @@ bool fast_ok(int T, int D, int ld, int ldo, int dtype)
 
 }  // namespace
 
-#define FATTN_DISPATCH(FN, ...)                                                                                   \
-    do {                                                                                                           \
-        if (dtype == VVAE_DT_F32) {                                                                                \
-            switch (D) { case 8: return FN<float, 8>(__VA_ARGS__); case 16: return FN<float, 16>(__VA_ARGS__);     \
-                         case 32: return FN<float, 32>(__VA_ARGS__); default: return FN<float, 64>(__VA_ARGS__); } \
-        } else {                                                                                                   \
-            switch (D) { case 8: return FN<bf16_t, 8>(__VA_ARGS__); case 16: return FN<bf16_t, 16>(__VA_ARGS__);   \
-                         case 32: return FN<bf16_t, 32>(__VA_ARGS__); default: return FN<bf16_t, 64>(__VA_ARGS__); } \
-        }                                                                                                          \
+#define FATTN_DISPATCH_T(FN, TT, ...)                                                  \
+    switch (D * 8 + lpr) {                                                              \
+        case 8 * 8 + 1: return FN<TT, 8, 1>(__VA_ARGS__);                               \
+        case 16 * 8 + 1: return FN<TT, 16, 1>(__VA_ARGS__);                             \
+        case 32 * 8 + 1: return FN<TT, 32, 1>(__VA_ARGS__);                             \
+        case 32 * 8 + 2: return FN<TT, 32, 2>(__VA_ARGS__);                             \
+        case 64 * 8 + 1: return FN<TT, 64, 1>(__VA_ARGS__);                             \
+        case 64 * 8 + 2: return FN<TT, 64, 2>(__VA_ARGS__);                             \
+        case 64 * 8 + 4: return FN<TT, 64, 4>(__VA_ARGS__);                             \
+        default: return VVAE_ERR_BAD_ARG;                                               \
+    }
+#define FATTN_DISPATCH(FN, ...)                                                         \
+    do {                                                                                \
+        const int lpr = pick_lpr(T, D);                                                 \
+        if (dtype == VVAE_DT_F32) { FATTN_DISPATCH_T(FN, float, __VA_ARGS__) }          \
+        else { FATTN_DISPATCH_T(FN, bf16_t, __VA_ARGS__) }                              \
     } while (0)
 
 // 1 if the lane-per-frame kernels take this shape (else callers use the generic vvae_temporal_attn_fwd/_bwd).
 extern "C" int vvae_temporal_attn_fast_supported(int T, int D, int ld, int ldo, int dtype) { return fast_ok(T, D, ld, ldo, dtype) ? 1 : 0; }
 
 // Workgroups (= rows of the dscale partial buffer, each 2*D floats: [dq_scale | dk_scale]) for this shape.
-extern "C" int vvae_temporal_attn_fast_blocks(int A, int T, int heads) { return ceil_div((long)A * heads, 64 / T); }
+extern "C" int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D)
+{
+    if (T < 1 || T > 64 || D < 1) return 0;
+    return ceil_div((long)A * heads, 64 / (T * pick_lpr(T, D)));
+}
 
 // lse: fp32 (A*heads, T) written.  Other arguments as vvae_temporal_attn_fwd.
 extern "C" int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, int ldo, float* lse, const float* q_scale,

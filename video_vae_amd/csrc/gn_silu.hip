@@ -96,15 +96,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
 }
 
-// out[n][j][2] (fp64) = sum over nblk workgroup partials part[n][blk][j][2] (fp32), fixed order.  grid = N, J = G or C.
+// out[n][j][2] (fp64) = sum over nblk workgroup partials part[n][blk][j][2] (fp32), fixed order.  J = G or C.
+// grid (ceil(2J/32), N); 256 threads = 32 outputs x 8 partial lanes (lane-strided sums, then a fixed tree).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, double* __restrict__ out, int nblk, int J)
 {
-    const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < 2 * J; i += 256) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)part[((long)n * nblk + b) * 2 * J + i];
-        out[(long)n * 2 * J + i] = s;
-    }
+    __shared__ double red[8][32];
+    const int n = blockIdx.y;
+    const int el = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + el;
+    double s = 0.0;
+    if (i < 2 * J)
+        for (int b = bl; b < nblk; b += 8) s += (double)part[((long)n * nblk + b) * 2 * J + i];
+    red[bl][el] = s;
+    __syncthreads();
+    if (bl == 0 && i < 2 * J)
+        out[(long)n * 2 * J + i] = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
 
 // per-block prologue: a_c = rstd_g*gamma_c, b_c = beta_c - mean_g*a_c for sample n
@@ -355,7 +361,7 @@ extern "C" int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G
     if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
     GN_DISPATCH(gn_stats_kernel, vok, (const T*)x, ldx, d, part, vpb);
     VVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, sums, (int)grid.x, G);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(2 * G, 32), N), dim3(256), 0, s, part, sums, (int)grid.x, G);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -397,7 +403,7 @@ extern "C" int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy
         dim3 grid(ceil_div(S, vpb_r), N);
         GN_DISPATCH(gn_silu_bwd_reduce_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, sums, gamma, beta, d, part, vpb_r);
         VVAE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, csum, (int)grid.x, C);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(2 * C, 32), N), dim3(256), 0, s, part, csum, (int)grid.x, C);
         VVAE_LAUNCH_CHECK();
     }
     GN_DISPATCH(gn_silu_bwd_apply_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, sums, csum, gamma, beta, d, vpb);

@@ -31,6 +31,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
     constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;          // rows per wave-iteration
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, ll = lane % LPR;
+    // this lane's columns never change: keep gamma / beta in registers for all the rows the wave walks (re-loading them per
+    // row moved 5x more bytes through L1 than the row itself)
+    float gm[VPL][V], bt[VPL][V];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int c = (k * LPR + ll) * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            gm[k][e] = c < d.C ? gamma[c + e] : 0.f;
+            bt[k][e] = (beta && c < d.C) ? beta[c + e] : 0.f;
+        }
+    }
     const long rstride = (long)gridDim.x * 4 * RPW;
     for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
@@ -60,10 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
             if (rv && c < d.C) {
                 float o[V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    o[e] = (v[k][e] - mean) * (rstd * gamma[c + e]);
-                    if (beta) o[e] += beta[c + e];
-                }
+                for (int e = 0; e < V; ++e) o[e] = (v[k][e] - mean) * (rstd * gm[k][e]) + bt[k][e];
                 VecIO<T_, V>::store(yr + c, o);
             }
         }
@@ -80,11 +89,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
     __shared__ float red[4][64][VPL * V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, ll = lane % LPR;
-    float ag[VPL][V], ab[VPL][V];
+    float ag[VPL][V], ab[VPL][V], gm[VPL][V];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k)
+    for (int k = 0; k < VPL; ++k) {
+        const int c = (k * LPR + ll) * V;
 #pragma unroll
-        for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+        for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gm[k][e] = c < d.C ? gamma[c + e] : 0.f; }
+    }
     const long rstride = (long)gridDim.x * 4 * RPW;
     for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
                     xh[k][e] = (xh[k][e] - mean) * rstd;
                     ag[k][e] += g[k][e] * xh[k][e];
                     ab[k][e] += g[k][e];
-                    g[k][e] *= gamma[c + e];
+                    g[k][e] *= gm[k][e];
                     s1 += g[k][e]; s2 += g[k][e] * xh[k][e];
                 }
             }
@@ -217,11 +228,11 @@ extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, co
     int lpr, vpl;
     if (dtype == VVAE_DT_F32) {
         if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
-        dim3 grid(ln_blocks(rows, lpr, 16384));
+        dim3 grid(ln_blocks(rows, lpr, 2048));
         LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, d);
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
-        dim3 grid(ln_blocks(rows, lpr, 16384));
+        dim3 grid(ln_blocks(rows, lpr, 2048));
         LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();

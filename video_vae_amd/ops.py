@@ -437,7 +437,7 @@ class _TemporalAttn(torch.autograd.Function):
         dt = _dt(qkv)
         dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
         if fast:
-            nblk = lib().vvae_temporal_attn_fast_blocks(a, t, heads)
+            nblk = lib().vvae_temporal_attn_fast_blocks(a, t, heads, d)
             part = torch.empty((nblk, 2 * d), dtype=torch.float32, device=qkv.device)
             nbytes = a * t * heads * d * 8 * qkv.element_size()
             check(_launch(f"temporal_attn_bwd T{t} D{d}", nbytes, 10 * a * heads * t * t * d, "tattn_bwd_fast",
