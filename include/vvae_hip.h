@@ -120,6 +120,20 @@ int vvae_temporal_attn_bwd_fast(const void* qkv, int ld, const void* out, int ld
                                 const float* sin_table, const uint8_t* mask, int mask_div, int inner, float* dscale_part,
                                 int A, int T, int heads, int D, float eps, int dtype, void* stream);
 
+/* ---- q/k-norm + RoPE prep around a library attention core (spatial half of FactoredAttention, train/layers.py:153-170,217-221).
+ *      fwd: qkv (tokens, 3*heads*D) -> out (tokens, 2*heads*D) = [rope(q_norm(q)) | rope(k_norm(k))]; RoPE position = token % S.
+ *      bwd: (dq', dk', dv) with element strides (token, head) -> dqkv (tokens, 3*heads*D), all three sections, one launch;
+ *           scale-gradient partials part (vvae_qk_prep_blocks(...), 2, D) fp32: [dq_scale | dk_scale], summed by the caller. ---- */
+int vvae_qk_prep_supported(int D, int dtype);
+int vvae_qk_prep_blocks(long tokens, int heads, int D);
+int vvae_qk_prep_fwd(const void* qkv, int ld, void* out, int ldo, const float* q_scale, const float* k_scale,
+                     const float* cos_table, const float* sin_table, long tokens, int S, int heads, int D, float eps,
+                     int dtype, void* stream);
+int vvae_qk_prep_bwd(const void* qkv, int ld, const void* dq, long dq_ts, long dq_hs, const void* dk, long dk_ts, long dk_hs,
+                     const void* dv, long dv_ts, long dv_hs, void* dqkv, int lddq, const float* q_scale, const float* k_scale,
+                     const float* cos_table, const float* sin_table, float* part, long tokens, int S, int heads, int D,
+                     float eps, int dtype, void* stream);
+
 /* ---- LayerNorm(eps, fast variance, fp32 stats): nnx.LayerNorm at train/layers.py:17,152,155-156,178.
  *      x row r at x + (r / inner) * outer_pitch + (r % inner) * inner_pitch (elements); y, dy, dx contiguous (rows, C).
  *      bwd writes per-workgroup partials part (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy]. ---- */

@@ -213,6 +213,64 @@ def test_temporal_attention_core(dev, a, t, heads, d, masked, dtype, generic):
         assert_close_scaled(xg.grad, xo.grad, rel=5e-2, what="dqkv")
 
 
+@pytest.mark.parametrize("a,s,heads,d", [(3, 256, 8, 64), (2, 100, 4, 32), (2, 40, 3, 16), (1, 70, 2, 8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_qk_prep_kernels(dev, a, s, heads, d, dtype):
+    """q/k-norm + RoPE prep pass (fwd and bwd, v-gradient copy included) against the oracle's LayerNorm + RoPE."""
+    ops = _ops()
+    hd = heads * d
+    qkv = rnd((a, s, 3 * hd), 60).to(dtype).float()
+    qs = 1 + 0.2 * rnd((d,), 61); ks = 1 + 0.2 * rnd((d,), 62)
+    gq = rnd((a, heads, s, d), 63).to(dtype).float(); gk = rnd((a, heads, s, d), 64).to(dtype).float()
+    gv = rnd((a, heads, s, d), 65).to(dtype).float()
+    cos, sin = OL.rope_tables(d, 256)
+    xo = qkv.clone().requires_grad_(True); qso = qs.clone().requires_grad_(True); kso = ks.clone().requires_grad_(True)
+    q, k, v = torch.chunk(xo, 3, dim=-1)
+    sp = lambda z: z.reshape(a, s, heads, d)
+    qn = O.layer_norm(sp(q), qso, None, dtype); kn = O.layer_norm(sp(k), kso, None, dtype)
+    qr, kr = OL.rope(qn, kn, cos, sin, dtype)
+    ((qr.transpose(1, 2) * gq).sum() + (kr.transpose(1, 2) * gk).sum() + (sp(v).transpose(1, 2) * gv).sum()).backward()
+    xg = qkv.to(dev, dtype)
+    qk = ops.qk_prep_fwd_raw(xg, qs.to(dev), ks.to(dev), cos.to(dev), sin.to(dev), heads)
+    # gradients handed over in a non-trivial layout: (a, s, heads, d) storage viewed as (a, heads, s, d)
+    lay = lambda g: g.to(dev, dtype).transpose(1, 2).contiguous().transpose(1, 2)
+    dqkv, dqs, dks = ops.qk_prep_bwd_raw(xg, lay(gq), gk.to(dev, dtype), lay(gv), qs.to(dev), ks.to(dev), cos.to(dev), sin.to(dev), heads)
+    ref_qk = torch.cat([qr.reshape(a, s, hd), kr.reshape(a, s, hd)], -1)
+    if dtype == torch.float32:
+        assert_close(qk, ref_qk, what="qk")
+        assert_close_scaled(dqkv, xo.grad, what="dqkv")
+        assert_close_scaled(dqs, qso.grad, what="dq_scale")
+        assert_close_scaled(dks, kso.grad, what="dk_scale")
+    else:
+        assert_close(qk, ref_qk, rtol=2e-2, atol=2e-2, what="qk")
+        assert_close_scaled(dqkv, xo.grad, rel=3e-2, what="dqkv")
+        assert_close_scaled(dqs, qso.grad, rel=3e-2, what="dq_scale")
+        assert_close_scaled(dks, kso.grad, rel=3e-2, what="dk_scale")
+    assert torch.equal(dqkv[..., 2 * hd:].float().cpu(), gv.transpose(1, 2).reshape(a, s, hd).to(dtype).float()), "dv is a copy"
+
+
+@pytest.mark.parametrize("a,s,heads,d", [(3, 256, 8, 64), (2, 96, 4, 32)])
+def test_spatial_attention_core_bf16(dev, a, s, heads, d):
+    """prep + library flash core + prep backward against the oracle's attention (reference train/layers.py:153-170)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    qkv = rnd((a, s, 3 * heads * d), 70).to(dtype).float()
+    qs = 1 + 0.2 * rnd((d,), 71); ks = 1 + 0.2 * rnd((d,), 72)
+    go = rnd((a, s, heads * d), 73).to(dtype).float()
+    cos, sin = OL.rope_tables(d, 256)
+    xo = qkv.clone().requires_grad_(True); qso = qs.clone().requires_grad_(True); kso = ks.clone().requires_grad_(True)
+    yo = _attn_ref(xo, qso, kso, None, heads, 256, dtype)
+    yo.backward(go)
+    xg = qkv.to(dev, dtype).requires_grad_(True); qsg = qs.to(dev).requires_grad_(True); ksg = ks.to(dev).requires_grad_(True)
+    assert ops.spatial_attention_supported(xg, heads, 256)
+    yg = ops.spatial_attention_core(xg, qsg, ksg, cos.to(dev), sin.to(dev), heads)
+    yg.backward(go.to(dev, dtype))
+    assert_close(yg, yo, rtol=3e-2, atol=3e-2, what="out")
+    assert_close_scaled(xg.grad, xo.grad, rel=5e-2, what="dqkv")
+    assert_close_scaled(qsg.grad, qso.grad, rel=5e-2, what="dq_scale")
+    assert_close_scaled(ksg.grad, kso.grad, rel=5e-2, what="dk_scale")
+
+
 def test_temporal_attention_masked_equals_truncated(dev):
     """Reference property (train/scratch.py:46-57): keys >= L masked  ==  attention over the first L frames."""
     ops = _ops()

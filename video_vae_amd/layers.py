@@ -214,6 +214,10 @@ class Attention(nn.Module):
                 div = a // m8.shape[0]
             o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached,
                                             self.ROPE.sin_cached, m8, div, self.num_heads, 1e-6)
+        elif mask is None and ops.spatial_attention_supported(qkv, self.num_heads, self.ROPE.cos_cached.shape[0]):
+            # spatial half in bf16: one HIP prep launch each way around the library flash-attention core
+            o = ops.spatial_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
+                                           self.num_heads, 1e-6)
         else:
             q, k, v = torch.chunk(qkv, 3, dim=-1)
             q = rearrange(q, "b s (h d) -> b s h d", h=self.num_heads)

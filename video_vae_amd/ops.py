@@ -470,6 +470,102 @@ def temporal_attention_fast_supported(t, d, c3, dtype):
     return dtype in DT and lib().vvae_temporal_attn_fast_supported(t, d, c3, c3 // 3, DT[dtype]) == 1
 
 
+# --------------------------------------------------------------------------------------------- spatial attention (prep + library core)
+def _tok_head(t, a, s):
+    """(a, heads, s, d) gradient -> (tensor, token stride, head stride) with one uniform token stride; copies only if it must."""
+    if not (t.stride(3) == 1 and t.stride(0) == s * t.stride(2)):
+        t = t.transpose(1, 2).contiguous().transpose(1, 2)
+    return t, t.stride(2), t.stride(1)
+
+
+def qk_prep_fwd_raw(qkv, qs, ks, cos, sin, heads, eps=1e-6):
+    """qkv (a, s, 3*heads*D) contiguous -> (a, s, 2*heads*D) = [rope(q_norm(q)) | rope(k_norm(k))] (no autograd)."""
+    a, s, c3 = qkv.shape
+    hd = c3 // 3
+    d = hd // heads
+    qk = torch.empty((a, s, 2 * hd), dtype=qkv.dtype, device=qkv.device)
+    tokens = a * s
+    check(_launch(f"qk_prep_fwd S{s} D{d}", tokens * 4 * hd * qkv.element_size(), 0, "qk_prep_fwd_kernel",
+                  lambda: lib().vvae_qk_prep_fwd(_p(qkv), c3, _p(qk), 2 * hd, _p(qs), _p(ks), _p(cos), _p(sin), tokens, s, heads, d,
+                                                 eps, _dt(qkv), _stream())), "vvae_qk_prep_fwd")
+    return qk
+
+
+def qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps=1e-6):
+    """dq, dk, dv: (a, heads, s, D) gradients (any strides) -> (dqkv (a, s, 3*heads*D), dq_scale (D), dk_scale (D)) (no autograd)."""
+    a, s, c3 = qkv.shape
+    hd = c3 // 3
+    d = hd // heads
+    dq, dq_ts, dq_hs = _tok_head(dq, a, s)
+    dk, dk_ts, dk_hs = _tok_head(dk, a, s)
+    dv, dv_ts, dv_hs = _tok_head(dv, a, s)
+    tokens = a * s
+    dqkv = torch.empty((a, s, c3), dtype=qkv.dtype, device=qkv.device)
+    nblk = lib().vvae_qk_prep_blocks(tokens, heads, d)
+    part = torch.empty((nblk, 2, d), dtype=torch.float32, device=qkv.device)
+    check(_launch(f"qk_prep_bwd S{s} D{d}", tokens * 8 * hd * qkv.element_size(), 0, "qk_prep_bwd_kernel",
+                  lambda: lib().vvae_qk_prep_bwd(_p(qkv), c3, _p(dq), dq_ts, dq_hs, _p(dk), dk_ts, dk_hs, _p(dv), dv_ts, dv_hs,
+                                                 _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(part), tokens, s, heads, d, eps,
+                                                 _dt(qkv), _stream())), "vvae_qk_prep_bwd")
+    tot = part.sum(0)
+    return dqkv, tot[0], tot[1]
+
+
+class _SpatialAttn(torch.autograd.Function):
+    """q/k-norm + RoPE prep (HIP, one launch) -> library flash-attention core -> (backward) core -> prep backward (HIP, one launch).
+
+    The custom Function owns the whole span so autograd never materialises the slice / cat / transpose gradients of the
+    q, k, v views (reference train/layers.py:153-170 with the mask-free spatial call of :217-221).
+    """
+
+    @staticmethod
+    def _views(qkv, qk, heads):
+        a, s, c3 = qkv.shape
+        hd = c3 // 3
+        d = hd // heads
+        q = qk[..., :hd].view(a, s, heads, d).transpose(1, 2)
+        k = qk[..., hd:].view(a, s, heads, d).transpose(1, 2)
+        v = qkv[..., 2 * hd:].view(a, s, heads, d).transpose(1, 2)
+        return q, k, v
+
+    @staticmethod
+    def forward(ctx, qkv, q_scale, k_scale, cos, sin, heads, eps):
+        qkv = qkv.contiguous()
+        a, s, c3 = qkv.shape
+        qs, ks = _f32(q_scale), _f32(k_scale)
+        qk = qk_prep_fwd_raw(qkv, qs, ks, cos, sin, heads, eps)
+        q, k, v = _SpatialAttn._views(qkv, qk, heads)
+        out, lse, cq, ck, mq, mk, seed, off, _ = torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, False, False)
+        ctx.save_for_backward(qkv, qs, ks, cos, sin, qk, out, lse, seed, off)
+        ctx.misc = (cq, ck, mq, mk, heads, eps, q_scale.dtype)
+        return out.transpose(1, 2).reshape(a, s, c3 // 3)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qs, ks, cos, sin, qk, out, lse, seed, off = ctx.saved_tensors
+        cq, ck, mq, mk, heads, eps, pdtype = ctx.misc
+        a, s, c3 = qkv.shape
+        q, k, v = _SpatialAttn._views(qkv, qk, heads)
+        do4 = do.to(qkv.dtype).reshape(a, s, heads, c3 // (3 * heads)).transpose(1, 2)
+        dq, dk, dv = torch.ops.aten._scaled_dot_product_flash_attention_backward(do4, q, k, v, out, lse, cq, ck, mq, mk, 0.0, False,
+                                                                                 seed, off)
+        dqkv, dqs, dks = qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps)
+        return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None
+
+
+def spatial_attention_supported(qkv, heads, max_len):
+    """bf16 GPU tensors with a head_dim the prep kernels take (fp32 and masked calls stay on the composed path)."""
+    if not (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[1] <= max_len):
+        return False
+    d = qkv.shape[-1] // (3 * heads)
+    return lib().vvae_qk_prep_supported(d, DT[qkv.dtype]) == 1
+
+
+def spatial_attention_core(qkv, q_scale, k_scale, cos, sin, heads, eps=1e-6):
+    """q_norm/k_norm -> RoPE -> softmax(QK^T/sqrt(D)) V over (a, s, 3*heads*D), no mask (reference train/layers.py:153-170)."""
+    return _SpatialAttn.apply(qkv, q_scale, k_scale, cos, sin, heads, eps)
+
+
 # --------------------------------------------------------------------------------------------- reparameterise + KL
 class _ReparamKl(torch.autograd.Function):
     @staticmethod
