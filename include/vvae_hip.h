@@ -141,8 +141,9 @@ int vvae_layernorm_supported(int C, int dtype);
 int vvae_layernorm_bwd_blocks(long rows, int C, int dtype);
 int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                        long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps, int dtype, void* stream);
-int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
-                       float* part, long rows, int C, int inner, long outer_pitch, long inner_pitch, int dtype, void* stream);
+int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                       void* dx, float* part, long rows, int C, int inner, long outer_pitch, long inner_pitch, int dtype,
+                       void* stream);
 
 /* ---- reparameterise + KL: train/model.py:124-128, train/rl_nonadversarial.py:146-147. ---- */
 int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, const float* mask, float* z, float* kl,

@@ -415,6 +415,47 @@ def test_layer_norm(dev, shape, dtype, use_bias):
         assert_close_scaled(bg.grad, bo.grad, rel=r, what="dbias")
 
 
+@pytest.mark.parametrize("shape", [(3, 70, 768), (2, 9, 512), (130, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layer_norm_fork_residual(dev, shape, dtype):
+    """x + f(LN(x)) with the skip gradient added inside the LayerNorm-backward kernel == the unfused graph; and the
+    skip-only / branch-only uses of the fork."""
+    ops = _ops()
+    c = shape[-1]
+    x = (rnd(shape, 80) * 1.3 + 0.2).to(dev, dtype)
+    sc = (1 + 0.2 * rnd((c,), 81)).to(dev); bi = (0.1 * rnd((c,), 82)).to(dev)
+    w = (rnd(shape, 83)).to(dev, dtype); go = rnd(shape, 84).to(dev, dtype)
+    f = lambda y: torch.tanh(y) * w
+
+    def run(fused):
+        xg = x.clone().requires_grad_(True); sg = sc.clone().requires_grad_(True); bg = bi.clone().requires_grad_(True)
+        if fused:
+            y, skip = ops.layer_norm_fork(xg, sg, bg)
+            out = skip + f(y)
+        else:
+            out = xg + f(ops.layer_norm(xg, sg, bg))
+        out.backward(go)
+        return out, xg.grad, sg.grad, bg.grad
+    o1, dx1, ds1, db1 = run(True)
+    o2, dx2, ds2, db2 = run(False)
+    assert torch.equal(o1, o2)
+    assert torch.equal(ds1, ds2) and torch.equal(db1, db2)
+    if dtype == torch.float32:
+        assert_close(dx1, dx2, rtol=1e-6, atol=1e-6, what="dx fused vs unfused")
+    else:
+        assert torch.equal(dx1, dx2), "bf16: round(LN grad) + skip grad, rounded once more -- same as the separate add"
+    xg = x.clone().requires_grad_(True)
+    y, skip = ops.layer_norm_fork(xg, sc, bi)
+    (skip * go).sum().backward()                                   # branch unused
+    assert_close(xg.grad, go, what="skip-only gradient")
+    xg = x.clone().requires_grad_(True)
+    y, skip = ops.layer_norm_fork(xg, sc, bi)
+    (y * go).sum().backward()                                      # skip unused
+    xr = x.clone().requires_grad_(True)
+    (ops.layer_norm(xr, sc, bi) * go).sum().backward()
+    assert torch.equal(xg.grad, xr.grad)
+
+
 def test_layer_norm_strided_head_view(dev):
     """q_norm on the q third of a fused QKV buffer, normalised in place of a gather copy (two-level row strides)."""
     ops = _ops()

@@ -31,17 +31,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
     constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;          // rows per wave-iteration
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, ll = lane % LPR;
-    // this lane's columns never change: keep gamma / beta in registers for all the rows the wave walks (re-loading them per
-    // row moved 5x more bytes through L1 than the row itself)
+    // this lane's columns never change: keep gamma / beta in registers for all the rows the wave walks.  They reach the
+    // registers through LDS (one coalesced pass per workgroup): per-lane strided dword loads of the affine cost ~30x the
+    // L1 line accesses of the row itself and were what bounded the kernel.
+    __shared__ __attribute__((aligned(16))) float sg[LPR * VPL * V], sb[LPR * VPL * V];
+    for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) {
+        sg[i] = i < d.C ? gamma[i] : 0.f;
+        sb[i] = (beta && i < d.C) ? beta[i] : 0.f;
+    }
+    __syncthreads();
     float gm[VPL][V], bt[VPL][V];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
         const int c = (k * LPR + ll) * V;
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            gm[k][e] = c < d.C ? gamma[c + e] : 0.f;
-            bt[k][e] = (beta && c < d.C) ? beta[c + e] : 0.f;
-        }
+        for (int e = 0; e < V; ++e) { gm[k][e] = sg[c + e]; bt[k][e] = sb[c + e]; }
     }
     const long rstride = (long)gridDim.x * 4 * RPW;
     for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
@@ -83,19 +87,24 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
 template <typename T_, int LPR, int VPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict__ x, const T_* __restrict__ dy, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                            T_* __restrict__ dx, float* __restrict__ part, LnDims d)
+                                                            const T_* __restrict__ dres, T_* __restrict__ dx, float* __restrict__ part,
+                                                            LnDims d)
 {
     constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;
-    __shared__ float red[4][64][VPL * V];
+    __shared__ __attribute__((aligned(16))) float red[4][64][VPL * V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, ll = lane % LPR;
+    float* sg = &red[0][0][0];                             // gamma via LDS (see the forward kernel); red is reused afterwards
+    for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) sg[i] = i < d.C ? gamma[i] : 0.f;
+    __syncthreads();
     float ag[VPL][V], ab[VPL][V], gm[VPL][V];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
         const int c = (k * LPR + ll) * V;
 #pragma unroll
-        for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gm[k][e] = c < d.C ? gamma[c + e] : 0.f; }
+        for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gm[k][e] = sg[c + e]; }
     }
+    __syncthreads();
     const long rstride = (long)gridDim.x * 4 * RPW;
     for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
@@ -130,6 +139,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
                 float o[V];
 #pragma unroll
                 for (int e = 0; e < V; ++e) o[e] = rstd * (g[k][e] - s1 - xh[k][e] * s2);
+                if (dres) {                              // pre-norm residual block: the skip path's gradient joins here
+                    float rr[V];
+                    VecIO<T_, V>::load(dres + r * d.C + c, rr);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[e] = round_to<T_>(o[e]) + rr[e];
+                }
                 VecIO<T_, V>::store(dr + c, o);
             }
         }
@@ -167,13 +182,14 @@ inline int ln_blocks(long rows, int lpr, int cap = 1024)
     return (int)(b < 1 ? 1 : b);
 }
 
-// pick lanes-per-row: smallest power of two >= C/V capped at 64; vectors per lane up to 4
+// pick lanes-per-row: the SMALLEST power of two (>= 8) that covers the row with <= 4 vectors per lane -- a wave then walks
+// 64/lpr rows at once with 3-4 sixteen-byte loads in flight per lane (C = 768 bf16: 32 lanes x 3 vectors, two rows per wave)
 inline bool ln_pick(int C, int V, int& lpr, int& vpl)
 {
     if (C % V) return false;
     const int nv = C / V;
     lpr = 8;
-    while (lpr < 64 && lpr < nv) lpr <<= 1;
+    while (lpr < 64 && (nv + lpr - 1) / lpr > 4) lpr <<= 1;
     vpl = (nv + lpr - 1) / lpr;
     return vpl <= 4;
 }
@@ -189,16 +205,15 @@ bool ln_ok(const LnDims& d, const void* x, int& lpr, int& vpl)
 
 }  // namespace
 
+#define LN_CASE(KERNEL, T_, L, P, ...) case L * 8 + P: hipLaunchKernelGGL((KERNEL<T_, L, P>), grid, dim3(256), 0, s, __VA_ARGS__); break;
 #define LN_SWITCH(KERNEL, T_, ...)                                                                                                   \
     do {                                                                                                                             \
         switch (lpr * 8 + vpl) {                                                                                                     \
-            case 8 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 8, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                       \
-            case 16 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 16, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
-            case 32 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 32, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
-            case 64 * 8 + 1: hipLaunchKernelGGL((KERNEL<T_, 64, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
-            case 64 * 8 + 2: hipLaunchKernelGGL((KERNEL<T_, 64, 2>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
-            case 64 * 8 + 3: hipLaunchKernelGGL((KERNEL<T_, 64, 3>), grid, dim3(256), 0, s, __VA_ARGS__); break;                     \
-            default: hipLaunchKernelGGL((KERNEL<T_, 64, 4>), grid, dim3(256), 0, s, __VA_ARGS__); break;                             \
+            LN_CASE(KERNEL, T_, 8, 1, __VA_ARGS__) LN_CASE(KERNEL, T_, 8, 2, __VA_ARGS__) LN_CASE(KERNEL, T_, 8, 3, __VA_ARGS__)     \
+            LN_CASE(KERNEL, T_, 8, 4, __VA_ARGS__) LN_CASE(KERNEL, T_, 16, 3, __VA_ARGS__) LN_CASE(KERNEL, T_, 16, 4, __VA_ARGS__)   \
+            LN_CASE(KERNEL, T_, 32, 3, __VA_ARGS__) LN_CASE(KERNEL, T_, 32, 4, __VA_ARGS__) LN_CASE(KERNEL, T_, 64, 3, __VA_ARGS__)  \
+            LN_CASE(KERNEL, T_, 64, 4, __VA_ARGS__)                                                                                  \
+            default: return VVAE_ERR_BAD_ARG;                                                                                        \
         }                                                                                                                            \
     } while (0)
 
@@ -240,21 +255,23 @@ extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, co
 }
 
 // dy, dx contiguous (rows, C).  part: fp32 (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy] per workgroup.
-extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
-                                  float* part, long rows, int C, int inner, long outer_pitch, long inner_pitch, int dtype, void* stream)
+// dres: NULL, or a contiguous (rows, C) gradient added to dx (the skip path of a pre-norm residual block: x + f(LN(x))).
+extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                                  void* dx, float* part, long rows, int C, int inner, long outer_pitch, long inner_pitch, int dtype,
+                                  void* stream)
 {
-    if (!x || !dy || !gamma || !mean || !rstd || !dx || !part) return VVAE_ERR_BAD_ARG;
+    if (!x || !dy || !gamma || !mean || !rstd || !dx || !part || ((uintptr_t)dres % 16)) return VVAE_ERR_BAD_ARG;
     LnDims d{rows, C, inner, outer_pitch, inner_pitch, 0.f};
     hipStream_t s = (hipStream_t)stream;
     int lpr, vpl;
     if (dtype == VVAE_DT_F32) {
         if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr));
-        LN_SWITCH(layernorm_bwd_kernel, float, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, part, d);
+        LN_SWITCH(layernorm_bwd_kernel, float, (const float*)x, (const float*)dy, gamma, mean, rstd, (const float*)dres, (float*)dx, part, d);
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr));
-        LN_SWITCH(layernorm_bwd_kernel, bf16_t, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, part, d);
+        LN_SWITCH(layernorm_bwd_kernel, bf16_t, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, part, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
     return 0;

@@ -100,6 +100,13 @@ class LayerNorm(nn.Module):
         b = self.bias.to(self.dtype) if self.bias is not None else None
         return F.layer_norm(x, (x.shape[-1],), self.scale.to(self.dtype), b, 1e-6)
 
+    def fork(self, x):
+        """-> (LayerNorm(x), x_skip) for ``x_skip + f(LayerNorm(x))``: on the HIP path x_skip is x routed through the
+        LayerNorm node, so the skip gradient is added inside its backward kernel (no separate add launch)."""
+        if x.dtype == self.dtype and ops.layer_norm_supported(x):
+            return ops.layer_norm_fork(x, self.scale, self.bias, 1e-6)
+        return self.forward(x), x
+
 
 class PatchEmbedding(nn.Module):
     """Reference train/layers.py:8-27: patchify -> LayerNorm -> Linear."""
@@ -189,10 +196,10 @@ class Attention(nn.Module):
         self.k_norm = LayerNorm(head_dim, dtype, param_dtype, use_bias=False)
 
     def forward_temporal_strided(self, x, mask=None):
-        """Temporal attention on x laid out (b, t, hw, c) -- attention over t for every (b, hw) without the
+        """x + temporal attention on x laid out (b, t, hw, c) -- attention over t for every (b, hw) without the
         "b t hw c -> (b hw) t c" transposes: LayerNorm and the projections are per-token, the fused core strides."""
         b, t, hw, _ = x.shape
-        x = self.input_norm(x)
+        x, skip = self.input_norm.fork(x)
         qkv = self.qkv_projection(x)
         m8, div = None, 1
         if mask is not None:
@@ -200,10 +207,18 @@ class Attention(nn.Module):
             div = (b * hw) // m8.shape[0]
         o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
                                         m8, div, self.num_heads, 1e-6, inner=hw)
-        return self.out_projection(o)
+        return skip + self.out_projection(o)
 
-    def forward(self, x, mask=None):
-        x = self.input_norm(x)
+    def residual(self, x, mask=None):
+        """x + self(x) with the skip gradient folded into the input LayerNorm's backward."""
+        return self.forward(x, mask, _residual=True)
+
+    def forward(self, x, mask=None, _residual=False):
+        skip = None
+        if _residual:
+            x, skip = self.input_norm.fork(x)
+        else:
+            x = self.input_norm(x)
         qkv = self.qkv_projection(x)
         a, s, _ = qkv.shape
         if s <= FUSED_CORE_MAX_SEQ:
@@ -230,7 +245,8 @@ class Attention(nn.Module):
                     mask.to(torch.bool).repeat_interleave(a // mask.shape[0], dim=0)
             o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=am)
             o = rearrange(o, "b h s d -> b s (h d)")
-        return self.out_projection(o)
+        o = self.out_projection(o)
+        return skip + o if _residual else o
 
 
 class MLP(nn.Module):
@@ -244,6 +260,11 @@ class MLP(nn.Module):
 
     def forward(self, x):
         return self.linear2(F.silu(self.linear1(self.norm(x))))
+
+    def residual(self, x):
+        """x + self(x) with the skip gradient folded into the LayerNorm's backward."""
+        y, skip = self.norm.fork(x)
+        return skip + self.linear2(F.silu(self.linear1(y)))
 
 
 class FactoredAttention(nn.Module):
@@ -268,19 +289,19 @@ class FactoredAttention(nn.Module):
         if x.is_cuda and t <= FUSED_CORE_MAX_SEQ and ops.temporal_attention_fast_supported(t, hd, 3 * hd * ta.num_heads, ta.qkv_projection.dtype):
             # every op of the temporal half except the attention core is per-token, and the core strides over frames:
             # stay in (b, t, hw, c) and skip both transpose copies (and their backward)
-            x = x + ta.forward_temporal_strided(x, mask=temporal_mask)
-            x = x + self.TemporalMLP(x)
+            x = ta.forward_temporal_strided(x, mask=temporal_mask)
+            x = self.TemporalMLP.residual(x)
             sx = x.reshape(b * t, hw, c)
-            sx = sx + self.SpatialAttention(sx)
-            sx = sx + self.SpatialMLP(sx)
+            sx = self.SpatialAttention.residual(sx)
+            sx = self.SpatialMLP.residual(sx)
             return sx.view(b, t, hw, c)
         tx = rearrange(x, "b t hw c -> (b hw) t c")
-        tx = tx + self.TemporalAttention(tx, mask=temporal_mask)
-        tx = tx + self.TemporalMLP(tx)
+        tx = self.TemporalAttention.residual(tx, mask=temporal_mask)
+        tx = self.TemporalMLP.residual(tx)
         x = rearrange(tx, "(b hw) t c -> b t hw c", b=b, hw=hw)
         sx = rearrange(x, "b t hw c -> (b t) hw c")
-        sx = sx + self.SpatialAttention(sx)
-        sx = sx + self.SpatialMLP(sx)
+        sx = self.SpatialAttention.residual(sx)
+        sx = self.SpatialMLP.residual(sx)
         return rearrange(sx, "(b t) hw c -> b t hw c", b=b, t=t)
 
 

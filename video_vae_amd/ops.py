@@ -678,9 +678,12 @@ def _rows2(x):
 
 
 class _LayerNorm(torch.autograd.Function):
+    """fork=True is the pre-norm residual form ``x + f(LN(x))``: forward also hands x back (an alias), so the gradient of the skip
+    path arrives in THIS node's backward and is added inside the LayerNorm-backward kernel instead of by a separate add launch."""
+
     @staticmethod
-    def forward(ctx, x, scale, bias, eps):
-        x, n, inner, op, ip = _rows2(x)
+    def forward(ctx, x_in, scale, bias, eps, fork):
+        x, n, inner, op, ip = _rows2(x_in)
         c = x.shape[-1]
         dt = _dt(x)
         s32 = _f32(scale)
@@ -693,22 +696,31 @@ class _LayerNorm(torch.autograd.Function):
                                                        _stream())), "vvae_layernorm_fwd")
         ctx.save_for_backward(x, s32, mean, rstd)
         ctx.args = (n, c, inner, op, ip, scale.dtype, bias is not None)
+        ctx.set_materialize_grads(False)
+        if fork:
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, s32, mean, rstd = ctx.saved_tensors
         n, c, inner, op, ip, pdtype, has_bias = ctx.args
         dt = _dt(x)
+        if dy is None:                                   # only the skip path was used
+            return dskip, None, None, None, None
         dy = dy.to(x.dtype).contiguous()
+        if dskip is not None:
+            dskip = dskip.to(x.dtype).contiguous()
         dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         nblk = lib().vvae_layernorm_bwd_blocks(n, c, dt)
         part = torch.empty((nblk, 2, c), dtype=torch.float32, device=x.device)
-        check(_launch(f"layernorm_bwd C{c}", 3 * x.numel() * x.element_size(), 0, "layernorm_bwd_kernel",
-                      lambda: lib().vvae_layernorm_bwd(_p(x), _p(dy), _p(s32), _p(mean), _p(rstd), _p(dx), _p(part), n, c, inner, op, ip,
-                                                       dt, _stream())), "vvae_layernorm_bwd")
+        nstreams = 4 if dskip is not None else 3
+        check(_launch(f"layernorm_bwd C{c}" + ("+skip" if dskip is not None else ""), nstreams * x.numel() * x.element_size(), 0,
+                      "layernorm_bwd_kernel",
+                      lambda: lib().vvae_layernorm_bwd(_p(x), _p(dy), _p(s32), _p(mean), _p(rstd), _p(dskip), _p(dx), _p(part), n, c, inner,
+                                                       op, ip, dt, _stream())), "vvae_layernorm_bwd")
         tot = part.sum(0)
-        return dx, tot[0].to(pdtype), (tot[1].to(pdtype) if has_bias else None), None
+        return dx, tot[0].to(pdtype), (tot[1].to(pdtype) if has_bias else None), None, None
 
 
 def layer_norm_supported(x):
@@ -717,7 +729,13 @@ def layer_norm_supported(x):
 
 def layer_norm(x, scale, bias=None, eps=1e-6):
     """nnx.LayerNorm over the last axis, fp32 statistics (reference train/layers.py:17,152,155-156,178)."""
-    return _LayerNorm.apply(x, scale, bias, eps)
+    return _LayerNorm.apply(x, scale, bias, eps, False)
+
+
+def layer_norm_fork(x, scale, bias=None, eps=1e-6):
+    """-> (LayerNorm(x), x): the second output is x itself, routed through the node so that in ``x_skip + f(y)`` the skip
+    gradient is added inside the LayerNorm-backward kernel (pre-norm residual blocks, reference train/layers.py:212-221)."""
+    return _LayerNorm.apply(x, scale, bias, eps, True)
 
 
 # --------------------------------------------------------------------------------------------- dense weight-gradient GEMM
