@@ -169,6 +169,8 @@ int vvae_sqnorm_accum(const float* g, long n, double* out, void* stream);
 int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_sq,
                         float gscale, float max_norm, float lr, float b1, float b2, float eps, long count, void* stream);
 int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+/* out[c] = sum_r part[r][c] in fixed order: folds the per-workgroup partial rows of the backward kernels (cols % 4 == 0). */
+int vvae_sum_rows(const float* part, int rows, int cols, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -456,6 +456,18 @@ def test_layer_norm_fork_residual(dev, shape, dtype):
     assert torch.equal(xg.grad, xr.grad)
 
 
+@pytest.mark.parametrize("shape", [(1024, 2, 768), (8192, 128), (1000, 2, 64), (7, 12), (1, 4), (4096, 1536)])
+def test_sum_rows(dev, shape):
+    """Fold of per-workgroup partial rows: fixed order (bitwise reproducible) and equal to an fp64 column sum."""
+    ops = _ops()
+    part = rnd(shape, 90).to(dev)
+    got = ops.sum_rows(part)
+    assert got.shape == part.shape[1:]
+    want = part.double().sum(0)
+    assert_close(got.double(), want, rtol=1e-5, atol=1e-4, what="sum_rows")
+    assert torch.equal(got, ops.sum_rows(part))
+
+
 def test_layer_norm_strided_head_view(dev):
     """q_norm on the q third of a fused QKV buffer, normalised in place of a gather copy (two-level row strides)."""
     ops = _ops()

@@ -22,6 +22,18 @@ template <int LPR> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// raw 16-byte vector -> fp32 lanes (the backward kernel keeps x and dy RAW between its two passes: 8 instead of 16 live
+// registers per bf16 vector, which is what lets four waves share a SIMD)
+__device__ __forceinline__ void unpack(const uint4& r, float (&v)[4]) {
+    v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+}
+__device__ __forceinline__ void unpack(const uint4& r, float (&v)[8]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void opaque(uint4& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+
 // y rows are written contiguously (pitch C).  mean / rstd: fp32 [rows] (saved for backward).
 template <typename T_, int LPR, int VPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict__ x, T_* __restrict__ y, const float* __restrict__ gamma,
@@ -91,20 +103,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
                                                             LnDims d)
 {
     constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;
-    __shared__ __attribute__((aligned(16))) float red[4][64][VPL * V];
+    __shared__ __attribute__((aligned(16))) float red[4][LPR][VPL * V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, ll = lane % LPR;
-    float* sg = &red[0][0][0];                             // gamma via LDS (see the forward kernel); red is reused afterwards
+    // gamma stays in LDS (see the forward kernel for why it gets there in one coalesced pass) and is re-read per use:
+    // registers go to the two column accumulators instead
+    __shared__ __attribute__((aligned(16))) float sg[LPR * VPL * V];
     for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) sg[i] = i < d.C ? gamma[i] : 0.f;
     __syncthreads();
-    float ag[VPL][V], ab[VPL][V], gm[VPL][V];
+    float ag[VPL][V], ab[VPL][V];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        const int c = (k * LPR + ll) * V;
+    for (int k = 0; k < VPL; ++k)
 #pragma unroll
-        for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gm[k][e] = sg[c + e]; }
-    }
-    __syncthreads();
+        for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
     const long rstride = (long)gridDim.x * 4 * RPW;
     for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
@@ -112,23 +123,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
         const T_* xr = x + row_off(d, rv ? r : 0);
         const T_* gr = dy + (rv ? r : 0) * d.C;
         const float mean = rv ? mean_in[r] : 0.f, rstd = rv ? rstd_in[r] : 0.f;
-        float xh[VPL][V], g[VPL][V];
+        uint4 rx[VPL], rg[VPL];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             const int c = (k * LPR + ll) * V;
+            rx[k] = make_uint4(0, 0, 0, 0); rg[k] = make_uint4(0, 0, 0, 0);
             if (rv && c < d.C) {
-                VecIO<T_, V>::load(xr + c, xh[k]);
-                VecIO<T_, V>::load(gr + c, g[k]);
+                rx[k] = *reinterpret_cast<const uint4*>(xr + c);
+                rg[k] = *reinterpret_cast<const uint4*>(gr + c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = (k * LPR + ll) * V;
+            if (rv && c < d.C) {
+                float xh[V], g[V];
+                unpack(rx[k], xh); unpack(rg[k], g);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    xh[k][e] = (xh[k][e] - mean) * rstd;
-                    ag[k][e] += g[k][e] * xh[k][e];
-                    ab[k][e] += g[k][e];
-                    g[k][e] *= gm[k][e];
-                    s1 += g[k][e]; s2 += g[k][e] * xh[k][e];
+                    xh[e] = (xh[e] - mean) * rstd;
+                    ag[k][e] += g[e] * xh[e];
+                    ab[k][e] += g[e];
+                    const float gg = g[e] * sg[c + e];
+                    s1 += gg; s2 += gg * xh[e];
                 }
             }
+            opaque(rx[k]); opaque(rg[k]);               // second pass re-decodes instead of keeping 2*V floats alive
         }
         s1 = group_sum<LPR>(s1) / d.C; s2 = group_sum<LPR>(s2) / d.C;
         T_* dr = dx + r * d.C;
@@ -136,9 +157,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
         for (int k = 0; k < VPL; ++k) {
             const int c = (k * LPR + ll) * V;
             if (rv && c < d.C) {
-                float o[V];
+                float xh[V], g[V], o[V];
+                unpack(rx[k], xh); unpack(rg[k], g);
 #pragma unroll
-                for (int e = 0; e < V; ++e) o[e] = rstd * (g[k][e] - s1 - xh[k][e] * s2);
+                for (int e = 0; e < V; ++e) o[e] = rstd * (g[e] * sg[c + e] - s1 - (xh[e] - mean) * rstd * s2);
                 if (dres) {                              // pre-norm residual block: the skip path's gradient joins here
                     float rr[V];
                     VecIO<T_, V>::load(dres + r * d.C + c, rr);
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
                 float t = pass ? ab[k][e] : ag[k][e];
 #pragma unroll
                 for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
-                red[wave][lane][k * V + e] = t;
+                if (lane < LPR) red[wave][lane][k * V + e] = t;
             }
         __syncthreads();
         for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) {

@@ -325,3 +325,47 @@ extern "C" int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stre
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
+// out[c] = sum_r part[r][c], r in fixed order: the fold of the per-workgroup partial rows the LayerNorm / attention backward
+// kernels emit (parameter gradients without float atomics).  Block = 8 column quads x 32 row lanes; a thread keeps 16 float4
+// loads in flight (the partials are L2-resident: latency, not bandwidth, is what a 1.5-million-element fold pays for).
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out)
+{
+    __shared__ float4 red[32][8];
+    const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = (blockIdx.x * 8 + cq) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+        for (int r0 = rl; r0 < rows; r0 += 32 * 16) {
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = r0 + 32 * i;
+                v[i] = r < rows ? *reinterpret_cast<const float4*>(part + (long)r * cols + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+        }
+    }
+    red[rl][cq] = s;
+    __syncthreads();
+    for (int st = 16; st > 0; st >>= 1) {
+        if (rl < st) {
+            const float4 a = red[rl][cq], b = red[rl + st][cq];
+            red[rl][cq] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < cols) *reinterpret_cast<float4*>(out + c) = red[0][cq];
+}
+}  // namespace
+
+// part: fp32 (rows, cols) contiguous, cols % 4 == 0; out: fp32 (cols) = column sums, deterministic order.
+extern "C" int vvae_sum_rows(const float* part, int rows, int cols, float* out, void* stream)
+{
+    if (!part || !out || rows <= 0 || cols <= 0 || cols % 4 || ((uintptr_t)part % 16) || ((uintptr_t)out % 16)) return VVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(ceil_div(cols, 32)), dim3(256), 0, (hipStream_t)stream, part, rows, cols, out);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

@@ -55,6 +55,25 @@ def _ws(nbytes, device):
     return buf, nbytes
 
 
+def sum_rows(part):
+    """Column sums of a (rows, ...) fp32 partial buffer in fixed order -> shape part.shape[1:] (no memset, no atomics).
+
+    Tall-and-narrow buffers are folded in two launches: (rows, cols) is read as (rows/k, k*cols) first, so the first pass
+    has enough workgroups, then the k partial rows are summed."""
+    r = part.shape[0]
+    cols0 = part.numel() // r
+    cols, k = cols0, 1
+    while r > 1024 and r % 2 == 0 and cols * 2 <= 8192:
+        r //= 2; cols *= 2; k *= 2
+    out = torch.empty((k,) + tuple(part.shape[1:]), dtype=torch.float32, device=part.device)
+    check(lib().vvae_sum_rows(_p(part), r, cols, _p(out), _stream()), "vvae_sum_rows")
+    if k == 1:
+        return out[0]
+    out2 = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    check(lib().vvae_sum_rows(_p(out), k, cols0, _p(out2), _stream()), "vvae_sum_rows")
+    return out2
+
+
 class KernelTimer:
     """Per-launch HIP-event timing of tagged kernels on the current stream (bench.py's roofline leg).
 
@@ -445,7 +464,7 @@ class _TemporalAttn(torch.autograd.Function):
                                                                     _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div, inner,
                                                                     _p(part), a, t, heads, d, eps, dt, _stream())),
                   "vvae_temporal_attn_bwd_fast")
-            tot = part.sum(0)
+            tot = sum_rows(part)
             dqs, dks = tot[:d], tot[d:]
         else:
             dqs = torch.empty((d,), dtype=torch.float32, device=qkv.device)
@@ -507,7 +526,7 @@ def qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps=1e-6):
                   lambda: lib().vvae_qk_prep_bwd(_p(qkv), c3, _p(dq), dq_ts, dq_hs, _p(dk), dk_ts, dk_hs, _p(dv), dv_ts, dv_hs,
                                                  _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(part), tokens, s, heads, d, eps,
                                                  _dt(qkv), _stream())), "vvae_qk_prep_bwd")
-    tot = part.sum(0)
+    tot = sum_rows(part)
     return dqkv, tot[0], tot[1]
 
 
@@ -719,7 +738,7 @@ class _LayerNorm(torch.autograd.Function):
                       "layernorm_bwd_kernel",
                       lambda: lib().vvae_layernorm_bwd(_p(x), _p(dy), _p(s32), _p(mean), _p(rstd), _p(dskip), _p(dx), _p(part), n, c, inner,
                                                        op, ip, dt, _stream())), "vvae_layernorm_bwd")
-        tot = part.sum(0)
+        tot = sum_rows(part)
         return dx, tot[0].to(pdtype), (tot[1].to(pdtype) if has_bias else None), None, None
 
 
