@@ -163,12 +163,21 @@ int vvae_gemm_tn_supported(int M, int N, int K, int lda, int ldb);
 size_t vvae_gemm_tn_ws_bytes(int M, int N, int K);
 int vvae_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, float* db, int M, int N, int K,
                       void* ws, size_t ws_bytes, void* stream);
+int vvae_gemm_tn_use_big_tiles(int on);   /* test hook: 0 = 128x128 kernel for every shape */
 
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam) at train/rl_nonadversarial.py:248-251. ---- */
 int vvae_sqnorm_accum(const float* g, long n, double* out, void* stream);
 int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_sq,
                         float gscale, float max_norm, float lr, float b1, float b2, float eps, long count, void* stream);
 int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+/* ---- dense-layer GEMM, both operands K-contiguous: C (M,N) bf16 = epi(A (M,K) . B (N,K)^T + bias), fp32 accumulation.
+ *      Linear forward (B = transposed bf16 weight shadow) and input gradient (B = the weight itself) of nnx.Linear at
+ *      train/layers.py:15,142-151,179-189.  epi 0 none; 1 + res (residual add); 2 SiLU, rounded pre-activation -> C2;
+ *      3 * silu'(res) (res = saved pre-activation).  The elementwise tail acts on the bf16-rounded linear output. ---- */
+int vvae_gemm_nt_supported(int M, int N, int K, int lda, int ldb, int ldc);
+int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* res,
+                      int ldr, void* C2, int ldc2, int epi, int M, int N, int K, void* stream);
+
 /* out[c] = sum_r part[r][c] in fixed order: folds the per-workgroup partial rows of the backward kernels (cols % 4 == 0). */
 int vvae_sum_rows(const float* part, int rows, int cols, float* out, void* stream);
 

@@ -25,3 +25,13 @@ for M, N in [(768, 1536), (768, 768), (512, 768), (1536, 768), (768, 512), (768,
     except Exception as e:
         t_f32 = float("nan")
     print(f"M{M} N{N}: own {t_own:.1f}us {fl/t_own/1e6:.0f}TF | blas TN bf16 {t_tn:.1f}us {fl/t_tn/1e6:.0f}TF | TN f32out {t_f32:.1f} | fwd NN {t_fwd:.1f}us {fl/t_fwd/1e6:.0f}TF | dgrad NT {t_dg:.1f}us {fl/t_dg/1e6:.0f}TF", flush=True)
+print("--- rocblas preferred")
+try:
+    torch.backends.cuda.preferred_blas_library("cublas")
+    for M, N in [(768, 1536), (512, 768)]:
+        x = torch.randn(K, M, device=dev, dtype=torch.bfloat16); w = torch.randn(M, N, device=dev, dtype=torch.bfloat16); dy = torch.randn(K, N, device=dev, dtype=torch.bfloat16)
+        fl = 2.0 * K * M * N
+        t_fwd = tm(lambda: torch.mm(x, w)); t_dg = tm(lambda: torch.mm(dy, w.t()))
+        print(f"M{M} N{N}: fwd {t_fwd:.1f}us {fl/t_fwd/1e6:.0f}TF dgrad {t_dg:.1f}us {fl/t_dg/1e6:.0f}TF", flush=True)
+except Exception as e:
+    print("rocblas path failed", e)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: pmc.sh <tag> <python script args...>   -> per-kernel averaged counters under gpurun_out/pmc_<tag>/
+tag=$1; shift
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM TA_BUSY_avr"; do
+  i=$((i+1))
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag/p$i -- python "$@" > $R/gpurun_out/pmc_$tag.p$i.log 2>&1 || echo "pass $i failed"
+done
+cd $R && python scratch/pmc_sum.py gpurun_out/pmc_$tag

@@ -508,19 +508,56 @@ def test_temporal_attention_strided_layout(dev, dtype):
     assert_close_scaled(k1.grad, k2.grad, rel=1e-5)
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 1000), (768, 1536, 4096), (512, 128, 33)])
-def test_gemm_tn_weight_gradient(dev, m, n, k):
-    """dW = X^T dY and db = colsum(dY) from the split-K HIP kernel vs fp32 torch on the same bf16 operands."""
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 1000), (768, 1536, 4096), (512, 128, 33), (256, 256, 32), (512, 768, 2080),
+                                   (768, 512, 16384), (256, 512, 96)])
+@pytest.mark.parametrize("big", [True, False])
+def test_gemm_tn_weight_gradient(dev, m, n, k, big):
+    """dW = X^T dY and db = colsum(dY) from the split-K HIP kernels vs fp32 torch on the same bf16 operands.
+    big=True: 256 x 256 tiles (LDS-DMA ring, staggered wave halves) where M, N, K allow; False: the 128 x 128 kernel."""
+    from video_vae_amd._lib import lib
     ops = _ops()
     a = rnd((k, m), 80).to(dev, torch.bfloat16)
     b = rnd((k, n), 81).to(dev, torch.bfloat16)
     assert ops.gemm_tn_supported(a, b)
-    c, db = ops.gemm_tn(a, b)
+    lib().vvae_gemm_tn_use_big_tiles(1 if big else 0)
+    try:
+        c, db = ops.gemm_tn(a, b)
+        c2, _ = ops.gemm_tn(a, b)
+        c3, none = ops.gemm_tn(a, b, False)
+    finally:
+        lib().vvae_gemm_tn_use_big_tiles(1)
     want = a.float().t() @ b.float()
     assert_close_scaled(c, want, rel=1e-4, what="dW")
     assert_close_scaled(db, b.float().sum(0), rel=1e-4, what="db")
-    c2, _ = ops.gemm_tn(a, b)
     assert torch.equal(c, c2), "slab reduction must be bitwise reproducible"
+    assert none is None and torch.equal(c, c3)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 192, 32), (512, 768, 512), (256, 128, 96), (1024, 1536, 768), (256, 512, 160)])
+def test_gemm_nt_linear_forms(dev, m, n, k):
+    """C = epi(A B^T + bias) (LDS-DMA ring NT GEMM) vs fp32 torch: plain, + residual, SiLU (+ saved pre-activation) and
+    * silu'(h); the fused tails act on the bf16-rounded linear output, i.e. equal Linear followed by the separate op."""
+    import torch.nn.functional as F
+    ops = _ops()
+    a = rnd((m, k), 95).to(dev, torch.bfloat16)
+    b = (rnd((n, k), 96) / k ** 0.5).to(dev, torch.bfloat16)
+    bias = rnd((n,), 97).to(dev)
+    res = rnd((m, n), 98).to(dev, torch.bfloat16)
+    assert ops.gemm_nt_supported(a, b)
+    ref = a.float() @ b.float().t() + bias
+    c = ops.gemm_nt(a, b, bias)
+    assert_close(c, ref, rtol=1e-2, atol=1e-2, what="linear")
+    assert float((c != ref.to(torch.bfloat16)).float().mean()) < 5e-3, "only accumulation-order flips of the last bf16 bit"
+    c1 = ops.gemm_nt(a, b, bias, res, ops.EPI_RES)
+    assert torch.equal(c1, (c.float() + res.float()).to(torch.bfloat16)), "residual add on the rounded output"
+    c2, h = ops.gemm_nt(a, b, bias, None, ops.EPI_SILU)
+    assert torch.equal(h, c)
+    assert_close(c2, F.silu(h.float()), rtol=1e-2, atol=1e-2, what="silu")
+    base = ops.gemm_nt(a, b, None)
+    c3 = ops.gemm_nt(a, b, None, res, ops.EPI_MUL_DSILU)
+    sg = torch.sigmoid(res.float())
+    assert_close(c3, base.float() * (sg * (1 + res.float() * (1 - sg))), rtol=1e-2, atol=1e-2, what="dsilu")
+    assert torch.equal(c, ops.gemm_nt(a, b, bias)), "deterministic"
 
 
 @pytest.mark.parametrize("ci,co,shape", [(32, 16, (2, 3, 6, 10)), (64, 32, (1, 2, 5, 7)), (128, 64, (1, 2, 4, 8))])

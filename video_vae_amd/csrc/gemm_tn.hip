@@ -14,6 +14,13 @@
 //   * the bias gradient rides along as an all-ones A fragment in the m-block-0 workgroups (no separate column-sum pass).
 #include "common.hpp"
 
+namespace tn256 {            // gemm_tn256.hip: 256 x 256 tiles for M, N multiples of 256
+bool supported(int M, int N, int K, int lda, int ldb);
+int pick_splits(int M, int N, int K);
+int launch(const void* A, int lda, const void* B, int ldb, float* slab, float* slab_db, int M, int N, int K, int splits, int* used,
+           hipStream_t s);
+}
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -141,6 +148,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
     }
 }
 
+bool g_tn_big = true;
+
 inline int pick_splits(int M, int N, int K)
 {
     const int tiles = (M / BM) * (N / BN);
@@ -163,7 +172,7 @@ extern "C" int vvae_gemm_tn_supported(int M, int N, int K, int lda, int ldb)
 extern "C" size_t vvae_gemm_tn_ws_bytes(int M, int N, int K)
 {
     if (M % BM || N % BN) return 0;
-    const int s = pick_splits(M, N, K);
+    const int s = (g_tn_big && tn256::supported(M, N, K, M, N)) ? tn256::pick_splits(M, N, K) : pick_splits(M, N, K);
     return ((size_t)s * M * N + (size_t)s * N) * sizeof(float);
 }
 
@@ -173,20 +182,34 @@ extern "C" int vvae_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb,
 {
     if (!A || !B || !C || !vvae_gemm_tn_supported(M, N, K, lda, ldb) || ((uintptr_t)A % 16) || ((uintptr_t)B % 16) ||
         ((uintptr_t)C % 16)) return VVAE_ERR_BAD_ARG;
-    const int splits = pick_splits(M, N, K);
     if (!ws || ws_bytes < vvae_gemm_tn_ws_bytes(M, N, K) || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const long MN = (long)M * N;
+    if (g_tn_big && tn256::supported(M, N, K, lda, ldb)) {
+        const int splits = tn256::pick_splits(M, N, K);
+        float* slab = (float*)ws;
+        float* slab_db = db ? slab + (size_t)splits * M * N : nullptr;
+        int used = 0;
+        const int rc = tn256::launch(A, lda, B, ldb, slab, slab_db, M, N, K, splits, &used, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(ceil_div(MN / 4 + N, 256)), dim3(256), 0, s, slab, slab_db, C, db, MN, N, used);
+        VVAE_LAUNCH_CHECK();
+        return 0;
+    }
+    const int splits = pick_splits(M, N, K);
     int klen = (K + splits - 1) / splits;
     klen = (klen + KS - 1) / KS * KS;
     const int used = (K + klen - 1) / klen;               // splits that own at least one token
     GemmDims d{M, N, K, lda, ldb, klen};
     float* slab = (float*)ws;
     float* slab_db = db ? slab + (size_t)splits * M * N : nullptr;
-    hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(M / BM, N / BN, used), dim3(256), LDS_BYTES, s, (const bf16_t*)A, (const bf16_t*)B, slab,
                        slab_db, d);
     VVAE_LAUNCH_CHECK();
-    const long MN = (long)M * N;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(ceil_div(MN / 4 + N, 256)), dim3(256), 0, s, slab, slab_db, C, db, MN, N, used);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+// Test / bench hook: 0 routes every shape through the 128 x 128 kernel (default 1: 256 x 256 tiles where M, N allow).
+extern "C" int vvae_gemm_tn_use_big_tiles(int on) { g_tn_big = on != 0; return 0; }

@@ -1,0 +1,222 @@
+// Weight-gradient GEMM, large-tile form: slab[split][M][N] (fp32) = sum over the split's tokens k of A[k][m] * B[k][n]
+// (A = layer input (tokens, in), B = output gradient (tokens, out), both bf16 token-major), M and N multiples of 256.
+// Called through vvae_gemm_tn_bf16 (gemm_tn.hip), which also runs the fixed-order slab reduction.
+//
+// Why a second kernel: the 128 x 128 tile kernel moves (128 + 128) * 2 B per 128 * 128 MACs through L2 -> LDS (600 MB for the
+// 768 x 1536 x 16 384 product) and measures at the ~11-13 TB/s this chip sustains on that path, not at its matrix rate.
+// A 256 x 256 tile halves the bytes per MAC; the loop then needs ~32 B/clk per CU and is paced by the matrix pipe.
+//
+//   * 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the tile = 4 x 2 v_mfma_f32_32x32x16_bf16 accumulators (128 VGPRs).
+//   * operands are K-major in memory (rows = tokens), so fragments (8 consecutive k per lane) come out of LDS through
+//     ds_read_b64_tr_b16; the LDS image is [32 tokens][256 channels] bf16 = 512-byte rows filled by LDS-DMA
+//     (global_load_lds_dwordx4, one piece = 2 whole token rows: full 128-byte lines on the L2 side, no VGPR round trip).
+//     Window swizzle: the 32-byte window W of token row r lives at W ^ (2 (r & 3)) -- applied on the per-lane SOURCE address
+//     of the DMA and on the read address -- so the 4 rows x 2 windows a half-wave transposes cover all 64 banks.
+//   * ring of 4 stages (32 tokens each, 128 KB), tiles issued three steps ahead, counted s_waitcnt vmcnt(8), raw s_barrier;
+//     waves 4-7 run one segment behind waves 0-3, so on every SIMD one wave multiplies (16 MFMAs) while its partner reads the
+//     next step's fragments, issues its DMA pieces and waits (the structure of gemm_nt.hip).
+//   * split-K over workgroups (tiles x splits ~ one workgroup per CU); partial tiles go to fp32 slabs with 128-byte row
+//     segments per store, summed in fixed order by gemm_tn_reduce_kernel: deterministic, no float atomics.
+//   * the bias gradient (column sums of B) rides along as an all-ones row operand in the m-tile-0 workgroups.
+#include "common.hpp"
+
+namespace tn256 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 256, BN = 256, KS = 32, S = 4;
+constexpr int ROW = 512;                       // bytes per token row of one operand tile
+constexpr int OPB = KS * ROW;                  // 16 KB per operand and stage
+constexpr int STAGE = 2 * OPB;
+constexpr int LDS_BYTES = S * STAGE;           // 128 KB
+constexpr int P = 4;                           // DMA pieces per wave and stage (2 A + 2 B)
+
+struct Dims { int M, N, K, lda, ldb, klen, tiles_m, tiles_n; };
+
+template <int N> __device__ __forceinline__ void wait_vm()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
+}
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// 8 k-values (two transposed 4 x 16 reads, token rows +0..3 and +4..7) of a 32-channel block for a 32x32x16 MFMA operand
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p)
+{
+    typedef __attribute__((address_space(3))) s16x4v* lds_ptr;
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * ROW));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ slab,
+                                                            float* __restrict__ slab_db, Dims d)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+
+    // workgroup -> (split, tile): consecutive logical ids (tiles of one split are neighbours: they share the split's operand
+    // panels) stay on one XCD.  Bijective form of the XCD remap (grid size need not be a multiple of 8).
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int tiles = d.tiles_m * d.tiles_n;
+    const int sp = L / tiles, tile = L - sp * tiles;
+    const int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int k_beg = sp * d.klen;
+    int k_end = k_beg + d.klen;
+    if (k_end > d.K) k_end = d.K;
+    const int nk = (k_end - k_beg) / KS;                         // >= 1 by construction of the grid
+
+    // ---- DMA: piece = 2 token rows x 512 B.  lane -> row 2*piece + (lane >> 5), slot lane & 31; the slot holds source chunk
+    //      slot ^ ((row & 3) << 2).  Wave w issues pieces 2w, 2w+1 of A and of B.
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 2 * (2 * wave + i) + (lane >> 5);
+        const int chunk = (lane & 31) ^ ((row & 3) << 2);
+        ga[i] = A + (long)(k_beg + row) * d.lda + m0 + chunk * 8;
+        gb[i] = B + (long)(k_beg + row) * d.ldb + n0 + chunk * 8;
+    }
+    auto issue = [&](int t, int stage) {
+        unsigned char* sb = smem + stage * STAGE + (2 * wave) * 1024;
+        const long ka = (long)t * KS * d.lda, kb = (long)t * KS * d.ldb;
+        glds16(ga[0] + ka, sb);
+        glds16(ga[1] + ka, sb + 1024);
+        glds16(gb[0] + kb, sb + OPB);
+        glds16(gb[1] + kb, sb + OPB + 1024);
+    };
+    auto wait_tiles = [&](int tiles_in_flight) {
+        if (tiles_in_flight >= 2) wait_vm<2 * P>(); else if (tiles_in_flight == 1) wait_vm<P>(); else wait_vm<0>();
+    };
+
+    // ---- transposed fragment reads.  lane: p = lane & 3 (4-channel group), q = (lane >> 2) & 3 (token row in the 4-row
+    //      group), mh = (lane >> 4) & 1 (16-channel half of the 32-block), kh = lane >> 5 (8-token half of the k16 step).
+    //      Token row = 16 ks + 8 kh + 4 u + q (u = the two reads of tr_frag); 32-channel block b lives at window (b ^ q).
+    const int p4 = lane & 3, qr = (lane >> 2) & 3, mh = (lane >> 4) & 1, kh = lane >> 5;
+    const int lrow = (8 * kh + qr) * ROW + mh * 32 + p4 * 8;
+    int aoff[4], boff[2];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) aoff[ib] = lrow + ((4 * wm + ib) ^ qr) * 64;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) boff[jb] = OPB + lrow + ((2 * wn + jb) ^ qr) * 64;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f32x16 accb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[j][e] = 0.f;
+    const bool do_bias = slab_db != nullptr && tm == 0 && wm == 0;           // wave-uniform
+    const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+    // ---- main loop (see gemm_nt.hip):   waves 0-3:  L0 | C0 | L1 | C1 | ...      waves 4-7:  -- | L0 | C0 | L1 | ...
+    const int npro = nk < S ? nk : S;
+    for (int t = 0; t < npro; ++t) issue(t, t);
+    wait_tiles(npro - 1);
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
+    int st = 0;
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* cur = smem + st * STAGE;
+        bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) af[ks][ib] = tr_frag(cur + aoff[ib] + ks * 16 * ROW);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) bfr[ks][jb] = tr_frag(cur + boff[jb] + ks * 16 * ROW);
+        }
+        if (t >= 1 && t - 1 + S < nk) issue(t - 1 + S, st == 0 ? S - 1 : st - 1);   // the stage tile t-1 used is free
+        const int issued = t + S < nk ? t + S : nk;
+        wait_tiles(issued - t - 2);                              // tile t+1 has landed; the rest may stay in flight
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+                    acc[ib][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][ib], bfr[ks][jb], acc[ib][jb], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) accb[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[ks][jb], accb[jb], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        st = st + 1 == S ? 0 : st + 1;
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();
+
+    // ---- partial tile -> slab.  acc[ib][jb][r]: m = 128 wm + 32 ib + 8 (r/4) + 4 kh + r%4, n = 64 wn + 32 jb + (lane & 31):
+    //      one store instruction writes two 128-byte row segments
+    float* out = slab + (long)sp * d.M * d.N;
+    const int nl = lane & 31;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 128 * wm + 32 * ib + 8 * (r >> 2) + 4 * kh + (r & 3);
+                out[(long)m * d.N + n0 + 64 * wn + 32 * jb + nl] = acc[ib][jb][r];
+            }
+    if (do_bias && kh == 0) {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) slab_db[(long)sp * d.N + n0 + 64 * wn + 32 * jb + nl] = accb[jb][0];
+    }
+}
+
+// splits so that tiles x splits ~ one workgroup per CU, each with at least 8 k-steps
+int pick_splits(int M, int N, int K)
+{
+    const int tiles = (M / BM) * (N / BN);
+    int s = 256 / tiles;
+    const int max_s = K / (8 * KS);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return s;
+}
+
+bool supported(int M, int N, int K, int lda, int ldb)
+{
+    return M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % KS == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N;
+}
+
+// launches the partial-tile kernel; returns the number of slabs written through *used (0 on error) and a status
+int launch(const void* A, int lda, const void* B, int ldb, float* slab, float* slab_db, int M, int N, int K, int splits, int* used,
+           hipStream_t s)
+{
+    int klen = (K + splits - 1) / splits;
+    klen = (klen + KS - 1) / KS * KS;
+    *used = (K + klen - 1) / klen;
+    Dims d{M, N, K, lda, ldb, klen, M / BM, N / BN};
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(d.tiles_m * d.tiles_n * *used), dim3(512), LDS_BYTES, s, (const bf16_t*)A, (const bf16_t*)B,
+                       slab, slab_db, d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace tn256

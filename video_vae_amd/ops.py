@@ -757,6 +757,35 @@ def layer_norm_fork(x, scale, bias=None, eps=1e-6):
     return _LayerNorm.apply(x, scale, bias, eps, True)
 
 
+# --------------------------------------------------------------------------------------------- dense NT GEMM (Linear fwd / dgrad)
+EPI_NONE, EPI_RES, EPI_SILU, EPI_MUL_DSILU = 0, 1, 2, 3
+
+
+def gemm_nt_supported(a, b):
+    return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] == b.shape[1]
+            and lib().vvae_gemm_nt_supported(a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), b.shape[0]) == 1)
+
+
+def gemm_nt(a, b, bias=None, res=None, epi=EPI_NONE):
+    """epi(a (M, K) @ b (N, K)^T + bias) in bf16 with fp32 accumulation (no autograd).  epi = EPI_RES adds ``res`` (M, N);
+    EPI_SILU returns (silu(h), h); EPI_MUL_DSILU multiplies by silu'(res)."""
+    m, k = a.shape
+    n = b.shape[0]
+    c = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    c2 = torch.empty((m, n), dtype=torch.bfloat16, device=a.device) if epi == EPI_SILU else None
+    if res is not None:
+        res = res.reshape(m, n)
+        if res.stride(1) != 1:
+            res = res.contiguous()
+    nbytes = (m * k + n * k + m * n * (1 + (epi != EPI_NONE))) * 2
+    check(_launch(f"gemm_nt {m}x{n} K{k} epi{epi}", nbytes, 2 * m * n * k, "gemm_nt_kernel",
+                  lambda: lib().vvae_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), n, _p(bias), _p(res),
+                                                  res.stride(0) if res is not None else 0, _p(c2), n, epi, m, n, k, _stream())),
+          "vvae_gemm_nt_bf16")
+    return (c, c2) if epi == EPI_SILU else c
+
+
 # --------------------------------------------------------------------------------------------- dense weight-gradient GEMM
 def gemm_tn_supported(a, b):
     return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
