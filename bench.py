@@ -31,6 +31,16 @@ PROD = dict(height=256, width=256, channels=3, patch_size=16, encoder_depth=9, d
             qkv_features=512, max_temporal_len=64, spatial_compression_rate=8, unembedding_upsample_rate=4)
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: separate
+    FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,20 +216,25 @@ def main():
         timed_in = ("eager steps right after the timed region (graph replay cannot host events)" if graphed
                     else "the timed region")
         if summ:
-            # the dominant hand-written launch = the tagged (kernel, shape) with the largest total time per step; its bound is
-            # set by arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 FLOP/B)
-            tag, top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
-            sec = top["avg_ms"] * 1e-3
-            gbs, tfs = top["bytes"] / sec / 1e9, top["flops"] / sec / 1e12
-            mfma_bound = top["bytes"] > 0 and top["flops"] / top["bytes"] > MFMA_PEAK_TFS * 1e3 / HBM_PEAK_GBS
-            fam_ms = sum(v["total_ms"] for v in summ.values() if v["kernel"] == top["kernel"]) / nsteps_timed
+            # the dominant hand-written kernel = the kernel (all its tagged shapes together) with the largest total time per
+            # step; per-launch figures are means over its launches, which is what `rocprofv3 --stats` averages for that kernel
+            # name.  Its bound is set by arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 FLOP/B).
+            fam = {}
+            for v in summ.values():
+                f = fam.setdefault(v["kernel"], dict(n=0, ms=0.0, bytes=0.0, flops=0.0))
+                f["n"] += v["n"]; f["ms"] += v["total_ms"]; f["bytes"] += v["bytes"] * v["n"]; f["flops"] += v["flops"] * v["n"]
+            kname, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
+            avg_ms = top["ms"] / top["n"]
+            b_l, f_l = top["bytes"] / top["n"], top["flops"] / top["n"]
+            gbs, tfs = b_l / (avg_ms * 1e-3) / 1e9, f_l / (avg_ms * 1e-3) / 1e12
+            mfma_bound = b_l > 0 and f_l / b_l > MFMA_PEAK_TFS * 1e3 / HBM_PEAK_GBS
             out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": tfs if mfma_bound else gbs,
                                "peak": MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                               "frac": (tfs / MFMA_PEAK_TFS) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": None,
-                               "kernel": top["kernel"], "launch": tag, "avg_ms": top["avg_ms"], "launches_timed": top["n"],
-                               "launches_per_step": top["n"] / nsteps_timed, "alg_bytes_per_launch": top["bytes"],
-                               "alg_flops_per_launch": top["flops"], "alg_GBps": gbs, "alg_TFLOPps": tfs,
-                               "kernel_ms_per_step": fam_ms, "timed_in": timed_in}
+                               "frac": (tfs / MFMA_PEAK_TFS) if mfma_bound else (gbs / HBM_PEAK_GBS),
+                               "traffic": measured_traffic(kname), "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
+                               "launches_per_step": top["n"] / nsteps_timed, "alg_bytes_per_launch": b_l,
+                               "alg_flops_per_launch": f_l, "alg_GBps": gbs, "alg_TFLOPps": tfs,
+                               "kernel_ms_per_step": top["ms"] / nsteps_timed, "timed_in": timed_in}
             rows = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]
             out["kernels"] = [{"launch": k, "kernel": v["kernel"], "per_step": v["n"] / nsteps_timed, "avg_ms": round(v["avg_ms"], 4),
                                "ms_per_step": round(v["total_ms"] / nsteps_timed, 3),

@@ -801,7 +801,8 @@ def gemm_tn(a, b, want_colsum=True):
     db = torch.empty((n,), dtype=torch.float32, device=a.device) if want_colsum else None
     wsb = lib().vvae_gemm_tn_ws_bytes(m, n, k)
     ws, wsb = _ws(wsb, a.device)
-    check(_launch(f"gemm_tn {m}x{n} K{k}", (k * (m + n)) * 2 + m * n * 4, 2 * m * n * k, "gemm_tn_bf16_kernel",
+    kern = ("gemm_tn256_kernel" if m % 256 == 0 and n % 256 == 0 and k % 32 == 0 else "gemm_tn_bf16_kernel") + " + gemm_tn_reduce_kernel"
+    check(_launch(f"gemm_tn {m}x{n} K{k}", (k * (m + n)) * 2 + m * n * 4, 2 * m * n * k, kern,
                   lambda: lib().vvae_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(db), m, n, k, _p(ws), wsb, _stream())),
           "vvae_gemm_tn_bf16")
     return c, db
