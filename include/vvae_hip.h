@@ -134,6 +134,18 @@ int vvae_qk_prep_bwd(const void* qkv, int ld, const void* dq, long dq_ts, long d
                      const float* cos_table, const float* sin_table, float* part, long tokens, int S, int heads, int D,
                      float eps, int dtype, void* stream);
 
+/* ---- fused spatial attention (sequence = h*w patches of a frame, train/layers.py:153-170,217-221): q/k-norm + RoPE +
+ *      softmax(QK^T/sqrt(D))V in one kernel per direction; bf16, head_dim 64, S % 32 == 0, S <= 256, no mask.
+ *      qkv (A*S, 3*heads*D) row pitch ld; out (A*S, heads*D) row pitch ldo; lse2 fp32 (A*heads, S) (base-2 log-sum-exp). ---- */
+int vvae_spatial_attn_supported(int S, int D, int dtype);
+int vvae_spatial_attn_fwd(const void* qkv, int ld, void* out, int ldo, float* lse2, const float* q_scale, const float* k_scale,
+                          const float* cos_table, const float* sin_table, int A, int S, int heads, int D, float eps, int dtype,
+                          void* stream);
+/* part: fp32 (A*heads, 2, D) per-(sequence, head) partials of [dq_scale | dk_scale]; dqkv fully written (q, k, v sections). */
+int vvae_spatial_attn_bwd(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse2,
+                          void* dqkv, int lddq, const float* q_scale, const float* k_scale, const float* cos_table,
+                          const float* sin_table, float* part, int A, int S, int heads, int D, float eps, int dtype, void* stream);
+
 /* ---- LayerNorm(eps, fast variance, fp32 stats): nnx.LayerNorm at train/layers.py:17,152,155-156,178.
  *      x row r at x + (r / inner) * outer_pitch + (r % inner) * inner_pitch (elements); y, dy, dx contiguous (rows, C).
  *      bwd writes per-workgroup partials part (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy]. ---- */

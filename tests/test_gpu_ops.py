@@ -3,6 +3,7 @@
 fp32 bar: rtol 1e-3 / atol 1e-4 (BASELINE.json:north_star).  bf16 storage: the oracle is run with dtype=bf16
 emulation and compared at bf16 resolution (rtol 2e-2, atol scaled).
 """
+import math
 import pytest
 import torch
 
@@ -249,10 +250,20 @@ def test_qk_prep_kernels(dev, a, s, heads, d, dtype):
     assert torch.equal(dqkv[..., 2 * hd:].float().cpu(), gv.transpose(1, 2).reshape(a, s, hd).to(dtype).float()), "dv is a copy"
 
 
-@pytest.mark.parametrize("a,s,heads,d", [(3, 256, 8, 64), (2, 96, 4, 32)])
-def test_spatial_attention_core_bf16(dev, a, s, heads, d):
-    """prep + library flash core + prep backward against the oracle's attention (reference train/layers.py:153-170)."""
+@pytest.mark.parametrize("a,s,heads,d", [(3, 256, 8, 64), (2, 96, 4, 32), (2, 160, 3, 64), (1, 32, 2, 64), (2, 224, 2, 64)])
+@pytest.mark.parametrize("library_core", [False, True])
+def test_spatial_attention_core_bf16(dev, a, s, heads, d, library_core):
+    """Spatial attention against the oracle (reference train/layers.py:153-170), forward and backward.
+    library_core=False: the fused MFMA kernels where they apply (head_dim 64); True: prep kernels + library flash core."""
     ops = _ops()
+    ops.SPATIAL_FORCE_LIBRARY_CORE[0] = library_core
+    try:
+        _spatial_core_case(ops, dev, a, s, heads, d)
+    finally:
+        ops.SPATIAL_FORCE_LIBRARY_CORE[0] = False
+
+
+def _spatial_core_case(ops, dev, a, s, heads, d):
     dtype = torch.bfloat16
     qkv = rnd((a, s, 3 * heads * d), 70).to(dtype).float()
     qs = 1 + 0.2 * rnd((d,), 71); ks = 1 + 0.2 * rnd((d,), 72)
@@ -269,6 +280,28 @@ def test_spatial_attention_core_bf16(dev, a, s, heads, d):
     assert_close_scaled(xg.grad, xo.grad, rel=5e-2, what="dqkv")
     assert_close_scaled(qsg.grad, qso.grad, rel=5e-2, what="dq_scale")
     assert_close_scaled(ksg.grad, kso.grad, rel=5e-2, what="dk_scale")
+
+
+@pytest.mark.parametrize("a,s,heads", [(3, 256, 8), (2, 96, 4), (5, 32, 2), (1, 160, 3)])
+def test_spatial_attention_fused_forward(dev, a, s, heads):
+    """One-kernel q/k-norm + RoPE + softmax(QK^T/sqrt(D))V (MFMA, head_dim 64) against the oracle's attention."""
+    ops = _ops()
+    d, dtype = 64, torch.bfloat16
+    qkv = rnd((a, s, 3 * heads * d), 75).to(dtype).float()
+    qs = 1 + 0.2 * rnd((d,), 76); ks = 1 + 0.2 * rnd((d,), 77)
+    cos, sin = OL.rope_tables(d, 256)
+    yo = _attn_ref(qkv, qs, ks, None, heads, 256, dtype)
+    xg = qkv.to(dev, dtype)
+    assert ops.spatial_attn_fused_supported(xg, heads)
+    yg, lse2 = ops.spatial_attn_fwd_raw(xg, qs.to(dev), ks.to(dev), cos.to(dev), sin.to(dev), heads)
+    assert_close(yg, yo, rtol=3e-2, atol=3e-2, what="out")
+    # log-sum-exp against an fp32 recomputation from the oracle's rotated q, k
+    q, k, v = torch.chunk(qkv, 3, dim=-1)
+    sp = lambda z: z.reshape(a, s, heads, d)
+    qr, kr = OL.rope(O.layer_norm(sp(q), qs, None, dtype), O.layer_norm(sp(k), ks, None, dtype), cos, sin, dtype)
+    sc = torch.einsum("aqhd,akhd->ahqk", qr, kr) / d ** 0.5
+    want = torch.logsumexp(sc, -1).reshape(a * heads, s) / math.log(2.0)
+    assert_close(lse2, want, rtol=1e-2, atol=2e-2, what="lse2")
 
 
 def test_temporal_attention_masked_equals_truncated(dev):

@@ -530,6 +530,66 @@ def qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps=1e-6):
     return dqkv, tot[0], tot[1]
 
 
+SPATIAL_FORCE_LIBRARY_CORE = [False]      # test hook: keep the prep kernels + library flash core even where the fused kernels apply
+
+
+def spatial_attn_fused_supported(qkv, heads):
+    a, s, c3 = qkv.shape
+    return (qkv.is_cuda and qkv.dtype == torch.bfloat16
+            and lib().vvae_spatial_attn_supported(s, c3 // (3 * heads), DT[qkv.dtype]) == 1)
+
+
+def spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads, eps=1e-6):
+    """Fused q/k-norm + RoPE + attention forward on (a, s, 3*heads*64) bf16 -> (out (a, s, heads*64), lse2 (a*heads, s)) (no autograd)."""
+    a, s, c3 = qkv.shape
+    hd = c3 // 3
+    d = hd // heads
+    out = torch.empty((a, s, hd), dtype=qkv.dtype, device=qkv.device)
+    lse2 = torch.empty((a * heads, s), dtype=torch.float32, device=qkv.device)
+    nbytes = a * s * (c3 + hd) * qkv.element_size()
+    check(_launch(f"spatial_attn_fwd S{s} D{d}", nbytes, 4 * a * heads * s * s * d, "sattn_fwd_kernel",
+                  lambda: lib().vvae_spatial_attn_fwd(_p(qkv), c3, _p(out), hd, _p(lse2), _p(qs), _p(ks), _p(cos), _p(sin), a, s, heads, d,
+                                                      eps, _dt(qkv), _stream())), "vvae_spatial_attn_fwd")
+    return out, lse2
+
+
+def spatial_attn_bwd_raw(qkv, out, lse2, dout, qs, ks, cos, sin, heads, eps=1e-6):
+    """-> (dqkv (a, s, 3*heads*64), dq_scale (64), dk_scale (64)) of the fused spatial attention (no autograd)."""
+    a, s, c3 = qkv.shape
+    hd = c3 // 3
+    d = hd // heads
+    dqkv = torch.empty((a, s, c3), dtype=qkv.dtype, device=qkv.device)
+    part = torch.empty((a * heads, 2, d), dtype=torch.float32, device=qkv.device)
+    nbytes = a * s * (2 * c3 + 2 * hd) * qkv.element_size()
+    check(_launch(f"spatial_attn_bwd S{s} D{d}", nbytes, 14 * a * heads * s * s * d, "sattn_bwd_kernel",
+                  lambda: lib().vvae_spatial_attn_bwd(_p(qkv), c3, _p(out), hd, _p(dout), hd, _p(lse2), _p(dqkv), c3, _p(qs), _p(ks),
+                                                      _p(cos), _p(sin), _p(part), a, s, heads, d, eps, _dt(qkv), _stream())),
+          "vvae_spatial_attn_bwd")
+    tot = sum_rows(part)
+    return dqkv, tot[0], tot[1]
+
+
+class _SpatialAttnFused(torch.autograd.Function):
+    """q/k-norm + RoPE + softmax(QK^T/sqrt(D))V, one hand-written kernel per direction (reference train/layers.py:153-170, :217-221)."""
+
+    @staticmethod
+    def forward(ctx, qkv, q_scale, k_scale, cos, sin, heads, eps):
+        qkv = qkv.contiguous()
+        qs, ks = _f32(q_scale), _f32(k_scale)
+        out, lse2 = spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads, eps)
+        ctx.save_for_backward(qkv, qs, ks, cos, sin, out, lse2)
+        ctx.misc = (heads, eps, q_scale.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qs, ks, cos, sin, out, lse2 = ctx.saved_tensors
+        heads, eps, pdtype = ctx.misc
+        do = do.to(qkv.dtype).contiguous()
+        dqkv, dqs, dks = spatial_attn_bwd_raw(qkv, out, lse2, do, qs, ks, cos, sin, heads, eps)
+        return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None
+
+
 class _SpatialAttn(torch.autograd.Function):
     """q/k-norm + RoPE prep (HIP, one launch) -> library flash-attention core -> (backward) core -> prep backward (HIP, one launch).
 
@@ -582,6 +642,8 @@ def spatial_attention_supported(qkv, heads, max_len):
 
 def spatial_attention_core(qkv, q_scale, k_scale, cos, sin, heads, eps=1e-6):
     """q_norm/k_norm -> RoPE -> softmax(QK^T/sqrt(D)) V over (a, s, 3*heads*D), no mask (reference train/layers.py:153-170)."""
+    if spatial_attn_fused_supported(qkv, heads) and not SPATIAL_FORCE_LIBRARY_CORE[0]:
+        return _SpatialAttnFused.apply(qkv, q_scale, k_scale, cos, sin, heads, eps)
     return _SpatialAttn.apply(qkv, q_scale, k_scale, cos, sin, heads, eps)
 
 
