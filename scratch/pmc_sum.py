@@ -6,7 +6,7 @@ for f in glob.glob(root + "/p*/*/*counter_collection.csv"):
         k = r["Kernel_Name"][:70]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
-    if not any(x in k for x in ("gemm", "Cijk", "conv3d", "layernorm", "tattn")):
+    if not any(x in k for x in ("gemm", "Cijk", "conv3d", "layernorm", "tattn", "sattn")):
         continue
     print(k)
     for c, v in sorted(cs.items()):

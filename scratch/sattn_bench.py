@@ -1,0 +1,29 @@
+import torch, sys
+sys.path.insert(0, ".")
+from video_vae_amd import ops
+sys.path.insert(0, "tests")
+from oracle import layers as OL
+dev = "cuda"
+def tmg(f, n=10):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3): f()
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(n): f()
+        g.replay(); st.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(5): g.replay()
+        e1.record(st); st.synchronize()
+    return e0.elapsed_time(e1) / (5 * n) * 1e3
+a, s, heads, d = 64, 256, 8, 64
+qkv = torch.randn(a, s, 3 * heads * d, device=dev, dtype=torch.bfloat16)
+qs = torch.ones(d, device=dev); ks = torch.ones(d, device=dev)
+cos, sin = OL.rope_tables(d, 256); cos, sin = cos.to(dev), sin.to(dev)
+do = torch.randn(a, s, heads * d, device=dev, dtype=torch.bfloat16)
+out, lse2 = ops.spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads)
+tf = tmg(lambda: ops.spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads))
+tb = tmg(lambda: ops.spatial_attn_bwd_raw(qkv, out, lse2, do, qs, ks, cos, sin, heads))
+print(f"sattn fwd {tf:.1f} us  bwd(+sum_rows) {tb:.1f} us")

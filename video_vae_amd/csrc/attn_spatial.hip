@@ -83,6 +83,31 @@ __device__ __forceinline__ int img_off(int row, int c) { return row * SROW + ((c
 // byte offset of the 8 bytes a transposed read takes at (row, 16-channel block cb (0..3), 4-channel group p)
 __device__ __forceinline__ int img_off_tr(int row, int cb, int p) { return row * SROW + ((((2 * cb + (p >> 1)) ^ gsw(row))) << 4) + (p & 1) * 8; }
 
+// Lane-constant parts of the fragment addresses (the swizzle term of a row depends on row bits 1..3 only, which a 32-row block
+// offset never touches): a row fragment is img + blk * 32 * SROW + row[ks]; a transposed fragment of the 16-row group u of
+// block blk and channel tile dt is the pair img + (blk * 32 + 16 u) * SROW + tr[dt][0 | 1] (token rows +0..3 and +8..11).
+struct FragAddr {
+    int row[4], tr[2][2];
+    __device__ __forceinline__ FragAddr(int lane) {
+        const int j = lane & 31, kh = lane >> 5, p4 = lane & 3, qr = (lane >> 2) & 3, mh = (lane >> 4) & 1;
+        const int gj = gsw(j), gl = (((qr >> 1) & 1) << 2) | kh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) row[ks] = j * SROW + (((2 * ks + kh) ^ gj) << 4);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+                tr[dt][x] = (4 * kh + qr + 8 * x) * SROW + (((2 * (2 * dt + mh) + (p4 >> 1)) ^ (gl | (x << 1))) << 4) + (p4 & 1) * 8;
+    }
+    __device__ __forceinline__ bf16x8 rowfrag(const unsigned char* img, int blk, int ks) const {
+        return *reinterpret_cast<const bf16x8*>(img + blk * 32 * SROW + row[ks]);
+    }
+    __device__ __forceinline__ bf16x8 trfrag(const unsigned char* img, int blk, int u, int dt) const {
+        const unsigned char* b = img + (blk * 32 + 16 * u) * SROW;
+        return tr_pair(b + tr[dt][0], b + tr[dt][1]);
+    }
+};
+
 // Stage rows [0, S) of one head into a swizzled LDS image: K path applies k_norm + RoPE, V path copies.  256 threads, 4 lanes per
 // row (attn_rows.hpp slices: lane p owns channels [8p, 8p+8) and [32+8p, 32+8p+8) = chunks p and 4+p).
 template <bool NORM>
@@ -91,7 +116,7 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, long 
                                            const float* __restrict__ sinT)
 {
     const int p = threadIdx.x & 3;
-    for (int row = threadIdx.x >> 2; row < S; row += 64) {
+    for (int row = threadIdx.x >> 2; row < S; row += (int)(blockDim.x >> 2)) {
         float x[16];
         load_row<bf16_t, SD, 4>(src + (tok0 + row) * ld, p, x);
         if (NORM) ln_rope_row<bf16_t, SD, 4>(x, p, scale, eps, cosT + (long)row * SD, sinT + (long)row * SD);
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
     __syncthreads();
 
     const int j = lane & 31, kh = lane >> 5;
-    const int p4 = lane & 3, qr = (lane >> 2) & 3, mh = (lane >> 4) & 1;
+    const FragAddr fa(lane);
     const float c2 = rsqrtf((float)SD) * 1.44269504088896341f;          // softmax scale in the exp2 domain
 
     for (int qb = wave; qb < NKB; qb += 4) {
@@ -165,8 +190,7 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
                     for (int e = 0; e < 16; ++e) s[g][e] = 0.f;
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + img_off((kb0 + g) * 32 + j, 2 * ks + kh));
-                        s[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[g], 0, 0, 0);
+                        s[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Ks, kb0 + g, ks), qf[ks], s[g], 0, 0, 0);
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) mg = fmaxf(mg, s[g][e]);
@@ -191,12 +215,9 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { pv[e] = exp2f((s[g][8 * u + e] - m) * c2); l += pv[e]; }
                         const bf16x8 pf = pack8(pv);                 // the reference multiplies V by probabilities in the value dtype
-                        const int r0 = (kb0 + g) * 32 + 16 * u + 4 * kh + qr;
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const bf16x8 vf = tr_pair(Vs + img_off_tr(r0, 2 * dt + mh, p4), Vs + img_off_tr(r0 + 8, 2 * dt + mh, p4));
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
-                        }
+                        for (int dt = 0; dt < 2; ++dt)
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(Vs, kb0 + g, u, dt), pf, o[dt], 0, 0, 0);
                     }
                 }
             }
@@ -287,12 +308,13 @@ __device__ __forceinline__ void store_acc_row(bf16_t* __restrict__ row, int kh, 
 }
 
 // part: (A*H, 2, 64) fp32 = per-(sequence, head) partial of [dq_scale | dk_scale] (summed by the caller).
-// Phase A (LDS = Q', dO images): every wave owns 32-key tiles and walks all queries: dV^T, dK^T (scores as [query][key], so the
-// contraction over queries is the register index).  Phase B (LDS = K', V images): every wave owns 32-query tiles and walks all
-// keys: dQ^T (scores as [key][query]).  Recomputing the score tile in both orientations costs two extra products out of seven
-// and saves every transpose through LDS; the kernel is bound by its HBM streams, not by the matrix pipe.
+// One workgroup of 8 waves per (sequence, head); Q' = rope(q_norm(Q)), K' = rope(k_norm(K)), V and dO are staged ONCE as swizzled LDS
+// images (128 KB at S = 256) and every operand of the seven products is a row or a transposed fragment of one of them.
+// Phase A: every wave owns a 32-key tile and walks all queries: dV^T, dK^T (scores as [query][key], so the contraction over
+// queries is the register index).  Phase B: every wave owns a 32-query tile and walks all keys: dQ^T (scores as [key][query]).
+// Recomputing the score tile in both orientations costs two extra products out of seven and saves every transpose through LDS.
 template <int NKB>
-__global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ out, int ldo,
+__global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ out, int ldo,
                                                            const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ lse2,
                                                            bf16_t* __restrict__ dqkv, int lddq, const float* __restrict__ q_scale,
                                                            const float* __restrict__ k_scale, const float* __restrict__ cosT,
@@ -300,11 +322,13 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restr
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int S = 32 * NKB;
-    unsigned char* I0 = smem;                         // phase A: Q' image; phase B: K' image
-    unsigned char* I1 = smem + S * SROW;              // phase A: dO image; phase B: V image
-    float* lseS = reinterpret_cast<float*>(smem + 2 * S * SROW);
+    unsigned char* Qs = smem;
+    unsigned char* Ks = smem + S * SROW;
+    unsigned char* Vs = smem + 2 * S * SROW;
+    unsigned char* Gs = smem + 3 * S * SROW;          // dO
+    float* lseS = reinterpret_cast<float*>(smem + 4 * S * SROW);
     float* delS = lseS + S;
-    float* red = delS + S;                            // [4 waves][2][64] scale-gradient partials
+    float* red = delS + S;                            // [8 waves][2][64] scale-gradient partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a = blockIdx.x / d.H, h = blockIdx.x - a * d.H;
     const int HD = d.H * SD;
@@ -312,56 +336,57 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restr
     const bf16_t* base = qkv + h * SD;
     const bf16_t* gbase = dout + h * SD;
     const int j = lane & 31, kh = lane >> 5;
-    const int p4 = lane & 3, qr = (lane >> 2) & 3, mh = (lane >> 4) & 1;
+    const FragAddr fa(lane);
     const float sm_scale = rsqrtf((float)SD);
     const float c2 = sm_scale * 1.44269504088896341f;
 
-    // ---- phase A staging: Q' (q_norm + RoPE), dO, delta = rowsum(dO * O), lse
-    stage_rows<true>(base, tok0, ld, I0, S, q_scale, d.eps, cosT, sinT);
-    stage_rows<false>(gbase, tok0, lddo, I1, S, nullptr, 0.f, nullptr, nullptr);
-    {
+    // ---- staging: Q' and K' (norm + RoPE), V, dO, delta = rowsum(dO * O), lse
+    stage_rows<true>(base, tok0, ld, Qs, S, q_scale, d.eps, cosT, sinT);
+    stage_rows<true>(base + HD, tok0, ld, Ks, S, k_scale, d.eps, cosT, sinT);
+    stage_rows<false>(base + 2 * HD, tok0, ld, Vs, S, nullptr, 0.f, nullptr, nullptr);
+    {                                                 // dO image + delta in one pass over dO
         const int p = threadIdx.x & 3;
-        for (int row = threadIdx.x >> 2; row < S; row += 64) {
+        for (int row = threadIdx.x >> 2; row < S; row += 128) {
             float go[16], oo[16];
             load_row<bf16_t, SD, 4>(gbase + (tok0 + row) * lddo, p, go);
             load_row<bf16_t, SD, 4>(out + (tok0 + row) * ldo + h * SD, p, oo);
-            float dl = 0.f;
+            float dl = 0.f, lo[8], hi[8];
 #pragma unroll
             for (int i = 0; i < 16; ++i) dl += go[i] * oo[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { lo[e] = go[e]; hi[e] = go[8 + e]; }
+            VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(Gs + img_off(row, p)), lo);
+            VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(Gs + img_off(row, 4 + p)), hi);
             dl = lpr_sum<4>(dl);
             if (p == 0) { delS[row] = dl; lseS[row] = lse2[((long)a * d.H + h) * S + row]; }
         }
     }
-    // scale-gradient contributions of this lane's rows (accumulator layout) are summed over the 32 rows a half-wave holds and
-    // parked in LDS per wave at the end of each phase (k_scale after A, q_scale after B): 32 live registers, not 64
-    auto flush = [&](float (&ds)[2][16], int which) {
+    // scale-gradient contributions (accumulator layout: 32 channels per lane) are summed over the 32 rows a half-wave holds with
+    // DPP butterflies (xor 1, 2, then the half-row and row mirrors; one cross-row shuffle) at the end of each tile and added to
+    // this wave's slots in LDS: nothing of it stays live across the tile loops
+    auto add_scale_grad = [&](const float (&ds)[2][16], int which) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float t = ds[dt][r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                if (j == 0) red[(wave * 2 + which) * SD + 32 * dt + 8 * (r >> 2) + 4 * kh + (r & 3)] = t;
+                t += dpp_xor1(t);
+                t += dpp_xor2(t);
+                t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x141, 0xf, 0xf, true));      // row_half_mirror
+                t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x140, 0xf, 0xf, true));      // row_mirror
+                t += __shfl_xor(t, 16, 64);
+                if (j == 0) red[(wave * 2 + which) * SD + 32 * dt + 8 * (r >> 2) + 4 * kh + (r & 3)] += t;
             }
     };
-    float dsk[2][16];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dsk[dt][r] = 0.f;
+    for (int i = threadIdx.x; i < 16 * SD; i += 512) red[i] = 0.f;
     __syncthreads();
 
     // ---- phase A: dV, dK for the wave's key tiles
-    for (int kt = wave; kt < NKB; kt += 4) {
+    for (int kt = wave; kt < NKB; kt += 8) {
         const int key = kt * 32 + j;
-        bf16x8 kc[4], vc[4];
-        load_q_frags(base + HD + (tok0 + key) * ld, kh, key, k_scale, d.eps, cosT, sinT, kc);
-        {
-            const bf16_t* vrow = base + 2 * HD + (tok0 + key) * ld;
+        bf16x8 kc[4], vc[4];                          // the tile's own K' / V rows: column operands, constant over the query loop
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) vc[ks] = *reinterpret_cast<const bf16x8*>(vrow + 16 * ks + 8 * kh);
-        }
+        for (int ks = 0; ks < 4; ++ks) { kc[ks] = fa.rowfrag(Ks, kt, ks); vc[ks] = fa.rowfrag(Vs, kt, ks); }
         f32x16 dv[2], dk[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -374,38 +399,30 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restr
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(I0 + img_off(qb * 32 + j, 2 * ks + kh));
-                const bf16x8 gfr = *reinterpret_cast<const bf16x8*>(I1 + img_off(qb * 32 + j, 2 * ks + kh));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kc[ks], s, 0, 0, 0);        // [query][key]
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr, vc[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Qs, qb, ks), kc[ks], s, 0, 0, 0);        // [query][key]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Gs, qb, ks), vc[ks], dp, 0, 0, 0);
             }
-            // register r <-> query 32 qb + 8 (r/4) + 4 kh + r%4
-            float pv[16], dsv[16];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float4 l4 = *reinterpret_cast<const float4*>(lseS + qb * 32 + 8 * rg + 4 * kh);
-                const float4 d4 = *reinterpret_cast<const float4*>(delS + qb * 32 + 8 * rg + 4 * kh);
-                const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = exp2f(s[rg * 4 + e] * c2 - lq[e]);
-                    pv[rg * 4 + e] = pe;
-                    dsv[rg * 4 + e] = pe * (dp[rg * 4 + e] - dq4[e]);
-                }
-            }
+            // register r <-> query 32 qb + 8 (r/4) + 4 kh + r%4; the two register halves are the two k16 steps of the next products
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 float p8[8], s8[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { p8[e] = pv[8 * u + e]; s8[e] = dsv[8 * u + e]; }
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(lseS + qb * 32 + 8 * (2 * u + hh) + 4 * kh);
+                    const float4 d4 = *reinterpret_cast<const float4*>(delS + qb * 32 + 8 * (2 * u + hh) + 4 * kh);
+                    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = exp2f(s[8 * u + 4 * hh + e] * c2 - lq[e]);
+                        p8[4 * hh + e] = pe;
+                        s8[4 * hh + e] = pe * (dp[8 * u + 4 * hh + e] - dq4[e]);
+                    }
+                }
                 const bf16x8 pf = pack8(p8), sf = pack8(s8);
-                const int r0 = qb * 32 + 16 * u + 4 * kh + qr;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 gt = tr_pair(I1 + img_off_tr(r0, 2 * dt + mh, p4), I1 + img_off_tr(r0 + 8, 2 * dt + mh, p4));
-                    const bf16x8 qt = tr_pair(I0 + img_off_tr(r0, 2 * dt + mh, p4), I0 + img_off_tr(r0 + 8, 2 * dt + mh, p4));
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dv[dt], 0, 0, 0);   // dV^T[d][key] += dO^T[d][q] P[q][key]
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, dk[dt], 0, 0, 0);   // dK^T[d][key] += Q'^T[d][q] dS[q][key]
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(Gs, qb, u, dt), pf, dv[dt], 0, 0, 0);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(Qs, qb, u, dt), sf, dk[dt], 0, 0, 0);   // dK^T[d][key] += Q'^T[d][q] dS[q][key]
                 }
             }
         }
@@ -423,34 +440,15 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restr
         load_acc_row(base + HD + (tok0 + key) * ld, kh, xh);
         rope_ln_bwd_acc(g, xh, kh, k_scale, d.eps, cosT + (long)key * SD, sinT + (long)key * SD);
         store_acc_row(dqkv + (tok0 + key) * lddq + HD + h * SD, kh, g);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dsk[dt][r] += xh[dt][r];
+        add_scale_grad(xh, 1);
     }
-    flush(dsk, 1);
-    __syncthreads();
-
-    // ---- phase B staging: K' and V images over the same LDS
-    stage_rows<true>(base + HD, tok0, ld, I0, S, k_scale, d.eps, cosT, sinT);
-    stage_rows<false>(base + 2 * HD, tok0, ld, I1, S, nullptr, 0.f, nullptr, nullptr);
-    __syncthreads();
 
     // ---- phase B: dQ for the wave's query tiles
-    float dsq[2][16];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dsq[dt][r] = 0.f;
-    for (int qt = wave; qt < NKB; qt += 4) {
+    for (int qt = wave; qt < NKB; qt += 8) {
         const int qrow = qt * 32 + j;
         bf16x8 qc[4], gc[4];
-        load_q_frags(base + (tok0 + qrow) * ld, kh, qrow, q_scale, d.eps, cosT, sinT, qc);
-        {
-            const bf16_t* grow = gbase + (tok0 + qrow) * lddo;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) gc[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks + 8 * kh);
-        }
+        for (int ks = 0; ks < 4; ++ks) { qc[ks] = fa.rowfrag(Qs, qt, ks); gc[ks] = fa.rowfrag(Gs, qt, ks); }
         const float lq = lseS[qrow], dl = delS[qrow];
         f32x16 dq[2];
 #pragma unroll
@@ -464,10 +462,8 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restr
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(I0 + img_off(kb * 32 + j, 2 * ks + kh));
-                const bf16x8 vfr = *reinterpret_cast<const bf16x8*>(I1 + img_off(kb * 32 + j, 2 * ks + kh));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qc[ks], s, 0, 0, 0);        // [key][query]
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, gc[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Ks, kb, ks), qc[ks], s, 0, 0, 0);        // [key][query]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Vs, kb, ks), gc[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -475,12 +471,9 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s8[e] = exp2f(s[8 * u + e] * c2 - lq) * (dp[8 * u + e] - dl);
                 const bf16x8 sf = pack8(s8);
-                const int r0 = kb * 32 + 16 * u + 4 * kh + qr;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 kt = tr_pair(I0 + img_off_tr(r0, 2 * dt + mh, p4), I0 + img_off_tr(r0 + 8, 2 * dt + mh, p4));
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, sf, dq[dt], 0, 0, 0);   // dQ^T[d][query] += K'^T[d][key] dS^T[key][query]
-                }
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(Ks, kb, u, dt), sf, dq[dt], 0, 0, 0);   // dQ^T[d][query] += K'^T[d][key] dS^T[key][query]
             }
         }
         float g[2][16], xh[2][16];
@@ -491,17 +484,16 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16_t* __restr
         load_acc_row(base + (tok0 + qrow) * ld, kh, xh);
         rope_ln_bwd_acc(g, xh, kh, q_scale, d.eps, cosT + (long)qrow * SD, sinT + (long)qrow * SD);
         store_acc_row(dqkv + (tok0 + qrow) * lddq + h * SD, kh, g);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dsq[dt][r] += xh[dt][r];
+        add_scale_grad(xh, 0);
     }
 
-    flush(dsq, 0);
     __syncthreads();
     if (threadIdx.x < 2 * SD) {
         const int t = threadIdx.x;
-        part[(long)blockIdx.x * 2 * SD + t] = (red[t] + red[2 * SD + t]) + (red[4 * SD + t] + red[6 * SD + t]);
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += red[w * 2 * SD + t];
+        part[(long)blockIdx.x * 2 * SD + t] = tot;
     }
 }
 
@@ -511,7 +503,7 @@ template <int NKB>
 int launch_sattn_bwd(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse2, void* dqkv, int lddq,
                      const float* qs, const float* ks, const float* cosT, const float* sinT, float* part, SAttnDims d, hipStream_t s)
 {
-    constexpr int lds = 2 * 32 * NKB * SROW + 2 * 32 * NKB * 4 + 8 * SD * 4;
+    constexpr int lds = 4 * 32 * NKB * SROW + 2 * 32 * NKB * 4 + 16 * SD * 4;
     auto k = sattn_bwd_kernel<NKB>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -519,7 +511,7 @@ int launch_sattn_bwd(const void* qkv, int ld, const void* out, int ldo, const vo
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(d.A * d.H), dim3(256), lds, s, (const bf16_t*)qkv, ld, (const bf16_t*)out, ldo, (const bf16_t*)dout, lddo, lse2,
+    hipLaunchKernelGGL(k, dim3(d.A * d.H), dim3(512), lds, s, (const bf16_t*)qkv, ld, (const bf16_t*)out, ldo, (const bf16_t*)dout, lddo, lse2,
                        (bf16_t*)dqkv, lddq, qs, ks, cosT, sinT, part, d);
     VVAE_LAUNCH_CHECK();
     return 0;
