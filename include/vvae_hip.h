@@ -63,6 +63,17 @@ int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, flo
 /* out[c] = sum over V rows of x[v][c] (bias gradients) */
 int vvae_colsum(const void* x, int ld, long V, int C, float* out, int dtype, void* stream);
 
+/* ---- 1x1x1 convolutions onto 3 channels as HBM streams (UNet.final_conv train/unet.py:144-153,188; the PatchUnEmbedding
+ *      down-projection train/layers.py:60-79).  Reached through vvae_conv3d_{fwd,dgrad,wgrad}; V = voxels, Cin in {12, 16}. ---- */
+int vvae_conv_pointwise_supported(int Cin, int Cout, int kt, int kh, int kw, int ldx, int dtype, const void* x);
+size_t vvae_conv_pointwise_ws_bytes(long V, int Cin, int Cout);
+int vvae_conv_pointwise_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, long V, int Cin, int Cout,
+                            int dtype, void* stream);
+int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, long V, int Cin, int Cout, int dtype,
+                              void* stream);
+int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, long V, int Cin, int Cout,
+                              int dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- GroupNorm(G, eps) + SiLU: nnx.GroupNorm + nnx.silu at train/unet.py:22-23,28-29.
  *      sums: fp64 [N][G][2] (sum, sum of squares) produced by vvae_gn_stats; S = voxels per sample. ---- */
 size_t vvae_gn_part_floats(int N, long S, int C);   /* fp32 scratch floats for `part` below (per-workgroup partial sums) */

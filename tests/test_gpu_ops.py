@@ -566,6 +566,46 @@ def test_gemm_tn_weight_gradient(dev, m, n, k, big):
     assert none is None and torch.equal(c, c3)
 
 
+@pytest.mark.parametrize("cin", [16, 12])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 9, 11), (1, 1, 1, 1), (1, 4, 64, 80)])
+def test_conv_pointwise_stream_kernels(dev, cin, dtype, shape):
+    """1x1x1 convs onto 3 channels (final_conv, un-embedding down-projection): HBM-stream kernels vs the generic matrix-core
+    path and vs the oracle, forward, input gradient, weight and bias gradients (fixed-order partial folds: reproducible)."""
+    from video_vae_amd import ops
+    n, t, h, w = shape
+    x = rnd((n, t, h, w, cin), 100).to(dtype).float()
+    k = rnd((1, 1, 1, cin, 3), 101, cin ** -0.5)
+    b = rnd((3,), 102, 0.1)
+    gy = rnd((n, t, h, w, 3), 103).to(dtype).float()
+    xg, kg, bg, gyg = x.to(dev, dtype), k.to(dev), b.to(dev), gy.to(dev, dtype)
+    y = ops.conv3d_fwd_raw(xg, kg, bg)
+    dx = ops.conv3d_dgrad_raw(gyg, kg)
+    dw, db = ops.conv3d_wgrad_raw(xg, gyg, tuple(k.shape))
+    dw2, _ = ops.conv3d_wgrad_raw(xg, gyg, tuple(k.shape))
+    assert torch.equal(dw, dw2)
+    ops.force_generic_conv(True)
+    try:
+        y_gen = ops.conv3d_fwd_raw(xg, kg, bg)
+        dx_gen = ops.conv3d_dgrad_raw(gyg, kg)
+        dw_gen, db_gen = ops.conv3d_wgrad_raw(xg, gyg, tuple(k.shape))
+    finally:
+        ops.force_generic_conv(False)
+    xo = x.clone().requires_grad_(True); ko = k.clone().requires_grad_(True); bo = b.clone().requires_grad_(True)
+    yo = O.conv3d_same(xo, ko, bo, dtype)
+    yo.backward(gy)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert_close(y, yo, rtol=tol, atol=tol, what="y vs oracle")
+    assert_close(y, y_gen, rtol=tol, atol=tol, what="y vs generic")
+    assert_close_scaled(dx, xo.grad, rel=tol, what="dx vs oracle")
+    assert_close_scaled(dx, dx_gen, rel=tol, what="dx vs generic")
+    tolw = 2e-4 if dtype == torch.float32 else 1e-2          # the oracle's bf16 emulation rounds the parameter gradient
+    assert_close_scaled(dw, ko.grad, rel=tolw, floor=1e-6, what="dw vs oracle")
+    assert_close_scaled(dw, dw_gen, rel=2e-4, floor=1e-6, what="dw vs generic")
+    assert_close_scaled(db, bo.grad, rel=tolw, floor=1e-6, what="db vs oracle")
+    assert_close_scaled(db, db_gen, rel=2e-4, floor=1e-6, what="db vs generic")
+
+
 @pytest.mark.parametrize("m,n,k", [(256, 192, 32), (512, 768, 512), (256, 128, 96), (1024, 1536, 768), (256, 512, 160)])
 def test_gemm_nt_linear_forms(dev, m, n, k):
     """C = epi(A B^T + bias) (LDS-DMA ring NT GEMM) vs fp32 torch: plain, + residual, SiLU (+ saved pre-activation) and

@@ -9,6 +9,17 @@ int vvae_conv3d_fwd_bf16(const void*, int, const float*, const float*, void*, in
 int vvae_conv3d_wgrad_bf16(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
 size_t vvae_conv3d_bf16_ws_bytes(int, int, int, int, int, int, int, int, int, int);
 int vvae_conv3d_bf16_supported(int, int, int, int, int, int, int, int, int);
+int vvae_conv_pointwise_supported(int, int, int, int, int, int, int, const void*);
+size_t vvae_conv_pointwise_ws_bytes(long, int, int);
+int vvae_conv_pointwise_fwd(const void*, int, const float*, const float*, void*, int, long, int, int, int, void*);
+int vvae_conv_pointwise_dgrad(const void*, int, const float*, void*, int, long, int, int, int, void*);
+int vvae_conv_pointwise_wgrad(const void*, int, const void*, int, float*, float*, long, int, int, int, void*, size_t, void*);
+}
+
+// 1x1x1 convolutions onto 3 channels (final_conv, the un-embedding down-projection) are HBM streams: conv_pointwise.hip
+static inline bool pointwise_shape(int Cin, int Cout, int kt, int kh, int kw)
+{
+    return kt == 1 && kh == 1 && kw == 1 && Cout == 3 && (Cin == 12 || Cin == 16);
 }
 
 static int g_force_generic = 0;
@@ -19,7 +30,9 @@ extern "C" void vvae_conv3d_force_generic(int on) { g_force_generic = on; }
 // Scratch bytes the caller must provide to fwd / dgrad / wgrad for this shape (0 = none needed).
 extern "C" size_t vvae_conv3d_workspace_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, int which)
 {
-    if (dtype != VVAE_DT_BF16 || g_force_generic) return 0;
+    if (g_force_generic) return 0;
+    if (pointwise_shape(Cin, Cout, kt, kh, kw)) return which == 2 ? vvae_conv_pointwise_ws_bytes((long)N * T * H * W, Cin, Cout) : 0;
+    if (dtype != VVAE_DT_BF16) return 0;
     return vvae_conv3d_bf16_ws_bytes(N, T, H, W, Cin, Cout, kt, kh, kw, which);
 }
 
@@ -29,6 +42,8 @@ extern "C" int vvae_conv3d_fwd(const void* x, int ldx, const float* w, const flo
                                int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
                                void* ws, size_t ws_bytes, void* stream)
 {
+    if (!g_force_generic && vvae_conv_pointwise_supported(Cin, Cout, kt, kh, kw, ldx, dtype, x))
+        return vvae_conv_pointwise_fwd(x, ldx, w, bias, y, ldy, (long)N * T * H * W, Cin, Cout, dtype, stream);
     if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, ldy, 0, 0))
         return vvae_conv3d_fwd_bf16(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, 0, 0, ws, ws_bytes, stream);
     return vvae_conv3d_fwd_generic(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
@@ -39,6 +54,8 @@ extern "C" int vvae_conv3d_dgrad(const void* dy, int lddy, const float* w, void*
                                  int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
                                  void* ws, size_t ws_bytes, void* stream)
 {
+    if (!g_force_generic && vvae_conv_pointwise_supported(Cin, Cout, kt, kh, kw, lddx, dtype, dx))
+        return vvae_conv_pointwise_dgrad(dy, lddy, w, dx, lddx, (long)N * T * H * W, Cin, Cout, dtype, stream);
     if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, lddx, lddy, 1, 0))
         return vvae_conv3d_fwd_bf16(dy, lddy, w, nullptr, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, 1, 0, ws, ws_bytes, stream);
     return vvae_conv3d_dgrad_generic(dy, lddy, w, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
@@ -49,6 +66,8 @@ extern "C" int vvae_conv3d_wgrad(const void* x, int ldx, const void* dy, int ldd
                                  int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
                                  void* ws, size_t ws_bytes, void* stream)
 {
+    if (!g_force_generic && vvae_conv_pointwise_supported(Cin, Cout, kt, kh, kw, ldx, dtype, x))
+        return vvae_conv_pointwise_wgrad(x, ldx, dy, lddy, dw, dbias, (long)N * T * H * W, Cin, Cout, dtype, ws, ws_bytes, stream);
     if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, lddy, 2, 0))
         return vvae_conv3d_wgrad_bf16(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, ws, ws_bytes, stream);
     return vvae_conv3d_wgrad_generic(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
