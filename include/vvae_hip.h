@@ -100,6 +100,11 @@ int vvae_convt_1x2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, flo
                            int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* bf16 MFMA path (weights in registers, no LDS) for the UNet decoder shapes 128->64, 64->32, 32->16:
  * dgrad = 0: x -> y (+bias); dgrad = 1: "x" is dy (2H x 2W, Cout), "y" is dx (H x W, Cin).  ws: packed weights. */
+/* bf16 matrix-core weight + bias gradient of the same layer (128->64, 64->32, 32->16): deterministic slab reduction. */
+int vvae_convt_wgrad_bf16_supported(int Cin, int Cout, int ldx, int lddy);
+size_t vvae_convt_wgrad_bf16_ws_bytes(int NT, int H, int W, int Cin, int Cout);
+int vvae_convt_1x2x2_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, int NT, int H, int W,
+                                int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int vvae_convt_bf16_supported(int Cin, int Cout, int ld_in, int ld_out);
 size_t vvae_convt_bf16_ws_bytes(int Cin, int Cout);
 int vvae_convt_1x2x2_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,

@@ -377,6 +377,27 @@ def convt_wgrad_raw(x, dy, kshape):
     return dw
 
 
+def convt_wgrad_db_raw(x, dy, kshape):
+    """-> (dw (1,2,2,Cin,Cout) fp32, db (Cout) fp32): one bf16 matrix-core launch pair where the layer qualifies, else the generic
+    weight gradient plus a column sum."""
+    x, ldx = rows(x)
+    dy, lddy = rows(dy)
+    n, t, h, w, cin = x.shape
+    cout = kshape[-1]
+    if (x.dtype == torch.bfloat16 and not _FORCE_GENERIC[0]
+            and lib().vvae_convt_wgrad_bf16_supported(cin, cout, ldx, lddy) == 1):
+        dw = torch.empty(kshape, dtype=torch.float32, device=x.device)
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        wsb = lib().vvae_convt_wgrad_bf16_ws_bytes(n * t, h, w, cin, cout)
+        ws, wsb = _ws(wsb, x.device)
+        vox = n * t * h * w
+        check(_launch(f"convt_wgrad {cin}->{cout} @{h}x{w}", vox * (cin + 4 * cout) * 2, 8 * vox * cin * cout, "convt_wgrad_bf16_kernel",
+                      lambda: lib().vvae_convt_1x2x2_wgrad_bf16(_p(x), ldx, _p(dy), lddy, _p(dw), _p(db), n * t, h, w, cin, cout,
+                                                                _p(ws), wsb, _stream())), "vvae_convt_1x2x2_wgrad_bf16")
+        return dw, db
+    return convt_wgrad_raw(x, dy, kshape), colsum_raw(dy)
+
+
 def colsum_raw(x):
     x, ld = rows(x)
     c = x.shape[-1]
@@ -398,9 +419,8 @@ class _ConvT(torch.autograd.Function):
         x, k32 = ctx.saved_tensors
         dy = dy.to(x.dtype)
         dx = convt_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
-        dw = convt_wgrad_raw(x, dy, tuple(k32.shape)).to(ctx.kdtype)
-        db = colsum_raw(dy).to(ctx.kdtype)
-        return dx, dw, db
+        dw, db = convt_wgrad_db_raw(x, dy, tuple(k32.shape))
+        return dx, dw.to(ctx.kdtype), db.to(ctx.kdtype)
 
 
 def conv_transpose_1x2x2(x, kernel, bias):
