@@ -128,4 +128,35 @@ static inline hipError_t vvae_zero_async(void* p, size_t bytes, hipStream_t s)
     hipLaunchKernelGGL(vvae_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, n);
     return hipGetLastError();
 }
+// Fold per-workgroup partial rows in fixed order: out[c] = sum_r part[r * stride + c] for c < ncols; columns < n0 go to out0[c],
+// the rest to out1[c - n0].  Block = 32 columns x 8 row lanes, 8 loads in flight per thread (the partials are L2-resident:
+// latency, not bandwidth, is what the fold pays for).  grid = ceil(ncols / 32).
+__global__ static void vvae_reduce_rows_kernel(const float* __restrict__ part, int rows, long stride, int ncols, float* __restrict__ out0, int n0,
+                                               float* __restrict__ out1)
+{
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < ncols) {
+        for (int r0 = rl; r0 < rows; r0 += 8 * 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + 8 * i;
+                v[i] = r < rows ? part[(long)r * stride + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < ncols) {
+        const float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+        if (c < n0) out0[c] = t;
+        else if (out1) out1[c - n0] = t;
+    }
+}
+
 #define VVAE_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -116,17 +116,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const T_* __restrict__ x,
     if (threadIdx.x < NA) part[(long)blockIdx.x * NA + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(64) void pw_wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int nw, int nb, float* __restrict__ dw,
-                                                              float* __restrict__ db)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x, na = nw + nb;
-    if (i >= na) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * na + i];
-    if (i < nw) dw[i] = (float)s;
-    else if (db) db[i - nw] = (float)s;
-}
-
 inline int pw_blocks(long V)
 {
     const long b = (V + 255) / 256;
@@ -208,7 +197,8 @@ extern "C" int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy,
     }
     VVAE_LAUNCH_CHECK();
     const int nw = Cin * Cout;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(ceil_div(nw + Cout, 64)), dim3(64), 0, s, part, nblk, nw, Cout, dw, dbias);
+    hipLaunchKernelGGL(vvae_reduce_rows_kernel, dim3(ceil_div(nw + Cout, 32)), dim3(256), 0, s, part, nblk, (long)(nw + Cout), nw + Cout, dw, nw,
+                       dbias);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -152,22 +152,11 @@ __global__ __launch_bounds__(256) void convt_wgrad_bf16_kernel(const bf16_t* __r
     }
 }
 
-// dw[i] = sum_b slab[b][i] (i < 4*Cin*Cout); db[co] = sum_b sum_tap slab[b][4*Cin*Cout + tap*Cout + co]; fixed order
-__global__ __launch_bounds__(256) void convt_wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int slab_floats, int nw, int cout,
-                                                                 float* __restrict__ dw, float* __restrict__ db)
+// db[co] = sum over the four taps of the folded bias sums
+__global__ __launch_bounds__(64) void convt_db_fold_kernel(const float* __restrict__ t4, int cout, float* __restrict__ db)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nw) {
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += slab[(long)b * slab_floats + i];
-        dw[i] = s;
-    } else if (db && i < nw + cout) {
-        const int co = i - nw;
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b)
-            for (int t = 0; t < 4; ++t) s += slab[(long)b * slab_floats + nw + t * cout + co];
-        db[co] = s;
-    }
+    const int co = blockIdx.x * 64 + threadIdx.x;
+    if (co < cout) db[co] = (t4[co] + t4[cout + co]) + (t4[2 * cout + co] + t4[3 * cout + co]);
 }
 
 inline bool cw_shape(int Cin, int Cout) { return (Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 32) || (Cin == 32 && Cout == 16); }
@@ -197,9 +186,16 @@ int launch_cw(const void* x, const void* dy, float* dw, float* db, float* slab, 
     }
     hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy, slab, d);
     VVAE_LAUNCH_CHECK();
+    // fold the slabs in fixed order: weight columns straight into dw, the 4 x COUT bias columns into the scratch row behind the slabs
     const int nw = 4 * CIN * COUT;
-    hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3(ceil_div(nw + COUT, 256)), dim3(256), 0, s, slab, nblk, C::SLAB, nw, COUT, dw, db);
+    float* t4 = slab + (long)nblk * C::SLAB;
+    hipLaunchKernelGGL(vvae_reduce_rows_kernel, dim3(ceil_div(C::SLAB, 32)), dim3(256), 0, s, slab, nblk, (long)C::SLAB, C::SLAB, dw, nw,
+                       db ? t4 : nullptr);
     VVAE_LAUNCH_CHECK();
+    if (db) {
+        hipLaunchKernelGGL(convt_db_fold_kernel, dim3(ceil_div(COUT, 64)), dim3(64), 0, s, t4, COUT, db);
+        VVAE_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -214,7 +210,7 @@ extern "C" int vvae_convt_wgrad_bf16_supported(int Cin, int Cout, int ldx, int l
 extern "C" size_t vvae_convt_wgrad_bf16_ws_bytes(int NT, int H, int W, int Cin, int Cout)
 {
     if (!cw_shape(Cin, Cout)) return 0;
-    return (size_t)cw_blocks((long)NT * H * W, Cin, Cout) * (4 * (size_t)Cin * Cout + 4 * Cout) * sizeof(float);
+    return ((size_t)cw_blocks((long)NT * H * W, Cin, Cout) + 1) * (4 * (size_t)Cin * Cout + 4 * Cout) * sizeof(float);
 }
 
 // x (NT,H,W,Cin) row pitch ldx; dy (NT,2H,2W,Cout) row pitch lddy; dw (1,2,2,Cin,Cout) fp32 and dbias (Cout) fp32 (or NULL) overwritten.
