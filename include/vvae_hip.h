@@ -168,7 +168,8 @@ int vvae_spatial_attn_bwd(const void* qkv, int ld, const void* out, int ldo, con
 int vvae_layernorm_supported(int C, int dtype);
 int vvae_layernorm_bwd_blocks(long rows, int C, int dtype);
 int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
-                       long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps, int dtype, void* stream);
+                       const void* addend, void* xsum, long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps,
+                       int dtype, void* stream);   /* addend/xsum non-NULL: normalise round(x + addend), write the sum to xsum */
 int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, const void* dres,
                        void* dx, float* part, long rows, int C, int inner, long outer_pitch, long inner_pitch, int dtype,
                        void* stream);

@@ -501,6 +501,37 @@ def test_sum_rows(dev, shape):
     assert torch.equal(got, ops.sum_rows(part))
 
 
+@pytest.mark.parametrize("shape", [(3, 70, 768), (2, 9, 512), (130, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_add_layer_norm_fork(dev, shape, dtype):
+    """(LN(skip + o), skip + o) in one kernel pass == add launch followed by the LayerNorm fork, forward and backward."""
+    ops = _ops()
+    c = shape[-1]
+    skip = (rnd(shape, 85) * 1.3 + 0.2).to(dev, dtype); o = rnd(shape, 86).to(dev, dtype)
+    sc = (1 + 0.2 * rnd((c,), 87)).to(dev); bi = (0.1 * rnd((c,), 88)).to(dev)
+    w = rnd(shape, 89).to(dev, dtype); go = rnd(shape, 90).to(dev, dtype)
+
+    def run(fused):
+        sk = skip.clone().requires_grad_(True); oo = o.clone().requires_grad_(True)
+        sg = sc.clone().requires_grad_(True); bg = bi.clone().requires_grad_(True)
+        if fused:
+            y, xs = ops.add_layer_norm_fork(sk, oo, sg, bg)
+        else:
+            y, xs = ops.layer_norm_fork(sk + oo, sg, bg)
+        out = xs + torch.tanh(y) * w
+        out.backward(go)
+        return out, sk.grad, oo.grad, sg.grad, bg.grad
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]), "forward (sum rounded to the storage dtype, then normalised) is bit-identical"
+    for i, nm in ((1, "dskip"), (2, "do")):
+        if dtype == torch.float32:
+            assert_close(a[i], b[i], rtol=1e-6, atol=1e-6, what=nm)
+        else:
+            assert torch.equal(a[i], b[i]), nm
+    assert torch.equal(a[1], a[2])
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+
+
 def test_layer_norm_strided_head_view(dev):
     """q_norm on the q third of a fused QKV buffer, normalised in place of a gather copy (two-level row strides)."""
     ops = _ops()

@@ -35,30 +35,27 @@ __device__ __forceinline__ void unpack(const uint4& r, float (&v)[8]) {
 __device__ __forceinline__ void opaque(uint4& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
 
 // y rows are written contiguously (pitch C).  mean / rstd: fp32 [rows] (saved for backward).
+// addend != NULL: the row normalised is round(x + addend) (addend, xsum contiguous (rows, C)) and that sum is written to xsum: the
+// residual add that closes one pre-norm block, fused with the LayerNorm that opens the next (one pass over the stream, not two).
 template <typename T_, int LPR, int VPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict__ x, T_* __restrict__ y, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, LnDims d)
+                                                            float* __restrict__ rstd_out, const T_* __restrict__ addend, T_* __restrict__ xsum,
+                                                            LnDims d)
 {
     constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;          // rows per wave-iteration
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, ll = lane % LPR;
-    // this lane's columns never change: keep gamma / beta in registers for all the rows the wave walks.  They reach the
-    // registers through LDS (one coalesced pass per workgroup): per-lane strided dword loads of the affine cost ~30x the
-    // L1 line accesses of the row itself and were what bounded the kernel.
+    // gamma / beta reach the lanes through LDS (one coalesced pass per workgroup): per-lane strided dword loads of the affine
+    // cost ~30x the L1 line accesses of the row itself and were what bounded the first version of this kernel.
     __shared__ __attribute__((aligned(16))) float sg[LPR * VPL * V], sb[LPR * VPL * V];
     for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) {
         sg[i] = i < d.C ? gamma[i] : 0.f;
         sb[i] = (beta && i < d.C) ? beta[i] : 0.f;
     }
     __syncthreads();
-    float gm[VPL][V], bt[VPL][V];
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        const int c = (k * LPR + ll) * V;
-#pragma unroll
-        for (int e = 0; e < V; ++e) { gm[k][e] = sg[c + e]; bt[k][e] = sb[c + e]; }
-    }
+    // gamma / beta are re-read from LDS at the point of use: ~50 VGPRs instead of ~118, i.e. 8 waves per SIMD, twice the bytes
+    // in flight per CU
     const long rstride = (long)gridDim.x * 4 * RPW;
     for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
@@ -71,6 +68,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
             const int c = (k * LPR + ll) * V;
             if (rv && c < d.C) {
                 VecIO<T_, V>::load(xr + c, v[k]);
+                if (addend) {
+                    float a[V];
+                    VecIO<T_, V>::load(addend + r * d.C + c, a);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[k][e] = round_to<T_>(v[k][e] + a[e]);
+                    VecIO<T_, V>::store(xsum + r * d.C + c, v[k]);
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) { s += v[k][e]; ss += v[k][e] * v[k][e]; }
             }
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
             if (rv && c < d.C) {
                 float o[V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) o[e] = (v[k][e] - mean) * (rstd * gm[k][e]) + bt[k][e];
+                for (int e = 0; e < V; ++e) o[e] = (v[k][e] - mean) * (rstd * sg[c + e]) + sb[c + e];
                 VecIO<T_, V>::store(yr + c, o);
             }
         }
@@ -256,21 +260,24 @@ extern "C" int vvae_layernorm_bwd_blocks(long rows, int C, int dtype)
 
 // x: rows of C elements, row r at x + (r / inner) * outer_pitch + (r % inner) * inner_pitch (elements); y contiguous (rows, C).
 // gamma fp32 [C]; beta fp32 [C] or NULL; mean, rstd fp32 [rows] written.
+// addend, xsum: both NULL, or contiguous (rows, C): normalise round(x + addend) and write that sum to xsum (fused residual add).
 extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
-                                  long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps, int dtype, void* stream)
+                                  const void* addend, void* xsum, long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps,
+                                  int dtype, void* stream)
 {
-    if (!x || !y || !gamma || !mean || !rstd) return VVAE_ERR_BAD_ARG;
+    if (!x || !y || !gamma || !mean || !rstd || (addend == nullptr) != (xsum == nullptr) || ((uintptr_t)addend % 16) || ((uintptr_t)xsum % 16))
+        return VVAE_ERR_BAD_ARG;
     LnDims d{rows, C, inner, outer_pitch, inner_pitch, eps};
     hipStream_t s = (hipStream_t)stream;
     int lpr, vpl;
     if (dtype == VVAE_DT_F32) {
         if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr, 2048));
-        LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, d);
+        LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, (const float*)addend, (float*)xsum, d);
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr, 2048));
-        LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, d);
+        LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
     return 0;

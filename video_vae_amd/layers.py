@@ -100,9 +100,17 @@ class LayerNorm(nn.Module):
         b = self.bias.to(self.dtype) if self.bias is not None else None
         return F.layer_norm(x, (x.shape[-1],), self.scale.to(self.dtype), b, 1e-6)
 
-    def fork(self, x):
+    def fork(self, x, pending=None):
         """-> (LayerNorm(x), x_skip) for ``x_skip + f(LayerNorm(x))``: on the HIP path x_skip is x routed through the
-        LayerNorm node, so the skip gradient is added inside its backward kernel (no separate add launch)."""
+        LayerNorm node, so the skip gradient is added inside its backward kernel (no separate add launch).
+
+        ``pending = (skip, o)``: the residual stream is still the un-added pair of the previous block; x = skip + o is formed
+        inside the LayerNorm kernel (one pass over the stream instead of an add launch followed by a LayerNorm launch)."""
+        if pending is not None:
+            skip, o = pending
+            if skip.dtype == self.dtype and ops.layer_norm_supported(skip):
+                return ops.add_layer_norm_fork(skip, o, self.scale, self.bias, 1e-6)
+            x = skip + o
         if x.dtype == self.dtype and ops.layer_norm_supported(x):
             return ops.layer_norm_fork(x, self.scale, self.bias, 1e-6)
         return self.forward(x), x
@@ -195,11 +203,12 @@ class Attention(nn.Module):
         self.q_norm = LayerNorm(head_dim, dtype, param_dtype, use_bias=False)
         self.k_norm = LayerNorm(head_dim, dtype, param_dtype, use_bias=False)
 
-    def forward_temporal_strided(self, x, mask=None):
+    def forward_temporal_strided(self, x, mask=None, pending=None, defer=False):
         """x + temporal attention on x laid out (b, t, hw, c) -- attention over t for every (b, hw) without the
-        "b t hw c -> (b hw) t c" transposes: LayerNorm and the projections are per-token, the fused core strides."""
-        b, t, hw, _ = x.shape
-        x, skip = self.input_norm.fork(x)
+        "b t hw c -> (b hw) t c" transposes: LayerNorm and the projections are per-token, the fused core strides.
+        pending / defer: see LayerNorm.fork; defer=True returns the un-added (skip, branch) pair."""
+        b, t, hw, _ = (pending[0] if pending is not None else x).shape
+        x, skip = self.input_norm.fork(x, pending)
         qkv = self.qkv_projection(x)
         m8, div = None, 1
         if mask is not None:
@@ -207,16 +216,17 @@ class Attention(nn.Module):
             div = (b * hw) // m8.shape[0]
         o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
                                         m8, div, self.num_heads, 1e-6, inner=hw)
-        return skip + self.out_projection(o)
+        o = self.out_projection(o)
+        return (skip, o) if defer else skip + o
 
-    def residual(self, x, mask=None):
-        """x + self(x) with the skip gradient folded into the input LayerNorm's backward."""
-        return self.forward(x, mask, _residual=True)
+    def residual(self, x, mask=None, pending=None, defer=False):
+        """x + self(x) with the skip gradient folded into the input LayerNorm's backward (pending / defer: LayerNorm.fork)."""
+        return self.forward(x, mask, _residual=True, _pending=pending, _defer=defer)
 
-    def forward(self, x, mask=None, _residual=False):
+    def forward(self, x, mask=None, _residual=False, _pending=None, _defer=False):
         skip = None
         if _residual:
-            x, skip = self.input_norm.fork(x)
+            x, skip = self.input_norm.fork(x, _pending)
         else:
             x = self.input_norm(x)
         qkv = self.qkv_projection(x)
@@ -246,7 +256,9 @@ class Attention(nn.Module):
             o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=am)
             o = rearrange(o, "b h s d -> b s (h d)")
         o = self.out_projection(o)
-        return skip + o if _residual else o
+        if not _residual:
+            return o
+        return (skip, o) if _defer else skip + o
 
 
 class MLP(nn.Module):
@@ -261,10 +273,11 @@ class MLP(nn.Module):
     def forward(self, x):
         return self.linear2(F.silu(self.linear1(self.norm(x))))
 
-    def residual(self, x):
-        """x + self(x) with the skip gradient folded into the LayerNorm's backward."""
-        y, skip = self.norm.fork(x)
-        return skip + self.linear2(F.silu(self.linear1(y)))
+    def residual(self, x, pending=None, defer=False):
+        """x + self(x) with the skip gradient folded into the LayerNorm's backward (pending / defer: LayerNorm.fork)."""
+        y, skip = self.norm.fork(x, pending)
+        o = self.linear2(F.silu(self.linear1(y)))
+        return (skip, o) if defer else skip + o
 
 
 class FactoredAttention(nn.Module):
@@ -282,19 +295,26 @@ class FactoredAttention(nn.Module):
         self.TemporalAttention = Attention(in_features, num_heads, qkv_features, max_temporal_len, False, rngs, dtype, param_dtype)
         self.TemporalMLP = MLP(in_features, mlp_dim, rngs, dtype, param_dtype)
 
-    def forward(self, x, temporal_mask):
-        b, t, hw, c = x.shape
+    def forward(self, x, temporal_mask, pending=None, defer=False):
+        """pending = (skip, o): the input is the un-added residual pair the previous layer returned with defer=True (its last
+        add then happens inside this layer's first LayerNorm kernel); defer=True returns such a pair instead of the sum."""
+        first = pending[0] if pending is not None else x
+        b, t, hw, c = first.shape
         ta = self.TemporalAttention
         hd = ta.q_norm.scale.shape[0]
-        if x.is_cuda and t <= FUSED_CORE_MAX_SEQ and ops.temporal_attention_fast_supported(t, hd, 3 * hd * ta.num_heads, ta.qkv_projection.dtype):
+        if first.is_cuda and t <= FUSED_CORE_MAX_SEQ and ops.temporal_attention_fast_supported(t, hd, 3 * hd * ta.num_heads, ta.qkv_projection.dtype):
             # every op of the temporal half except the attention core is per-token, and the core strides over frames:
-            # stay in (b, t, hw, c) and skip both transpose copies (and their backward)
-            x = ta.forward_temporal_strided(x, mask=temporal_mask)
-            x = self.TemporalMLP.residual(x)
-            sx = x.reshape(b * t, hw, c)
-            sx = self.SpatialAttention.residual(sx)
-            sx = self.SpatialMLP.residual(sx)
-            return sx.view(b, t, hw, c)
+            # stay in (b, t, hw, c) and skip both transpose copies (and their backward); each residual add rides in the
+            # LayerNorm kernel of the following block
+            p = ta.forward_temporal_strided(x, mask=temporal_mask, pending=pending, defer=True)
+            p = self.TemporalMLP.residual(None, pending=p, defer=True)
+            p = (p[0].reshape(b * t, hw, c), p[1].reshape(b * t, hw, c))
+            p = self.SpatialAttention.residual(None, pending=p, defer=True)
+            p = self.SpatialMLP.residual(None, pending=p, defer=True)
+            p = (p[0].view(b, t, hw, c), p[1].view(b, t, hw, c))
+            return p if defer else p[0] + p[1]
+        if pending is not None:
+            x = pending[0] + pending[1]
         tx = rearrange(x, "b t hw c -> (b hw) t c")
         tx = self.TemporalAttention.residual(tx, mask=temporal_mask)
         tx = self.TemporalMLP.residual(tx)
@@ -302,7 +322,8 @@ class FactoredAttention(nn.Module):
         sx = rearrange(x, "b t hw c -> (b t) hw c")
         sx = self.SpatialAttention.residual(sx)
         sx = self.SpatialMLP.residual(sx)
-        return rearrange(sx, "(b t) hw c -> b t hw c", b=b, t=t)
+        out = rearrange(sx, "(b t) hw c -> b t hw c", b=b, t=t)
+        return (out, torch.zeros_like(out)) if defer else out
 
 
 class _RoundSTE(torch.autograd.Function):

@@ -34,8 +34,14 @@ class Encoder(nn.Module):
 
     def _trunk(self, x, mask):
         x = self.patch_embedding(x)
-        for layer in self.layers:
-            x = layer(x, mask)
+        # each layer hands its last residual add to the next layer's first LayerNorm kernel (layers.FactoredAttention)
+        pend, n = None, len(self.layers)
+        for i, layer in enumerate(self.layers):
+            r = layer(x, mask, pending=pend, defer=i + 1 < n)
+            if i + 1 < n:
+                pend = r
+            else:
+                x = r
         mean = self.spatial_compression(x)
         variance = F.softplus(self.variance_estimator(x))
         log_variance = torch.log(variance)
@@ -68,8 +74,14 @@ class Decoder(nn.Module):
 
     def forward(self, x, mask, rngs, train=True):
         x = self.spatial_decompression(x)
-        for layer in self.layers:
-            x = layer(x, mask)
+        # each layer hands its last residual add to the next layer's first LayerNorm kernel (layers.FactoredAttention)
+        pend, n = None, len(self.layers)
+        for i, layer in enumerate(self.layers):
+            r = layer(x, mask, pending=pend, defer=i + 1 < n)
+            if i + 1 < n:
+                pend = r
+            else:
+                x = r
         feat, x = self.patch_unembedding(x)
         return x + self.unet(feat)
 

@@ -793,8 +793,8 @@ class _LayerNorm(torch.autograd.Function):
         mean = torch.empty((n,), dtype=torch.float32, device=x.device)
         rstd = torch.empty((n,), dtype=torch.float32, device=x.device)
         check(_launch(f"layernorm_fwd C{c}", 2 * x.numel() * x.element_size(), 0, "layernorm_fwd_kernel",
-                      lambda: lib().vvae_layernorm_fwd(_p(x), _p(y), _p(s32), _p(b32), _p(mean), _p(rstd), n, c, inner, op, ip, eps, dt,
-                                                       _stream())), "vvae_layernorm_fwd")
+                      lambda: lib().vvae_layernorm_fwd(_p(x), _p(y), _p(s32), _p(b32), _p(mean), _p(rstd), None, None, n, c, inner, op, ip,
+                                                       eps, dt, _stream())), "vvae_layernorm_fwd")
         ctx.save_for_backward(x, s32, mean, rstd)
         ctx.args = (n, c, inner, op, ip, scale.dtype, bias is not None)
         ctx.set_materialize_grads(False)
@@ -804,24 +804,60 @@ class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
-        x, s32, mean, rstd = ctx.saved_tensors
-        n, c, inner, op, ip, pdtype, has_bias = ctx.args
-        dt = _dt(x)
-        if dy is None:                                   # only the skip path was used
-            return dskip, None, None, None, None
-        dy = dy.to(x.dtype).contiguous()
-        if dskip is not None:
-            dskip = dskip.to(x.dtype).contiguous()
-        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-        nblk = lib().vvae_layernorm_bwd_blocks(n, c, dt)
-        part = torch.empty((nblk, 2, c), dtype=torch.float32, device=x.device)
-        nstreams = 4 if dskip is not None else 3
-        check(_launch(f"layernorm_bwd C{c}" + ("+skip" if dskip is not None else ""), nstreams * x.numel() * x.element_size(), 0,
-                      "layernorm_bwd_kernel",
-                      lambda: lib().vvae_layernorm_bwd(_p(x), _p(dy), _p(s32), _p(mean), _p(rstd), _p(dskip), _p(dx), _p(part), n, c, inner,
-                                                       op, ip, dt, _stream())), "vvae_layernorm_bwd")
-        tot = sum_rows(part)
-        return dx, tot[0].to(pdtype), (tot[1].to(pdtype) if has_bias else None), None, None
+        dx, dsc, dbi = _ln_backward(ctx, dy, dskip)
+        return dx, dsc, dbi, None, None
+
+
+def _ln_backward(ctx, dy, dskip):
+    """Shared by _LayerNorm and _AddLayerNorm: LayerNorm backward with the residual-stream gradient added in the kernel."""
+    x, s32, mean, rstd = ctx.saved_tensors
+    n, c, inner, op, ip, pdtype, has_bias = ctx.args
+    dt = _dt(x)
+    if dy is None:                                   # only the skip path was used
+        return dskip, None, None
+    dy = dy.to(x.dtype).contiguous()
+    if dskip is not None:
+        dskip = dskip.to(x.dtype).contiguous()
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    nblk = lib().vvae_layernorm_bwd_blocks(n, c, dt)
+    part = torch.empty((nblk, 2, c), dtype=torch.float32, device=x.device)
+    nstreams = 4 if dskip is not None else 3
+    check(_launch(f"layernorm_bwd C{c}" + ("+skip" if dskip is not None else ""), nstreams * x.numel() * x.element_size(), 0,
+                  "layernorm_bwd_kernel",
+                  lambda: lib().vvae_layernorm_bwd(_p(x), _p(dy), _p(s32), _p(mean), _p(rstd), _p(dskip), _p(dx), _p(part), n, c, inner,
+                                                   op, ip, dt, _stream())), "vvae_layernorm_bwd")
+    tot = sum_rows(part)
+    return dx, tot[0].to(pdtype), (tot[1].to(pdtype) if has_bias else None)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(LayerNorm(skip + o), skip + o) in one pass: the residual add that closes a pre-norm block fused with the LayerNorm that opens
+    the next one.  Backward is LayerNorm backward + the gradient of the sum, which goes to both addends unchanged."""
+
+    @staticmethod
+    def forward(ctx, skip, o, scale, bias, eps):
+        skip = skip.contiguous()
+        o = o.to(skip.dtype).reshape(skip.shape).contiguous()
+        n, c = skip.numel() // skip.shape[-1], skip.shape[-1]
+        dt = _dt(skip)
+        s32 = _f32(scale)
+        b32 = _f32(bias) if bias is not None else None
+        y = torch.empty(skip.shape, dtype=skip.dtype, device=skip.device)
+        xs = torch.empty(skip.shape, dtype=skip.dtype, device=skip.device)
+        mean = torch.empty((n,), dtype=torch.float32, device=skip.device)
+        rstd = torch.empty((n,), dtype=torch.float32, device=skip.device)
+        check(_launch(f"add_layernorm_fwd C{c}", 4 * skip.numel() * skip.element_size(), 0, "layernorm_fwd_kernel",
+                      lambda: lib().vvae_layernorm_fwd(_p(skip), _p(y), _p(s32), _p(b32), _p(mean), _p(rstd), _p(o), _p(xs), n, c, 1, c, 0,
+                                                       eps, dt, _stream())), "vvae_layernorm_fwd")
+        ctx.save_for_backward(xs, s32, mean, rstd)
+        ctx.args = (n, c, 1, c, 0, scale.dtype, bias is not None)
+        ctx.set_materialize_grads(False)
+        return y, xs
+
+    @staticmethod
+    def backward(ctx, dy, dxs=None):
+        dx, dsc, dbi = _ln_backward(ctx, dy, dxs)
+        return dx, dx, dsc, dbi, None
 
 
 def layer_norm_supported(x):
@@ -831,6 +867,12 @@ def layer_norm_supported(x):
 def layer_norm(x, scale, bias=None, eps=1e-6):
     """nnx.LayerNorm over the last axis, fp32 statistics (reference train/layers.py:17,152,155-156,178)."""
     return _LayerNorm.apply(x, scale, bias, eps, False)
+
+
+def add_layer_norm_fork(skip, o, scale, bias=None, eps=1e-6):
+    """-> (LayerNorm(skip + o), skip + o), one kernel pass (reference train/layers.py:212-221: ``x = x + f(...)`` followed by the
+    next block's LayerNorm)."""
+    return _AddLayerNorm.apply(skip, o, scale, bias, eps)
 
 
 def layer_norm_fork(x, scale, bias=None, eps=1e-6):
