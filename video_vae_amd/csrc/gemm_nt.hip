@@ -11,49 +11,48 @@
 //   * 8 waves as 4 (M) x 2 (N); a wave owns 64 x 96 (or 64 x 64) of C = 2 x 3 (2 x 2) v_mfma_f32_32x32x16_bf16 tiles.  The
 //     WEIGHT rows are the MFMA's row operand, so a lane's 4 consecutive accumulator registers are 4 consecutive output
 //     channels of one token (packed 8-byte writes in the epilogue).
-//   * K advances in 32-element tiles staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into a
-//     ring of S = 5 LDS stages.  A CU can take ~64 B/clk from L2 and the loop needs ~70 B/clk to keep the matrix pipe
-//     full, so the loop lives on the L2 -> LDS stream and what matters is how many bytes are in flight: tiles are issued
-//     four steps ahead (112 KB per CU) and retired with COUNTED s_waitcnt vmcnt(n) -- never 0 inside the loop -- behind one
-//     raw s_barrier per step.  The wait at step t retires tile t+1, so after the barrier every wave may pre-read the first
-//     fragments of tile t+1 while tile t is still being multiplied: the matrix pipe does not idle across the barrier.
-//   * LDS image: [row][32 k] bf16 = 64-byte rows, written lane-linearly by the DMA (a 1 KiB piece = 16 rows).  The XOR swizzle
-//     that makes the 32-row ds_read_b128 fragment reads conflict-free (16-byte chunk c of row r lives in slot c ^ ((r >> 2) & 3))
-//     is applied to the per-lane SOURCE address and to the read address (the same involution on both sides).
+//   * K advances in 64-element tiles staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into two
+//     LDS stages.  The loop lives on the L2 -> LDS stream, and that stream runs at full rate only for whole 128-byte lines: a
+//     piece is 8 rows x 128 B (with a 32-element tile, i.e. 64-byte half lines, the DMA alone measured 13.5 TB/s chip-wide
+//     against a ~17 TB/s ceiling for half-line requests -- slower than the matrix pipe needs).
+//   * LDS image: [row][64 k] bf16 = 128-byte rows, written lane-linearly by the DMA.  The XOR swizzle that makes the 32-row
+//     ds_read_b128 fragment reads conflict-free (16-byte chunk c of row r lives in slot c ^ ((r >> 1) & 7)) is applied to the
+//     per-lane SOURCE address and to the read address (the same involution on both sides).
+//   * waves 4-7 run ONE SEGMENT behind waves 0-3 (two waves share a SIMD: w and w + 4): on every SIMD one wave multiplies
+//     (24 MFMAs on fragments it already holds) while its partner reads the next tile's fragments.  Both halves issue their
+//     DMA pieces of tile t+1 in the same segment -- the first in which the stage tile t-1 used is free -- and wait for them one
+//     segment before the first read, so a tile has a whole step (two segments) to land:
+//          waves 0-3:  L0 | C0 | L1 | C1 | ...     L_t: read fragments of tile t, issue own pieces of tile t+1
+//          waves 4-7:  -- | L0 | C0 | L1 | ...     C_t: issue own pieces of tile t+2, multiply tile t           (| = s_barrier)
 //   * epilogue through LDS: accumulators (+bias, rounded to bf16) are parked as a [256][BN] image, then stored with coalesced
 //     16-byte rows; the residual add / SiLU / SiLU-derivative variants run in that second pass on the rounded values, so the
 //     fused result is bit-identical to Linear followed by the separate elementwise op.
 //   * workgroup -> tile map keeps the tiles of one row block (which share the A panel) on one XCD (private L2).
 #include "common.hpp"
-#include <cstdlib>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BK = 32;                         // K elements per staged tile (64-byte LDS rows)
+constexpr int BK = 64;                         // K elements per staged tile (128-byte LDS rows)
 constexpr int ROWB = BK * 2;
 
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SILU = 2, EPI_MUL_DSILU = 3 };
 
-struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi, dbg; };
+struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi; };
 
-template <int BM_, int BN_, int WM_, int WN_, int S_>
+template <int BM_, int BN_, int WM_, int WN_>
 struct NtCfg {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, S = S_, D = S_ - 1;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
     static constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile
     static constexpr int MB = WTM / 32, NB = WTN / 32;          // 32x32 MFMA tiles per wave
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    static constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16; // 1 KiB DMA pieces (16 rows) per tile
-    static constexpr int PA = A_PIECES / NWAVES;                 // A pieces per wave
-    static constexpr int PB_MAX = (B_PIECES + NWAVES - 1) / NWAVES, PB_MIN = B_PIECES / NWAVES;
-    static constexpr int SPLIT = B_PIECES % NWAVES;              // waves < SPLIT carry PB_MAX B pieces (0: all carry PB_MIN)
+    static constexpr int PA = BM / 8 / NWAVES, PB = BN / 8 / NWAVES;   // 1 KiB DMA pieces (8 rows) per wave and tile
     static constexpr int CP = BN * 2 + 16;                      // epilogue image row pitch (bytes)
-    static constexpr int LDS = S * STAGE > BM * CP ? S * STAGE : BM * CP;
-    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && A_PIECES % NWAVES == 0 && NWAVES == 8, "tile / wave layout");
-    static_assert((BN * 2 / 16) * BM % NT == 0, "epilogue chunks per thread");
-    static_assert(D >= 2 && LDS <= 160 * 1024, "ring depth");
+    static constexpr int LDS = 2 * STAGE > BM * CP ? 2 * STAGE : BM * CP;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0 && NWAVES == 8, "tile / wave layout");
+    static_assert((BN * 2 / 16) * BM % NT == 0 && LDS <= 160 * 1024, "epilogue chunks per thread / LDS");
 };
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base)
@@ -62,12 +61,8 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt left at their maxima): gfx9 encoding vmcnt = imm[3:0] | imm[15:14]
-template <int N> __device__ __forceinline__ void wait_vm()
-{
-    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
-}
+// s_waitcnt vmcnt(0) only (expcnt / lgkmcnt left at their maxima)
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 // d/dx silu(x) = s (1 + x (1 - s)), s = sigmoid(x)
@@ -80,69 +75,46 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int wm = wave / C::WN, wn = wave % C::WN, grp = wave >> 2;
 
     // XCD-aware tile map: blockIdx round-robins over the 8 XCDs; give each XCD a contiguous run of tiles (n fastest), so the
     // tiles that share an A row panel hit the same L2
     const int tn_count = d.N / C::BN;
     const int ntiles = gridDim.x;
-    int t = blockIdx.x;
-    if ((ntiles & 7) == 0) t = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
-    const int m0 = (t / tn_count) * C::BM, n0 = (t % tn_count) * C::BN;
+    int t0 = blockIdx.x;
+    if ((ntiles & 7) == 0) t0 = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int m0 = (t0 / tn_count) * C::BM, n0 = (t0 % tn_count) * C::BN;
 
-    // ---- staging: a DMA piece = 16 rows x 64 bytes; lane -> row lane >> 2, slot lane & 3; the slot holds source chunk
-    //      slot ^ ((row >> 2) & 3) = slot ^ ((lane >> 4) & 3).  Wave w issues A pieces w*PA .. and B pieces w, w + 8.
-    const int prow = lane >> 2, pkc = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    // ---- staging: a DMA piece = 8 rows x 128 bytes; lane -> row lane >> 3, slot lane & 7; the slot holds source chunk
+    //      slot ^ ((row >> 1) & 7).  Wave w issues A pieces w*PA .. and B pieces w*PB ..
     const bf16_t* ga[C::PA];
-    const bf16_t* gb[C::PB_MAX];
+    const bf16_t* gb[C::PB];
 #pragma unroll
-    for (int i = 0; i < C::PA; ++i) ga[i] = A + (long)(m0 + (wave * C::PA + i) * 16 + prow) * d.lda + pkc;
-#pragma unroll
-    for (int i = 0; i < C::PB_MAX; ++i) {
-        int pb = wave + 8 * i;
-        if (pb >= C::B_PIECES) pb = wave;                        // never issued (see nb below); keeps the address valid
-        gb[i] = B + (long)(n0 + pb * 16 + prow) * d.ldb + pkc;
+    for (int i = 0; i < C::PA; ++i) {
+        const int row = (wave * C::PA + i) * 8 + (lane >> 3);
+        ga[i] = A + (long)(m0 + row) * d.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
     }
-    const int nb = (C::SPLIT == 0 || wave < C::SPLIT) ? C::PB_MAX : C::PB_MIN;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i) {
+        const int row = (wave * C::PB + i) * 8 + (lane >> 3);
+        gb[i] = B + (long)(n0 + row) * d.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
     auto issue = [&](int kt, int stage) {
         unsigned char* sb = smem + stage * C::STAGE;
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < C::PA; ++i) glds16(ga[i] + k0, sb + (wave * C::PA + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < C::PB_MAX; ++i)
-            if (i < nb) glds16(gb[i] + k0, sb + C::A_BYTES + (wave + 8 * i) * 1024);
-    };
-    // allow `tiles` whole tiles of this wave's pieces to stay in flight
-    auto wait_tiles = [&](int tiles) {
-        if (C::SPLIT == 0 || wave < C::SPLIT) {
-            if (tiles >= 3) wait_vm<3 * (C::PA + C::PB_MAX)>(); else if (tiles == 2) wait_vm<2 * (C::PA + C::PB_MAX)>();
-            else if (tiles == 1) wait_vm<C::PA + C::PB_MAX>(); else wait_vm<0>();
-        } else {
-            if (tiles >= 3) wait_vm<3 * (C::PA + C::PB_MIN)>(); else if (tiles == 2) wait_vm<2 * (C::PA + C::PB_MIN)>();
-            else if (tiles == 1) wait_vm<C::PA + C::PB_MIN>(); else wait_vm<0>();
-        }
+        for (int i = 0; i < C::PB; ++i) glds16(gb[i] + k0, sb + C::A_BYTES + (wave * C::PB + i) * 1024);
     };
 
     // ---- fragment reads: 32 rows x 16 k per ds_read_b128; lane (row = lane & 31, kh = lane >> 5)
-    const int fr = lane & 31, kh = lane >> 5, sw = (fr >> 2) & 3;
-    int koff[2];
+    const int fr = lane & 31, kh = lane >> 5, sw = (fr >> 1) & 7;
+    int koff[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) koff[ks] = ((2 * ks + kh) ^ sw) << 4;
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = ((2 * ks + kh) ^ sw) << 4;
     const int a_row = (wm * C::WTM + fr) * ROWB;                  // token rows of this wave (MFMA column operand)
     const int b_row = C::A_BYTES + (wn * C::WTN + fr) * ROWB;     // weight rows (MFMA row operand)
-    auto read_frags = [&](const unsigned char* base, int ks, bf16x8 (&tf)[C::MB], bf16x8 (&wf)[C::NB]) {
-#pragma unroll
-        for (int j = 0; j < C::MB; ++j) tf[j] = *reinterpret_cast<const bf16x8*>(base + a_row + j * 32 * ROWB + koff[ks]);
-#pragma unroll
-        for (int i = 0; i < C::NB; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + b_row + i * 32 * ROWB + koff[ks]);
-    };
-    auto mma = [&](f32x16 (&acc)[C::NB][C::MB], const bf16x8 (&tf)[C::MB], const bf16x8 (&wf)[C::NB]) {
-#pragma unroll
-        for (int i = 0; i < C::NB; ++i)
-#pragma unroll
-            for (int j = 0; j < C::MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], tf[j], acc[i][j], 0, 0, 0);
-    };
 
     f32x16 acc[C::NB][C::MB];
 #pragma unroll
@@ -152,36 +124,38 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ---- main loop: two waves share a SIMD (w and w + 4).  Waves 4-7 run ONE SEGMENT behind waves 0-3, so on every SIMD one
-    //      wave multiplies (12 MFMAs on fragments it already holds) while its partner reads the next tile's fragments from
-    //      LDS, issues its DMA pieces and sits out its counted vmcnt wait: the matrix pipe never waits for an LDS read.
-    //          waves 0-3:  L0 | C0 | L1 | C1 | L2 | ...        (| = s_barrier)
-    //          waves 4-7:  -- | L0 | C0 | L1 | C1 | ...
-    //      L_t: read the fragments of tile t; refill the stage tile t-1 used (both halves finished reading it before the
-    //      barrier that opened this segment); wait until tile t+1 has landed, leaving S-2 tiles in flight.
     const int nk = d.K / BK;
-    const int grp = wave >> 2;
-    const int npro = nk < C::S ? nk : C::S;   // the whole ring
-    for (int t = 0; t < npro; ++t) issue(t, t);
-    wait_tiles(npro - 1);                     // tile 0 has landed (this wave's pieces) ...
-    __builtin_amdgcn_s_barrier();             // ... and everybody's
-    if (grp) __builtin_amdgcn_s_barrier();    // the stagger
-    bf16x8 tf0[C::MB], wf0[C::NB], tf1[C::MB], wf1[C::NB];
-    int st = 0;                               // stage of tile t
+    issue(0, 0);
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();             // tile 0 visible to all
+    if (grp) {
+        if (nk > 1) issue(1, 1);              // this half's pieces of tile 1 (the other half issues its own in L0)
+        __builtin_amdgcn_s_barrier();         // the stagger
+    }
     for (int t = 0; t < nk; ++t) {
-        const unsigned char* cur = smem + st * C::STAGE;
-        if (!(d.dbg & 4)) {
-            read_frags(cur, 0, tf0, wf0);
-            read_frags(cur, 1, tf1, wf1);
+        const unsigned char* cur = smem + (t & 1) * C::STAGE;
+        // ---- L_t
+        bf16x8 tf[4][C::MB], wf[4][C::NB];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int j = 0; j < C::MB; ++j) tf[ks][j] = *reinterpret_cast<const bf16x8*>(cur + a_row + j * 32 * ROWB + koff[ks]);
+#pragma unroll
+            for (int i = 0; i < C::NB; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + b_row + i * 32 * ROWB + koff[ks]);
         }
-        if (t >= 1 && t - 1 + C::S < nk && !(d.dbg & 1)) issue(t - 1 + C::S, st == 0 ? C::S - 1 : st - 1);
-        // tiles issued so far: min(nk, t + S); everything beyond tile t+1 may stay in flight
-        const int issued = t + C::S < nk ? t + C::S : nk;
-        wait_tiles(issued - t - 2);
+        if (!grp) { if (t + 1 < nk) issue(t + 1, (t + 1) & 1); }
+        else wait_vm0();                      // waves 4-7: their pieces of tile t+1 (issued a step ago) have landed
         __builtin_amdgcn_s_barrier();
-        if (!(d.dbg & 2)) { mma(acc, tf0, wf0); mma(acc, tf1, wf1); }
+        // ---- C_t
+        if (grp && t + 2 < nk) issue(t + 2, t & 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < C::NB; ++i)
+#pragma unroll
+                for (int j = 0; j < C::MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
+        if (!grp) wait_vm0();                 // waves 0-3: their pieces of tile t+1 have landed
         __builtin_amdgcn_s_barrier();
-        st = st + 1 == C::S ? 0 : st + 1;
     }
     if (!grp) __builtin_amdgcn_s_barrier();
     __syncthreads();                          // every wave is done with the operand buffers: reuse them for the C image
@@ -242,8 +216,8 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     }
 }
 
-typedef NtCfg<256, 192, 4, 2, 5> Nt192;
-typedef NtCfg<256, 128, 4, 2, 5> Nt128;
+typedef NtCfg<256, 192, 4, 2> Nt192;
+typedef NtCfg<256, 128, 4, 2> Nt128;
 
 inline int nt_pick(int M, int N, int K)
 {
@@ -272,7 +246,7 @@ int launch_nt(const void* A, const void* B, void* Cout, const float* bias, const
 
 }  // namespace
 
-// 1 if vvae_gemm_nt_bf16 takes this shape (M % 256 == 0, K % 32 == 0, N % 192 == 0 or N % 128 == 0, 16-byte aligned pitches).
+// 1 if vvae_gemm_nt_bf16 takes this shape (M % 256 == 0, K % 64 == 0, N % 192 == 0 or N % 128 == 0, 16-byte aligned pitches).
 extern "C" int vvae_gemm_nt_supported(int M, int N, int K, int lda, int ldb, int ldc)
 {
     return (nt_pick(M, N, K) && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && lda >= K && ldb >= K && ldc >= N) ? 1 : 0;
@@ -288,8 +262,7 @@ extern "C" int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
         ((uintptr_t)B % 16) || ((uintptr_t)C % 16)) return VVAE_ERR_BAD_ARG;
     if ((epi == EPI_RES || epi == EPI_MUL_DSILU) && (!res || ldr % 8 || ldr < N || ((uintptr_t)res % 16))) return VVAE_ERR_BAD_ARG;
     if (epi == EPI_SILU && (!C2 || ldc2 % 8 || ldc2 < N || ((uintptr_t)C2 % 16))) return VVAE_ERR_BAD_ARG;
-    static const int dbg = getenv("VVAE_NT_DBG") ? atoi(getenv("VVAE_NT_DBG")) : 0;   // ablation hook (bench only)
-    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, dbg};
+    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi};
     hipStream_t s = (hipStream_t)stream;
     if (nt_pick(M, N, K) == 192) return launch_nt<Nt192>(A, B, C, bias, res, C2, d, s);
     return launch_nt<Nt128>(A, B, C, bias, res, C2, d, s);
