@@ -8,4 +8,4 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES S
   i=$((i+1))
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag/p$i -- python "$@" > $R/gpurun_out/pmc_$tag.p$i.log 2>&1 || echo "pass $i failed"
 done
-cd $R && python scratch/pmc_sum.py gpurun_out/pmc_$tag
+cd $R && python tools/pmc_sum.py gpurun_out/pmc_$tag

@@ -1,7 +1,7 @@
 import torch, sys
 sys.path.insert(0, ".")
 from video_vae_amd import ops
-sys.path.insert(0, "tests")
+
 from oracle import layers as OL
 dev = "cuda"
 def tmg(f, n=10):
