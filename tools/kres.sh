@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_kres.sh file.hip  -> kernel name, VGPRs, spills, occupancy, LDS
+# usage: tools/kres.sh file.hip  -> kernel name, VGPRs, spills, occupancy, LDS
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -c "$1" -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur=None
