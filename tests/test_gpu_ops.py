@@ -597,6 +597,44 @@ def test_gemm_tn_weight_gradient(dev, m, n, k, big):
     assert none is None and torch.equal(c, c3)
 
 
+def test_gemm_tn_grouped_deferred(dev):
+    """Parked Linear weight gradients multiplied in one grouped launch (whole-K tiles, no slabs) straight into the flat gradient
+    slots == the per-product split-K kernel; bias sums included; the optimizer is told which slots are already in place."""
+    import types
+    ops = _ops()
+    k = 1024
+    shapes = [(768, 1536), (512, 768), (1536, 768), (256, 256), (768, 768), (1536, 1536), (512, 512), (768, 512), (256, 1536), (1536, 256),
+              (1536, 1536)]
+    items, want = [], []
+    marked = []
+    opt = types.SimpleNamespace(mark_external=lambda p: marked.append(p))
+    for i, (m, n) in enumerate(shapes):
+        a = rnd((k, m), 120 + i).to(dev, torch.bfloat16); b = rnd((k, n), 140 + i).to(dev, torch.bfloat16)
+        kern = torch.nn.Parameter(torch.zeros(m, n, device=dev)); bias = torch.nn.Parameter(torch.zeros(n, device=dev))
+        kern.gview = torch.full((m, n), 7.0, device=dev); bias.gview = torch.full((n,), 7.0, device=dev)
+        items.append((a, b, kern, bias))
+        want.append(ops.gemm_tn(a, b, True))
+    assert sum((m // 256) * (n // 256) for m, n in shapes) >= ops.GROUP_MIN_TILES
+    ops.WGRAD_QUEUE[0] = []
+    try:
+        for a, b, kern, bias in items:
+            assert ops.wgrad_deferrable(a, b, kern, bias)
+    finally:
+        ops.WGRAD_QUEUE[0] = None
+    ops.flush_wgrad(items, opt)
+    for (a, b, kern, bias), (dw, db) in zip(items, want):
+        assert_close_scaled(kern.gview, dw, rel=2e-5, what="grouped dW vs split-K dW")
+        assert_close_scaled(bias.gview, db, rel=2e-5, what="grouped db")
+        assert_close_scaled(kern.gview, a.float().t() @ b.float(), rel=1e-4, what="grouped dW vs fp32")
+    assert len(marked) == 2 * len(items)
+    # a short queue takes the per-product path and lands in the same slots
+    for a, b, kern, bias in items[:2]:
+        kern.gview.fill_(3.0); bias.gview.fill_(3.0)
+    ops.flush_wgrad(items[:2], opt)
+    for (a, b, kern, bias), (dw, db) in zip(items[:2], want[:2]):
+        assert torch.equal(kern.gview, dw) and torch.equal(bias.gview, db)
+
+
 @pytest.mark.parametrize("ci,co,shape", [(32, 16, (2, 3, 6, 10)), (64, 32, (1, 2, 5, 7)), (128, 64, (1, 2, 4, 8)), (32, 16, (1, 5, 32, 40)),
                                          (128, 64, (2, 4, 16, 16))])
 def test_conv_transpose_wgrad_bf16(dev, ci, co, shape):

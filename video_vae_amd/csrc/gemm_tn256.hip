@@ -56,25 +56,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p)
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ slab,
-                                                            float* __restrict__ slab_db, Dims d)
+// One 256 x 256 output tile over tokens [k_beg, k_beg + nk * 32): out[m][n] (row pitch ld_out, already offset to the tile's
+// matrix) += nothing -- it is WRITTEN: a split-K slab or, with the whole K range, the final gradient.  out_db (or NULL): column sums of
+// B for this tile's columns (only meaningful for m-tile 0).
+__device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int lda, int ldb, int m0, int n0, int k_beg,
+                                           int nk, float* __restrict__ out, int ld_out, float* __restrict__ out_db)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
-
-    // workgroup -> (split, tile): consecutive logical ids (tiles of one split are neighbours: they share the split's operand
-    // panels) stay on one XCD.  Bijective form of the XCD remap (grid size need not be a multiple of 8).
-    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int tiles = d.tiles_m * d.tiles_n;
-    const int sp = L / tiles, tile = L - sp * tiles;
-    const int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int k_beg = sp * d.klen;
-    int k_end = k_beg + d.klen;
-    if (k_end > d.K) k_end = d.K;
-    const int nk = (k_end - k_beg) / KS;                         // >= 1 by construction of the grid
 
     // ---- DMA: piece = 2 token rows x 512 B.  lane -> row 2*piece + (lane >> 5), slot lane & 31; the slot holds source chunk
     //      slot ^ ((row & 3) << 2).  Wave w issues pieces 2w, 2w+1 of A and of B.
@@ -84,12 +74,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __rest
     for (int i = 0; i < 2; ++i) {
         const int row = 2 * (2 * wave + i) + (lane >> 5);
         const int chunk = (lane & 31) ^ ((row & 3) << 2);
-        ga[i] = A + (long)(k_beg + row) * d.lda + m0 + chunk * 8;
-        gb[i] = B + (long)(k_beg + row) * d.ldb + n0 + chunk * 8;
+        ga[i] = A + (long)(k_beg + row) * lda + m0 + chunk * 8;
+        gb[i] = B + (long)(k_beg + row) * ldb + n0 + chunk * 8;
     }
     auto issue = [&](int t, int stage) {
         unsigned char* sb = smem + stage * STAGE + (2 * wave) * 1024;
-        const long ka = (long)t * KS * d.lda, kb = (long)t * KS * d.ldb;
+        const long ka = (long)t * KS * lda, kb = (long)t * KS * ldb;
         glds16(ga[0] + ka, sb);
         glds16(ga[1] + ka, sb + 1024);
         glds16(gb[0] + kb, sb + OPB);
@@ -122,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __rest
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) accb[j][e] = 0.f;
-    const bool do_bias = slab_db != nullptr && tm == 0 && wm == 0;           // wave-uniform
+    const bool do_bias = out_db != nullptr && wm == 0;                       // wave-uniform
     const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
@@ -164,9 +154,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __rest
     }
     if (!grp) __builtin_amdgcn_s_barrier();
 
-    // ---- partial tile -> slab.  acc[ib][jb][r]: m = 128 wm + 32 ib + 8 (r/4) + 4 kh + r%4, n = 64 wn + 32 jb + (lane & 31):
+    // ---- tile -> memory.  acc[ib][jb][r]: m = 128 wm + 32 ib + 8 (r/4) + 4 kh + r%4, n = 64 wn + 32 jb + (lane & 31):
     //      one store instruction writes two 128-byte row segments
-    float* out = slab + (long)sp * d.M * d.N;
     const int nl = lane & 31;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
@@ -175,12 +164,48 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 128 * wm + 32 * ib + 8 * (r >> 2) + 4 * kh + (r & 3);
-                out[(long)m * d.N + n0 + 64 * wn + 32 * jb + nl] = acc[ib][jb][r];
+                out[(long)m * ld_out + n0 + 64 * wn + 32 * jb + nl] = acc[ib][jb][r];
             }
     if (do_bias && kh == 0) {
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) slab_db[(long)sp * d.N + n0 + 64 * wn + 32 * jb + nl] = accb[jb][0];
+        for (int jb = 0; jb < 2; ++jb) out_db[n0 + 64 * wn + 32 * jb + nl] = accb[jb][0];
     }
+}
+
+// split-K form: slab[split][M][N], slab_db[split][N]
+__global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ slab,
+                                                            float* __restrict__ slab_db, Dims d)
+{
+    // workgroup -> (split, tile): consecutive logical ids (tiles of one split are neighbours: they share the split's operand
+    // panels) stay on one XCD.  Bijective form of the XCD remap (grid size need not be a multiple of 8).
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int tiles = d.tiles_m * d.tiles_n;
+    const int sp = L / tiles, tile = L - sp * tiles;
+    const int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
+    const int k_beg = sp * d.klen;
+    int k_end = k_beg + d.klen;
+    if (k_end > d.K) k_end = d.K;
+    tn256_tile(A, B, d.lda, d.ldb, tm * BM, tn * BN, k_beg, (k_end - k_beg) / KS, slab + (long)sp * d.M * d.N, d.N,
+               (slab_db && tm == 0) ? slab_db + (long)sp * d.N : nullptr);
+}
+
+// grouped form: up to 32 weight-gradient products that share K (the tokens of one step) in ONE launch, one whole-K tile per
+// workgroup -- with >= 256 tiles in flight nothing is split, so there are no slabs and no reduction pass: every tile is written
+// once, straight into its parameter's slot of the optimizer's flat gradient buffer.
+struct GroupProb { const bf16_t* A; const bf16_t* B; float* C; float* db; int M, N, lda, ldb, tiles_n, tile_start; };
+struct GroupArgs { GroupProb p[32]; int nprob, K; };
+
+__global__ __launch_bounds__(512, 1) void gemm_tn256_grouped_kernel(GroupArgs g)
+{
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    int pi = 0;
+    for (int i = 1; i < g.nprob; ++i) pi = L >= g.p[i].tile_start ? i : pi;      // uniform scan (tile_start ascending)
+    const GroupProb& P = g.p[pi];
+    const int tile = L - P.tile_start;
+    const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+    tn256_tile(P.A, P.B, P.lda, P.ldb, tm * BM, tn * BN, 0, g.K / KS, P.C, P.N, (P.db && tm == 0) ? P.db : nullptr);
 }
 
 // splits so that tiles x splits ~ one workgroup per CU, each with at least 8 k-steps
@@ -219,4 +244,37 @@ int launch(const void* A, int lda, const void* B, int ldb, float* slab, float* s
     return e == hipSuccess ? 0 : (int)e;
 }
 
+int launch_grouped(const GroupArgs& g, int total_tiles, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3(total_tiles), dim3(512), LDS_BYTES, s, g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // namespace tn256
+
+// Grouped dense weight gradients: for i < n: C_i (M_i, N_i) fp32 (contiguous, overwritten) = A_i^T B_i, db_i (N_i) fp32 or NULL =
+// column sums of B_i, with A_i (K, M_i) / B_i (K, N_i) bf16 token-major (row pitches lda_i / ldb_i), all sharing K.
+// n <= 32, M_i and N_i multiples of 256, K a multiple of 32.  One launch, one whole-K 256 x 256 tile per workgroup: no split-K slabs
+// and no reduction pass (meant for >= ~200 tiles per call so the chip is full without splitting K).
+extern "C" int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C,
+                                         float* const* db, const int* M, const int* N, int n, int K, void* stream)
+{
+    if (!A || !lda || !B || !ldb || !C || !db || !M || !N || n <= 0 || n > 32 || K <= 0 || K % tn256::KS) return VVAE_ERR_BAD_ARG;
+    tn256::GroupArgs g;
+    g.nprob = n; g.K = K;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!A[i] || !B[i] || !C[i] || !tn256::supported(M[i], N[i], K, lda[i], ldb[i]) || ((uintptr_t)A[i] % 16) || ((uintptr_t)B[i] % 16) ||
+            ((uintptr_t)C[i] % 16)) return VVAE_ERR_BAD_ARG;
+        g.p[i] = tn256::GroupProb{(const bf16_t*)A[i], (const bf16_t*)B[i], C[i], db[i], M[i], N[i], lda[i], ldb[i], N[i] / tn256::BN, tiles};
+        tiles += (M[i] / tn256::BM) * (N[i] / tn256::BN);
+    }
+    return tn256::launch_grouped(g, tiles, (hipStream_t)stream);
+}

@@ -20,6 +20,7 @@ import gc
 import torch
 
 from . import loss as L
+from . import ops
 
 
 class GraphedTrainStep:
@@ -40,7 +41,9 @@ class GraphedTrainStep:
             loss, aux = L.loss_fn_plain(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
         # torch.autograd.grad instead of .backward(): no AccumulateGrad nodes take part, so nothing created on another stream
         # (e.g. by the optimizer's hooks at construction time) can leak a cross-stream dependency into the capture
-        grads = torch.autograd.grad(loss, self.opt.params, allow_unused=True)
+        self.opt.external = set()
+        with ops.deferred_wgrad(self.opt):               # dense weight gradients: parked, then grouped launches into the flat buffer
+            grads = torch.autograd.grad(loss, self.opt.params, allow_unused=True)
         self.opt.land_all(grads)
         return loss.detach(), {k: v.detach() for k, v in aux.items() if k != "reconstruction"}
 

@@ -47,6 +47,7 @@ class _LinearBf16(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, wb)
         ctx.xshape = x.shape
+        ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the parked gradient is to be written
         return torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1])
 
     @staticmethod
@@ -57,6 +58,10 @@ class _LinearBf16(torch.autograd.Function):
             dy2 = dy2.to(torch.bfloat16)
         dx = torch.mm(dy2, wb.t()).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = db = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ops.wgrad_deferrable(x2, dy2, ctx.kparam, ctx.bparam):
+            # parked: multiplied after backward in a grouped launch, straight into the optimizer's flat gradient buffer
+            ops.WGRAD_QUEUE[0].append((x2, dy2, ctx.kparam, ctx.bparam))
+            return dx, None, None
         if ctx.needs_input_grad[1] and ops.gemm_tn_supported(x2, dy2):
             # split-K weight-gradient GEMM on the HIP kernel (bias gradient rides along): K = tokens >> M, N
             dw, db = ops.gemm_tn(x2, dy2, ctx.needs_input_grad[2])

@@ -110,7 +110,8 @@ def train_step(model, optimizer, video, mask, hparams, hw, rngs, perceptual_loss
         loss, aux = loss_fn(model, video, emask, original_mask, rngs, hparams, perceptual_loss_fn, vgg_params)
     else:
         loss, aux = loss_fn_plain(model, video, emask, original_mask, rngs, hparams)
-    loss.backward()
+    with ops.deferred_wgrad(optimizer):
+        loss.backward()
     optimizer.update()
     return loss.detach(), aux
 

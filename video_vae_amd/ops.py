@@ -910,6 +910,96 @@ def gemm_nt(a, b, bias=None, res=None, epi=EPI_NONE):
     return (c, c2) if epi == EPI_SILU else c
 
 
+# --------------------------------------------------------------------------------------------- deferred, grouped dense weight gradients
+WGRAD_QUEUE = [None]          # a list while a ``deferred_wgrad`` block is open: Linear backward parks (x, dy, kernel, bias) there
+GROUP_MAX = 32                # products per grouped launch (kernel-argument table)
+GROUP_MIN_TILES = 128         # below this many 256x256 tiles a launch cannot fill the chip without splitting K: per-product path
+
+
+class deferred_wgrad:
+    """``with deferred_wgrad(optimizer): loss.backward()``.
+
+    Weight gradients are not on backward's critical path (only the input gradients are), so the Linear layers of the transformer
+    trunk park their (input, output-gradient) pairs instead of launching one split-K product each; on exit the pairs are multiplied
+    in grouped launches -- hundreds of whole-K tiles at once, so nothing is split and nothing is reduced -- straight into the
+    parameters' slots of the optimizer's flat gradient buffer (``param.gview``), which the optimizer is told about
+    (``optimizer.external``) so that it neither zeroes nor copies them.
+    """
+
+    def __init__(self, optimizer):
+        self.opt = optimizer
+
+    def __enter__(self):
+        WGRAD_QUEUE[0] = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        q, WGRAD_QUEUE[0] = WGRAD_QUEUE[0], None
+        if et is None:
+            flush_wgrad(q, self.opt)
+        return False
+
+
+def wgrad_deferrable(x2, dy2, kernel, bias):
+    """Linear.backward asks: may this product be parked?  (bf16 GPU operands, flat-buffer slots present, 256-multiples.)"""
+    if WGRAD_QUEUE[0] is None or getattr(kernel, "gview", None) is None or (bias is not None and getattr(bias, "gview", None) is None):
+        return False
+    k, m = x2.shape
+    n = dy2.shape[1]
+    return (x2.is_cuda and x2.dtype == torch.bfloat16 and dy2.dtype == torch.bfloat16 and x2.stride(1) == 1 and dy2.stride(1) == 1
+            and m % 256 == 0 and n % 256 == 0 and k % 32 == 0 and x2.stride(0) % 8 == 0 and dy2.stride(0) % 8 == 0
+            and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0)
+
+
+def flush_wgrad(queue, optimizer):
+    """Run the parked weight-gradient products (see deferred_wgrad)."""
+    if not queue:
+        return
+    seen = set()
+    groups = {}
+    for x2, dy2, kernel, bias in queue:
+        key = id(kernel)
+        if key in seen:                                  # a weight used twice in one step would need accumulation: not supported here
+            raise VvaeError("deferred_wgrad: a Linear kernel was used twice in one backward pass")
+        seen.add(key)
+        groups.setdefault(x2.shape[0], []).append((x2, dy2, kernel, bias))
+    for k, items in groups.items():
+        i = 0
+        while i < len(items):
+            chunk = items[i:i + GROUP_MAX]
+            i += GROUP_MAX
+            tiles = sum((x2.shape[1] // 256) * (dy2.shape[1] // 256) for x2, dy2, _, _ in chunk)
+            if tiles >= GROUP_MIN_TILES:
+                _gemm_tn_grouped(chunk, k)
+            else:
+                for x2, dy2, kernel, bias in chunk:
+                    dw, db = gemm_tn(x2, dy2, bias is not None)
+                    kernel.gview.copy_(dw)
+                    if bias is not None:
+                        bias.gview.copy_(db)
+    for _, _, kernel, bias in queue:
+        optimizer.mark_external(kernel)
+        if bias is not None:
+            optimizer.mark_external(bias)
+
+
+def _gemm_tn_grouped(chunk, k):
+    n = len(chunk)
+    VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    a = VP(*[x2.data_ptr() for x2, _, _, _ in chunk])
+    b = VP(*[dy2.data_ptr() for _, dy2, _, _ in chunk])
+    c = VP(*[kn.gview.data_ptr() for _, _, kn, _ in chunk])
+    db = VP(*[(bi.gview.data_ptr() if bi is not None else None) for _, _, _, bi in chunk])
+    lda = IA(*[x2.stride(0) for x2, _, _, _ in chunk])
+    ldb = IA(*[dy2.stride(0) for _, dy2, _, _ in chunk])
+    ms = IA(*[x2.shape[1] for x2, _, _, _ in chunk])
+    ns = IA(*[dy2.shape[1] for _, dy2, _, _ in chunk])
+    flops = sum(2 * k * x2.shape[1] * dy2.shape[1] for x2, dy2, _, _ in chunk)
+    nbytes = sum(k * (x2.shape[1] + dy2.shape[1]) * 2 + x2.shape[1] * dy2.shape[1] * 4 for x2, dy2, _, _ in chunk)
+    check(_launch(f"gemm_tn_grouped x{n} K{k}", nbytes, flops, "gemm_tn256_grouped_kernel",
+                  lambda: lib().vvae_gemm_tn_grouped_bf16(a, lda, b, ldb, c, db, ms, ns, n, k, _stream())), "vvae_gemm_tn_grouped_bf16")
+
+
 # --------------------------------------------------------------------------------------------- dense weight-gradient GEMM
 def gemm_tn_supported(a, b):
     return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2

@@ -74,6 +74,7 @@ class Optimizer:
             p.data = self.p[o:o + n].view(p.shape)
             p.grad = None
             self.gviews.append(self.g[o:o + n].view(p.shape))
+            p.gview = self.gviews[-1]                             # written directly by ops.deferred_wgrad
             if self.shadow is not None:
                 p.bf16 = self.shadow[o:o + n].view(p.shape)       # read by layers.Linear: no per-call weight casts
         if self.shadow is not None:
@@ -92,6 +93,8 @@ class Optimizer:
                 start, members = e, []
         self.arrived = [0] * len(self.buckets)
         self.landed = [False] * len(self.buckets)
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.external = set()          # parameter indices whose flat-buffer slot was written directly this step
         self.reducer = None            # set by ddp.GradReducer
         self.defer_reduce = False      # graph mode: do not launch collectives from the landing hooks (see graph.py)
         for i, p in enumerate(self.params):
@@ -112,7 +115,9 @@ class Optimizer:
         dsts, srcs = [], []
         for i in self.bucket_params[b]:
             p = self.params[i]
-            if p.grad is None:
+            if i in self.external:
+                pass                                              # already in place (ops.deferred_wgrad)
+            elif p.grad is None:
                 self.gviews[i].zero_()
             elif p.grad.data_ptr() != self.gviews[i].data_ptr():
                 dsts.append(self.gviews[i])
@@ -128,7 +133,9 @@ class Optimizer:
     def land_all(self, grads):
         """Install gradients given in ``self.params`` order (None = zero), e.g. from torch.autograd.grad (graph capture)."""
         dsts, srcs = [], []
-        for gv, gr in zip(self.gviews, grads):
+        for i, (gv, gr) in enumerate(zip(self.gviews, grads)):
+            if i in self.external:
+                continue                                          # already in place (ops.deferred_wgrad)
             if gr is None:
                 gv.zero_()
             else:
@@ -138,7 +145,12 @@ class Optimizer:
             torch._foreach_copy_(dsts, srcs)
         self.landed = [True] * len(self.buckets)
 
+    def mark_external(self, param):
+        """The gradient of ``param`` has been written straight into its flat-buffer slot for this step."""
+        self.external.add(self.index[id(param)])
+
     def zero_grad(self):
+        self.external = set()
         for p in self.params:
             p.grad = None
         self.arrived = [0] * len(self.buckets)
