@@ -192,7 +192,7 @@ int vvae_gemm_tn_supported(int M, int N, int K, int lda, int ldb);
 size_t vvae_gemm_tn_ws_bytes(int M, int N, int K);
 int vvae_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, float* db, int M, int N, int K,
                       void* ws, size_t ws_bytes, void* stream);
-/* Grouped form: n <= 32 weight gradients that share K in one launch, one whole-K 256x256 tile per workgroup (no split-K slabs,
+/* Grouped form: n <= 64 weight gradients that share K in one launch, one whole-K 256x256 tile per workgroup (no split-K slabs,
  * no reduction pass): C_i (M_i, N_i) fp32 contiguous = A_i^T B_i, db_i (N_i) or NULL; M_i, N_i % 256 == 0, K % 32 == 0.  The arrays
  * are host arrays of device pointers / ints. */
 int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C,

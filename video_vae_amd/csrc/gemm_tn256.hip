@@ -190,11 +190,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __rest
                (slab_db && tm == 0) ? slab_db + (long)sp * d.N : nullptr);
 }
 
-// grouped form: up to 32 weight-gradient products that share K (the tokens of one step) in ONE launch, one whole-K tile per
+// grouped form: up to 64 weight-gradient products that share K (the tokens of one step) in ONE launch, one whole-K tile per
 // workgroup -- with >= 256 tiles in flight nothing is split, so there are no slabs and no reduction pass: every tile is written
 // once, straight into its parameter's slot of the optimizer's flat gradient buffer.
 struct GroupProb { const bf16_t* A; const bf16_t* B; float* C; float* db; int M, N, lda, ldb, tiles_n, tile_start; };
-struct GroupArgs { GroupProb p[32]; int nprob, K; };
+constexpr int GROUP_MAX = 64;
+struct GroupArgs { GroupProb p[GROUP_MAX]; int nprob, K; };        // 3 KB of kernel arguments
 
 __global__ __launch_bounds__(512, 1) void gemm_tn256_grouped_kernel(GroupArgs g)
 {
@@ -261,12 +262,12 @@ int launch_grouped(const GroupArgs& g, int total_tiles, hipStream_t s)
 
 // Grouped dense weight gradients: for i < n: C_i (M_i, N_i) fp32 (contiguous, overwritten) = A_i^T B_i, db_i (N_i) fp32 or NULL =
 // column sums of B_i, with A_i (K, M_i) / B_i (K, N_i) bf16 token-major (row pitches lda_i / ldb_i), all sharing K.
-// n <= 32, M_i and N_i multiples of 256, K a multiple of 32.  One launch, one whole-K 256 x 256 tile per workgroup: no split-K slabs
+// n <= 64, M_i and N_i multiples of 256, K a multiple of 32.  One launch, one whole-K 256 x 256 tile per workgroup: no split-K slabs
 // and no reduction pass (meant for >= ~200 tiles per call so the chip is full without splitting K).
 extern "C" int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C,
                                          float* const* db, const int* M, const int* N, int n, int K, void* stream)
 {
-    if (!A || !lda || !B || !ldb || !C || !db || !M || !N || n <= 0 || n > 32 || K <= 0 || K % tn256::KS) return VVAE_ERR_BAD_ARG;
+    if (!A || !lda || !B || !ldb || !C || !db || !M || !N || n <= 0 || n > tn256::GROUP_MAX || K <= 0 || K % tn256::KS) return VVAE_ERR_BAD_ARG;
     tn256::GroupArgs g;
     g.nprob = n; g.K = K;
     int tiles = 0;

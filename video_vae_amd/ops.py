@@ -912,7 +912,8 @@ def gemm_nt(a, b, bias=None, res=None, epi=EPI_NONE):
 
 # --------------------------------------------------------------------------------------------- deferred, grouped dense weight gradients
 WGRAD_QUEUE = [None]          # a list while a ``deferred_wgrad`` block is open: Linear backward parks (x, dy, kernel, bias) there
-GROUP_MAX = 32                # products per grouped launch (kernel-argument table)
+GROUP_MAX = 64                # products per grouped launch (kernel-argument table)
+GROUP_TILES = 512             # close a group once it holds about this many 256x256 tiles: two full rounds over 256 CUs
 GROUP_MIN_TILES = 128         # below this many 256x256 tiles a launch cannot fill the chip without splitting K: per-product path
 
 
@@ -964,11 +965,15 @@ def flush_wgrad(queue, optimizer):
         seen.add(key)
         groups.setdefault(x2.shape[0], []).append((x2, dy2, kernel, bias))
     for k, items in groups.items():
-        i = 0
-        while i < len(items):
-            chunk = items[i:i + GROUP_MAX]
-            i += GROUP_MAX
-            tiles = sum((x2.shape[1] // 256) * (dy2.shape[1] // 256) for x2, dy2, _, _ in chunk)
+        chunks, cur, cur_tiles = [], [], 0
+        for it in items:                                  # greedy: groups of ~GROUP_TILES tiles (whole rounds over the CUs)
+            t = (it[0].shape[1] // 256) * (it[1].shape[1] // 256)
+            if cur and (len(cur) == GROUP_MAX or cur_tiles + t > GROUP_TILES):
+                chunks.append((cur, cur_tiles)); cur, cur_tiles = [], 0
+            cur.append(it); cur_tiles += t
+        if cur:
+            chunks.append((cur, cur_tiles))
+        for chunk, tiles in chunks:
             if tiles >= GROUP_MIN_TILES:
                 _gemm_tn_grouped(chunk, k)
             else:
