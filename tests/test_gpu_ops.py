@@ -621,7 +621,10 @@ def test_gemm_tn_grouped_deferred(dev):
             assert ops.wgrad_deferrable(a, b, kern, bias)
     finally:
         ops.WGRAD_QUEUE[0] = None
-    ops.flush_wgrad(items, opt)
+    q = ops._WgradQueue(opt)
+    for it in items:
+        q.append(it)
+    q.flush()
     for (a, b, kern, bias), (dw, db) in zip(items, want):
         assert_close_scaled(kern.gview, dw, rel=2e-5, what="grouped dW vs split-K dW")
         assert_close_scaled(bias.gview, db, rel=2e-5, what="grouped db")

@@ -42,6 +42,7 @@ class GraphedTrainStep:
         # torch.autograd.grad instead of .backward(): no AccumulateGrad nodes take part, so nothing created on another stream
         # (e.g. by the optimizer's hooks at construction time) can leak a cross-stream dependency into the capture
         self.opt.external = set()
+        self.opt.hooks_active = False                    # gradients arrive through land_all below, not through the hooks
         with ops.deferred_wgrad(self.opt):               # dense weight gradients: parked, then grouped launches into the flat buffer
             grads = torch.autograd.grad(loss, self.opt.params, allow_unused=True)
         self.opt.land_all(grads)

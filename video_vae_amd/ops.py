@@ -921,24 +921,46 @@ class deferred_wgrad:
     """``with deferred_wgrad(optimizer): loss.backward()``.
 
     Weight gradients are not on backward's critical path (only the input gradients are), so the Linear layers of the transformer
-    trunk park their (input, output-gradient) pairs instead of launching one split-K product each; on exit the pairs are multiplied
-    in grouped launches -- hundreds of whole-K tiles at once, so nothing is split and nothing is reduced -- straight into the
-    parameters' slots of the optimizer's flat gradient buffer (``param.gview``), which the optimizer is told about
-    (``optimizer.external``) so that it neither zeroes nor copies them.
+    trunk park their (input, output-gradient) pairs instead of launching one split-K product each; whenever about GROUP_TILES
+    256x256 tiles have been parked (and on exit) the pairs are multiplied in ONE grouped launch -- hundreds of whole-K tiles at
+    once, so nothing is split and nothing is reduced -- straight into the parameters' slots of the optimizer's flat gradient buffer
+    (``param.gview``).  The optimizer is told (``optimizer.mark_external``) so that it neither zeroes nor copies those slots and
+    can hand completed gradient buckets to the data-parallel reducer while backward is still running.
     """
 
     def __init__(self, optimizer):
         self.opt = optimizer
 
     def __enter__(self):
-        WGRAD_QUEUE[0] = []
+        WGRAD_QUEUE[0] = _WgradQueue(self.opt)
         return self
 
     def __exit__(self, et, ev, tb):
         q, WGRAD_QUEUE[0] = WGRAD_QUEUE[0], None
         if et is None:
-            flush_wgrad(q, self.opt)
+            q.flush()
         return False
+
+
+class _WgradQueue:
+    def __init__(self, optimizer):
+        self.opt, self.items, self.tiles, self.k, self.seen = optimizer, [], 0, None, set()
+
+    def append(self, item):
+        x2, dy2, kernel, bias = item
+        if id(kernel) in self.seen:                          # a weight used twice in one step would need accumulation
+            raise VvaeError("deferred_wgrad: a Linear kernel was used twice in one backward pass")
+        self.seen.add(id(kernel))
+        t = (x2.shape[1] // 256) * (dy2.shape[1] // 256)
+        if self.items and (x2.shape[0] != self.k or len(self.items) == GROUP_MAX or self.tiles + t > GROUP_TILES):
+            self.flush()
+        self.items.append(item); self.tiles += t; self.k = x2.shape[0]
+
+    def flush(self):
+        items, tiles, k = self.items, self.tiles, self.k
+        self.items, self.tiles = [], 0
+        if items:
+            flush_wgrad(items, self.opt, tiles, k)
 
 
 def wgrad_deferrable(x2, dy2, kernel, bias):
@@ -952,37 +974,22 @@ def wgrad_deferrable(x2, dy2, kernel, bias):
             and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0)
 
 
-def flush_wgrad(queue, optimizer):
-    """Run the parked weight-gradient products (see deferred_wgrad)."""
-    if not queue:
+def flush_wgrad(items, optimizer, tiles=None, k=None):
+    """Multiply the parked pairs ``(x (K, M), dy (K, N), kernel, bias)`` (all with the same K, at most GROUP_MAX of them)."""
+    if not items:
         return
-    seen = set()
-    groups = {}
-    for x2, dy2, kernel, bias in queue:
-        key = id(kernel)
-        if key in seen:                                  # a weight used twice in one step would need accumulation: not supported here
-            raise VvaeError("deferred_wgrad: a Linear kernel was used twice in one backward pass")
-        seen.add(key)
-        groups.setdefault(x2.shape[0], []).append((x2, dy2, kernel, bias))
-    for k, items in groups.items():
-        chunks, cur, cur_tiles = [], [], 0
-        for it in items:                                  # greedy: groups of ~GROUP_TILES tiles (whole rounds over the CUs)
-            t = (it[0].shape[1] // 256) * (it[1].shape[1] // 256)
-            if cur and (len(cur) == GROUP_MAX or cur_tiles + t > GROUP_TILES):
-                chunks.append((cur, cur_tiles)); cur, cur_tiles = [], 0
-            cur.append(it); cur_tiles += t
-        if cur:
-            chunks.append((cur, cur_tiles))
-        for chunk, tiles in chunks:
-            if tiles >= GROUP_MIN_TILES:
-                _gemm_tn_grouped(chunk, k)
-            else:
-                for x2, dy2, kernel, bias in chunk:
-                    dw, db = gemm_tn(x2, dy2, bias is not None)
-                    kernel.gview.copy_(dw)
-                    if bias is not None:
-                        bias.gview.copy_(db)
-    for _, _, kernel, bias in queue:
+    if tiles is None:
+        tiles = sum((x2.shape[1] // 256) * (dy2.shape[1] // 256) for x2, dy2, _, _ in items)
+        k = items[0][0].shape[0]
+    if tiles >= GROUP_MIN_TILES:
+        _gemm_tn_grouped(items, k)
+    else:                                                    # too few tiles to fill the chip without splitting K
+        for x2, dy2, kernel, bias in items:
+            dw, db = gemm_tn(x2, dy2, bias is not None)
+            kernel.gview.copy_(dw)
+            if bias is not None:
+                bias.gview.copy_(db)
+    for _, _, kernel, bias in items:
         optimizer.mark_external(kernel)
         if bias is not None:
             optimizer.mark_external(bias)

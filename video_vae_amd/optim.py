@@ -95,6 +95,7 @@ class Optimizer:
         self.landed = [False] * len(self.buckets)
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.external = set()          # parameter indices whose flat-buffer slot was written directly this step
+        self.hooks_active = True       # False while gradients arrive through land_all (graph capture) instead of the hooks
         self.reducer = None            # set by ddp.GradReducer
         self.defer_reduce = False      # graph mode: do not launch collectives from the landing hooks (see graph.py)
         for i, p in enumerate(self.params):
@@ -146,8 +147,15 @@ class Optimizer:
         self.landed = [True] * len(self.buckets)
 
     def mark_external(self, param):
-        """The gradient of ``param`` has been written straight into its flat-buffer slot for this step."""
-        self.external.add(self.index[id(param)])
+        """The gradient of ``param`` has been written straight into its flat-buffer slot for this step (ops.deferred_wgrad):
+        it counts as arrived, so a completed bucket goes to the reducer while backward is still running."""
+        i = self.index[id(param)]
+        self.external.add(i)
+        if self.hooks_active:
+            b = self.param_bucket[i]
+            self.arrived[b] += 1
+            if self.arrived[b] == len(self.bucket_params[b]) and not self.landed[b]:
+                self._land(b)
 
     def zero_grad(self):
         self.external = set()
