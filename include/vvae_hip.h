@@ -214,6 +214,9 @@ int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, i
 
 /* out[c] = sum_r part[r][c] in fixed order: folds the per-workgroup partial rows of the backward kernels (cols % 4 == 0). */
 int vvae_sum_rows(const float* part, int rows, int cols, float* out, void* stream);
+/* n <= 64 partial buffers folded in one launch: part[i] fp32 (rows[i], cols[i]); columns [0, n0[i]) -> d0[i], the rest -> d1[i] (or NULL). */
+int vvae_fold_rows_grouped(const void* const* part, float* const* d0, float* const* d1, const int* rows, const int* cols,
+                           const int* n0, int n, void* stream);
 
 #ifdef __cplusplus
 }

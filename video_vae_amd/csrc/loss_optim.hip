@@ -369,3 +369,61 @@ extern "C" int vvae_sum_rows(const float* part, int rows, int cols, float* out, 
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
+// Grouped fold: up to 64 partial buffers in one launch (the dgamma / dbeta / q-k-scale partial rows of a whole backward pass).
+// Entry e: out[c] = sum_r part_e[r * cols_e + c]; columns < n0_e go to d0_e[c], the rest to d1_e[c - n0_e] (or nowhere if d1_e is
+// NULL).  Blocks [block_start_e, block_start_{e+1}) belong to entry e, 32 columns each; same row order as vvae_reduce_rows_kernel.
+constexpr int FOLD_MAX = 64;
+struct FoldEntry { const float* part; float* d0; float* d1; int rows, cols, n0, block_start; };
+struct FoldArgs { FoldEntry e[FOLD_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void fold_rows_grouped_kernel(FoldArgs g)
+{
+    __shared__ float red[8][32];
+    int ei = 0;
+    for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].block_start ? i : ei;
+    const FoldEntry& E = g.e[ei];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x - E.block_start) * 32 + cl;
+    float s = 0.f;
+    if (c < E.cols) {
+        for (int r0 = rl; r0 < E.rows; r0 += 8 * 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + 8 * i;
+                v[i] = r < E.rows ? E.part[(long)r * E.cols + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < E.cols) {
+        const float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+        if (c < E.n0) E.d0[c] = t;
+        else if (E.d1) E.d1[c - E.n0] = t;
+    }
+}
+}  // namespace
+
+// n <= 64 partial buffers folded in one launch.  part[i]: fp32 (rows[i], cols[i]) contiguous; d0[i] receives columns [0, n0[i]),
+// d1[i] (or NULL) columns [n0[i], cols[i]).  Host arrays of device pointers / ints.  Fixed row order: deterministic.
+extern "C" int vvae_fold_rows_grouped(const void* const* part, float* const* d0, float* const* d1, const int* rows, const int* cols,
+                                      const int* n0, int n, void* stream)
+{
+    if (!part || !d0 || !d1 || !rows || !cols || !n0 || n <= 0 || n > FOLD_MAX) return VVAE_ERR_BAD_ARG;
+    FoldArgs g;
+    g.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!part[i] || !d0[i] || rows[i] <= 0 || cols[i] <= 0 || n0[i] <= 0 || n0[i] > cols[i]) return VVAE_ERR_BAD_ARG;
+        g.e[i] = FoldEntry{(const float*)part[i], d0[i], d1[i], rows[i], cols[i], n0[i], blocks};
+        blocks += ceil_div(cols[i], 32);
+    }
+    hipLaunchKernelGGL(fold_rows_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

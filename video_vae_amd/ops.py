@@ -55,6 +55,20 @@ def _ws(nbytes, device):
     return buf, nbytes
 
 
+def fold_partials(part, p0, p1, n0):
+    """Column sums of the per-workgroup partial rows ``part`` (rows, cols): columns [0, n0) are the gradient of parameter
+    ``p0``, the rest that of ``p1`` (None: dropped).  Inside ``deferred_wgrad`` (and when the parameters own flat-buffer slots)
+    the fold is parked and runs with up to 63 others in one launch straight into those slots: returns (None, None).  Otherwise
+    returns the two sums."""
+    q = WGRAD_QUEUE[0]
+    if (q is not None and p0 is not None and part.is_cuda and getattr(p0, "gview", None) is not None and p0.numel() == n0
+            and (p1 is None or (getattr(p1, "gview", None) is not None and p1.numel() == part.numel() // part.shape[0] - n0))):
+        q.append_fold(part, p0, p1)
+        return None, None
+    tot = sum_rows(part).reshape(-1)
+    return tot[:n0], tot[n0:]
+
+
 def sum_rows(part):
     """Column sums of a (rows, ...) fp32 partial buffer in fixed order -> shape part.shape[1:] (no memset, no atomics).
 
@@ -461,6 +475,7 @@ class _TemporalAttn(torch.autograd.Function):
         else:
             check(lib().vvae_temporal_attn_fwd(_p(qkv), ld, _p(out), heads * d, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div,
                                                a, t, heads, d, eps, dt, _stream()), "vvae_temporal_attn_fwd")
+        ctx.qparam, ctx.kparam = q_scale, k_scale
         ctx.save_for_backward(qkv, qs, ks, cos, sin, mask, out, lse)
         ctx.args = (mask_div, heads, eps, q_scale.dtype, fast, inner, a, t)
         return out
@@ -484,8 +499,9 @@ class _TemporalAttn(torch.autograd.Function):
                                                                     _p(qs), _p(ks), _p(cos), _p(sin), _p(mask), mask_div, inner,
                                                                     _p(part), a, t, heads, d, eps, dt, _stream())),
                   "vvae_temporal_attn_bwd_fast")
-            tot = sum_rows(part)
-            dqs, dks = tot[:d], tot[d:]
+            dqs, dks = fold_partials(part, ctx.qparam, ctx.kparam, d)
+            if dqs is None:
+                return dqkv, None, None, None, None, None, None, None, None, None
         else:
             dqs = torch.empty((d,), dtype=torch.float32, device=qkv.device)
             dks = torch.empty((d,), dtype=torch.float32, device=qkv.device)
@@ -530,7 +546,7 @@ def qk_prep_fwd_raw(qkv, qs, ks, cos, sin, heads, eps=1e-6):
     return qk
 
 
-def qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps=1e-6):
+def qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps=1e-6, params=None):
     """dq, dk, dv: (a, heads, s, D) gradients (any strides) -> (dqkv (a, s, 3*heads*D), dq_scale (D), dk_scale (D)) (no autograd)."""
     a, s, c3 = qkv.shape
     hd = c3 // 3
@@ -546,8 +562,8 @@ def qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps=1e-6):
                   lambda: lib().vvae_qk_prep_bwd(_p(qkv), c3, _p(dq), dq_ts, dq_hs, _p(dk), dk_ts, dk_hs, _p(dv), dv_ts, dv_hs,
                                                  _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(part), tokens, s, heads, d, eps,
                                                  _dt(qkv), _stream())), "vvae_qk_prep_bwd")
-    tot = sum_rows(part)
-    return dqkv, tot[0], tot[1]
+    g0, g1 = fold_partials(part, params[0], params[1], d) if params is not None else fold_partials(part, None, None, d)
+    return dqkv, g0, g1
 
 
 SPATIAL_FORCE_LIBRARY_CORE = [False]      # test hook: keep the prep kernels + library flash core even where the fused kernels apply
@@ -573,7 +589,7 @@ def spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads, eps=1e-6):
     return out, lse2
 
 
-def spatial_attn_bwd_raw(qkv, out, lse2, dout, qs, ks, cos, sin, heads, eps=1e-6):
+def spatial_attn_bwd_raw(qkv, out, lse2, dout, qs, ks, cos, sin, heads, eps=1e-6, params=None):
     """-> (dqkv (a, s, 3*heads*64), dq_scale (64), dk_scale (64)) of the fused spatial attention (no autograd)."""
     a, s, c3 = qkv.shape
     hd = c3 // 3
@@ -585,8 +601,8 @@ def spatial_attn_bwd_raw(qkv, out, lse2, dout, qs, ks, cos, sin, heads, eps=1e-6
                   lambda: lib().vvae_spatial_attn_bwd(_p(qkv), c3, _p(out), hd, _p(dout), hd, _p(lse2), _p(dqkv), c3, _p(qs), _p(ks),
                                                       _p(cos), _p(sin), _p(part), a, s, heads, d, eps, _dt(qkv), _stream())),
           "vvae_spatial_attn_bwd")
-    tot = sum_rows(part)
-    return dqkv, tot[0], tot[1]
+    g0, g1 = fold_partials(part, params[0], params[1], d) if params is not None else fold_partials(part, None, None, d)
+    return dqkv, g0, g1
 
 
 class _SpatialAttnFused(torch.autograd.Function):
@@ -599,6 +615,7 @@ class _SpatialAttnFused(torch.autograd.Function):
         out, lse2 = spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads, eps)
         ctx.save_for_backward(qkv, qs, ks, cos, sin, out, lse2)
         ctx.misc = (heads, eps, q_scale.dtype)
+        ctx.qparam, ctx.kparam = q_scale, k_scale
         return out
 
     @staticmethod
@@ -606,7 +623,9 @@ class _SpatialAttnFused(torch.autograd.Function):
         qkv, qs, ks, cos, sin, out, lse2 = ctx.saved_tensors
         heads, eps, pdtype = ctx.misc
         do = do.to(qkv.dtype).contiguous()
-        dqkv, dqs, dks = spatial_attn_bwd_raw(qkv, out, lse2, do, qs, ks, cos, sin, heads, eps)
+        dqkv, dqs, dks = spatial_attn_bwd_raw(qkv, out, lse2, do, qs, ks, cos, sin, heads, eps, (ctx.qparam, ctx.kparam))
+        if dqs is None:
+            return dqkv, None, None, None, None, None, None
         return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None
 
 
@@ -637,6 +656,7 @@ class _SpatialAttn(torch.autograd.Function):
         out, lse, cq, ck, mq, mk, seed, off, _ = torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, False, False)
         ctx.save_for_backward(qkv, qs, ks, cos, sin, qk, out, lse, seed, off)
         ctx.misc = (cq, ck, mq, mk, heads, eps, q_scale.dtype)
+        ctx.qparam, ctx.kparam = q_scale, k_scale
         return out.transpose(1, 2).reshape(a, s, c3 // 3)
 
     @staticmethod
@@ -648,7 +668,9 @@ class _SpatialAttn(torch.autograd.Function):
         do4 = do.to(qkv.dtype).reshape(a, s, heads, c3 // (3 * heads)).transpose(1, 2)
         dq, dk, dv = torch.ops.aten._scaled_dot_product_flash_attention_backward(do4, q, k, v, out, lse, cq, ck, mq, mk, 0.0, False,
                                                                                  seed, off)
-        dqkv, dqs, dks = qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps)
+        dqkv, dqs, dks = qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps, (ctx.qparam, ctx.kparam))
+        if dqs is None:
+            return dqkv, None, None, None, None, None, None
         return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None
 
 
@@ -797,6 +819,7 @@ class _LayerNorm(torch.autograd.Function):
                                                        eps, dt, _stream())), "vvae_layernorm_fwd")
         ctx.save_for_backward(x, s32, mean, rstd)
         ctx.args = (n, c, inner, op, ip, scale.dtype, bias is not None)
+        ctx.sparam, ctx.bparam = scale, bias
         ctx.set_materialize_grads(False)
         if fork:
             return y, x_in.view_as(x_in)
@@ -826,8 +849,10 @@ def _ln_backward(ctx, dy, dskip):
                   "layernorm_bwd_kernel",
                   lambda: lib().vvae_layernorm_bwd(_p(x), _p(dy), _p(s32), _p(mean), _p(rstd), _p(dskip), _p(dx), _p(part), n, c, inner,
                                                    op, ip, dt, _stream())), "vvae_layernorm_bwd")
-    tot = sum_rows(part)
-    return dx, tot[0].to(pdtype), (tot[1].to(pdtype) if has_bias else None)
+    g0, g1 = fold_partials(part, ctx.sparam, ctx.bparam, c)
+    if g0 is None:
+        return dx, None, None
+    return dx, g0.to(pdtype), (g1.to(pdtype) if has_bias else None)
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -851,6 +876,7 @@ class _AddLayerNorm(torch.autograd.Function):
                                                        eps, dt, _stream())), "vvae_layernorm_fwd")
         ctx.save_for_backward(xs, s32, mean, rstd)
         ctx.args = (n, c, 1, c, 0, scale.dtype, bias is not None)
+        ctx.sparam, ctx.bparam = scale, bias
         ctx.set_materialize_grads(False)
         return y, xs
 
@@ -939,12 +965,39 @@ class deferred_wgrad:
         q, WGRAD_QUEUE[0] = WGRAD_QUEUE[0], None
         if et is None:
             q.flush()
+            q.flush_folds()
         return False
+
+
+FOLD_MAX = 64                 # partial buffers per grouped fold launch
 
 
 class _WgradQueue:
     def __init__(self, optimizer):
         self.opt, self.items, self.tiles, self.k, self.seen = optimizer, [], 0, None, set()
+        self.folds = []                                      # parked (partial rows, param0, param1) of LayerNorm / q-k-norm scales
+
+    def append_fold(self, part, p0, p1):
+        self.folds.append((part, p0, p1))
+        if len(self.folds) == FOLD_MAX:
+            self.flush_folds()
+
+    def flush_folds(self):
+        folds, self.folds = self.folds, []
+        if not folds:
+            return
+        n = len(folds)
+        VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        rows = [f[0].shape[0] for f in folds]
+        cols = [f[0].numel() // f[0].shape[0] for f in folds]
+        n0 = [f[1].numel() for f in folds]
+        check(lib().vvae_fold_rows_grouped(VP(*[f[0].data_ptr() for f in folds]), VP(*[f[1].gview.data_ptr() for f in folds]),
+                                           VP(*[(f[2].gview.data_ptr() if f[2] is not None else None) for f in folds]),
+                                           IA(*rows), IA(*cols), IA(*n0), n, _stream()), "vvae_fold_rows_grouped")
+        for _, p0, p1 in folds:
+            self.opt.mark_external(p0)
+            if p1 is not None:
+                self.opt.mark_external(p1)
 
     def append(self, item):
         x2, dy2, kernel, bias = item
