@@ -276,7 +276,7 @@ extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, co
         LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, (const float*)addend, (float*)xsum, d);
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
-        dim3 grid(ln_blocks(rows, lpr, 2048));
+        dim3 grid(ln_blocks(rows, lpr, 1024));          // 4096 waves: all resident at 6 waves/SIMD (2048 left a third-full second round)
         LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
