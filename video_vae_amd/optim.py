@@ -95,6 +95,7 @@ class Optimizer:
         self.landed = [False] * len(self.buckets)
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.external = set()          # parameter indices whose flat-buffer slot was written directly this step
+        self.clean = set(range(len(self.params)))     # slots known to hold zeros (self.g starts zeroed)
         self.hooks_active = True       # False while gradients arrive through land_all (graph capture) instead of the hooks
         self.reducer = None            # set by ddp.GradReducer
         self.defer_reduce = False      # graph mode: do not launch collectives from the landing hooks (see graph.py)
@@ -117,12 +118,17 @@ class Optimizer:
         for i in self.bucket_params[b]:
             p = self.params[i]
             if i in self.external:
-                pass                                              # already in place (ops.deferred_wgrad)
+                self.clean.discard(i)                             # already in place (ops.deferred_wgrad)
             elif p.grad is None:
-                self.gviews[i].zero_()
+                if i not in self.clean:                           # a slot nobody has written since it was last zeroed stays zero
+                    self.gviews[i].zero_()
+                    self.clean.add(i)
             elif p.grad.data_ptr() != self.gviews[i].data_ptr():
+                self.clean.discard(i)
                 dsts.append(self.gviews[i])
                 srcs.append(p.grad)
+            else:
+                self.clean.discard(i)
             p.grad = None
         if dsts:
             torch._foreach_copy_(dsts, srcs)
@@ -136,10 +142,14 @@ class Optimizer:
         dsts, srcs = [], []
         for i, (gv, gr) in enumerate(zip(self.gviews, grads)):
             if i in self.external:
+                self.clean.discard(i)
                 continue                                          # already in place (ops.deferred_wgrad)
             if gr is None:
-                gv.zero_()
+                if i not in self.clean:                           # a slot nobody has written since it was last zeroed stays zero
+                    gv.zero_()
+                    self.clean.add(i)
             else:
+                self.clean.discard(i)
                 dsts.append(gv)
                 srcs.append(gr)
         if dsts:
