@@ -123,6 +123,7 @@ int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, 
 
 /* lane-per-frame form of the same core for head_dim D in {8,16,32,64} (the production path): forward also writes the
  * row log-sum-exp `lse` (A*heads, T) fp32; backward consumes (out, lse) and writes per-workgroup partials of the
+ * cos_table / sin_table of the _fast, qk_prep and spatial entry points: fp32 values ALREADY rounded to the activation dtype.
  * q_norm / k_norm scale gradients: dscale_part (vvae_temporal_attn_fast_blocks(...), 2*D) fp32, summed by the caller.
  * inner = 1: sequences contiguous (A,T,C).  inner = hw: tensors are (b,t,hw,C), sequence a = b*hw+i strides over frames
  * (no transpose copies around the temporal half of FactoredAttention). */

@@ -3,6 +3,10 @@
 // A head row of D channels is split over LPR adjacent lanes, DL = D/LPR channels each.  Lane p owns channels
 // [p*HL, (p+1)*HL) and [D/2 + p*HL, D/2 + (p+1)*HL), HL = DL/2, so the RoPE rotate-half partner of every channel sits in
 // the SAME lane; LayerNorm sums finish with one or two quad-DPP adds (reference train/layers.py:100-128,159-163).
+//
+// RoPE tables: the kernels built on these helpers take cos / sin tables whose values are ALREADY rounded to the activation dtype
+// (the reference multiplies by tables cast to q's dtype, layers.py:113-114): the caller rounds them once, the kernels do not
+// spend four conversions per rotated pair on it.
 #pragma once
 #include "common.hpp"
 
@@ -111,8 +115,8 @@ __device__ __forceinline__ void ln_rope_row(float (&x)[D / LPR], int p, const fl
     for (int i = 0; i < S::HL; ++i) {                    // rotate-half pair (i, i + HL) = channels (c, c + D/2)
         const float lo = x[i], hi = x[i + S::HL];
         const int cl = S::ch(i, p), chh = S::ch(i + S::HL, p);
-        x[i] = round_to<T_>(round_to<T_>(lo * round_to<T_>(cosr[cl])) + round_to<T_>(-hi * round_to<T_>(sinr[cl])));
-        x[i + S::HL] = round_to<T_>(round_to<T_>(hi * round_to<T_>(cosr[chh])) + round_to<T_>(lo * round_to<T_>(sinr[chh])));
+        x[i] = round_to<T_>(round_to<T_>(lo * cosr[cl]) + round_to<T_>(-hi * sinr[cl]));
+        x[i + S::HL] = round_to<T_>(round_to<T_>(hi * cosr[chh]) + round_to<T_>(lo * sinr[chh]));
     }
 }
 
@@ -127,8 +131,8 @@ __device__ __forceinline__ void rope_ln_bwd_row(float (&g)[D / LPR], float (&xh)
     for (int i = 0; i < S::HL; ++i) {                    // RoPE transpose on the (i, i+HL) pair
         const float lo = g[i], hi = g[i + S::HL];
         const int cl = S::ch(i, p), chh = S::ch(i + S::HL, p);
-        g[i] = lo * round_to<T_>(cosr[cl]) + hi * round_to<T_>(sinr[chh]);
-        g[i + S::HL] = hi * round_to<T_>(cosr[chh]) - lo * round_to<T_>(sinr[cl]);
+        g[i] = lo * cosr[cl] + hi * sinr[chh];
+        g[i + S::HL] = hi * cosr[chh] - lo * sinr[cl];
     }
     float sc[S::DL];
     load_tab<T_, D, LPR>(scale, p, sc);

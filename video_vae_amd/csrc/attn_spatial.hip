@@ -55,8 +55,8 @@ __device__ __forceinline__ void ln_rope_frag(float (&x)[4][8], int kh, const flo
         for (int e = 0; e < 8; ++e) {
             const int cl = 16 * ks + 8 * kh + e, ch = cl + 32;
             const float lo = x[ks][e], hi = x[ks + 2][e];
-            x[ks][e] = round_to<bf16_t>(round_to<bf16_t>(lo * round_to<bf16_t>(cosr[cl])) + round_to<bf16_t>(-hi * round_to<bf16_t>(sinr[cl])));
-            x[ks + 2][e] = round_to<bf16_t>(round_to<bf16_t>(hi * round_to<bf16_t>(cosr[ch])) + round_to<bf16_t>(lo * round_to<bf16_t>(sinr[ch])));
+            x[ks][e] = round_to<bf16_t>(round_to<bf16_t>(lo * cosr[cl]) + round_to<bf16_t>(-hi * sinr[cl]));
+            x[ks + 2][e] = round_to<bf16_t>(round_to<bf16_t>(hi * cosr[ch]) + round_to<bf16_t>(lo * sinr[ch]));
         }
 }
 
@@ -261,8 +261,8 @@ __device__ __forceinline__ void rope_ln_bwd_acc(float (&g)[2][16], float (&xh)[2
     for (int r = 0; r < 16; ++r) {
         const int cl = 8 * (r >> 2) + 4 * kh + (r & 3), ch = cl + 32;
         const float lo = g[0][r], hi = g[1][r];
-        g[0][r] = lo * round_to<bf16_t>(cosr[cl]) + hi * round_to<bf16_t>(sinr[ch]);
-        g[1][r] = hi * round_to<bf16_t>(cosr[ch]) - lo * round_to<bf16_t>(sinr[cl]);
+        g[0][r] = lo * cosr[cl] + hi * sinr[ch];
+        g[1][r] = hi * cosr[ch] - lo * sinr[cl];
         xh[0][r] = (xh[0][r] - mean) * rstd;
         xh[1][r] = (xh[1][r] - mean) * rstd;
         const float d0 = g[0][r] * scale[cl], d1 = g[1][r] * scale[ch];

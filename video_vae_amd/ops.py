@@ -442,6 +442,21 @@ def conv_transpose_1x2x2(x, kernel, bias):
     return _ConvT.apply(x, kernel, bias)
 
 
+_ROPE_TABS = {}
+
+
+def _rope_tabs(cos, sin, dtype):
+    """RoPE tables rounded ONCE to the activation dtype (the fused kernels take them pre-rounded; reference layers.py:113-114)."""
+    if dtype == torch.float32:
+        return cos, sin
+    key = (cos.data_ptr(), sin.data_ptr(), dtype)
+    hit = _ROPE_TABS.get(key)
+    if hit is None or hit[0] is not cos or hit[1] is not sin:
+        hit = (cos, sin, cos.to(dtype).to(torch.float32).contiguous(), sin.to(dtype).to(torch.float32).contiguous())
+        _ROPE_TABS[key] = hit
+    return hit[2], hit[3]
+
+
 # --------------------------------------------------------------------------------------------- temporal attention core
 ATTN_FORCE_GENERIC = [False]      # test hook: use the generic (any head_dim) kernels
 
@@ -460,6 +475,7 @@ class _TemporalAttn(torch.autograd.Function):
         else:
             a, t = qkv.shape[:2]
         qs, ks = _f32(q_scale), _f32(k_scale)
+        cos, sin = _rope_tabs(cos, sin, qkv.dtype)
         out = torch.empty(qkv.shape[:-1] + (heads * d,), dtype=qkv.dtype, device=qkv.device)
         fast = (not ATTN_FORCE_GENERIC[0]) and lib().vvae_temporal_attn_fast_supported(t, d, ld, heads * d, dt) == 1
         if inner > 1 and not fast:
@@ -538,6 +554,7 @@ def qk_prep_fwd_raw(qkv, qs, ks, cos, sin, heads, eps=1e-6):
     a, s, c3 = qkv.shape
     hd = c3 // 3
     d = hd // heads
+    cos, sin = _rope_tabs(cos, sin, qkv.dtype)
     qk = torch.empty((a, s, 2 * hd), dtype=qkv.dtype, device=qkv.device)
     tokens = a * s
     check(_launch(f"qk_prep_fwd S{s} D{d}", tokens * 4 * hd * qkv.element_size(), 0, "qk_prep_fwd_kernel",
@@ -554,6 +571,7 @@ def qk_prep_bwd_raw(qkv, dq, dk, dv, qs, ks, cos, sin, heads, eps=1e-6, params=N
     dq, dq_ts, dq_hs = _tok_head(dq, a, s)
     dk, dk_ts, dk_hs = _tok_head(dk, a, s)
     dv, dv_ts, dv_hs = _tok_head(dv, a, s)
+    cos, sin = _rope_tabs(cos, sin, qkv.dtype)
     tokens = a * s
     dqkv = torch.empty((a, s, c3), dtype=qkv.dtype, device=qkv.device)
     nblk = lib().vvae_qk_prep_blocks(tokens, heads, d)
@@ -580,6 +598,7 @@ def spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads, eps=1e-6):
     a, s, c3 = qkv.shape
     hd = c3 // 3
     d = hd // heads
+    cos, sin = _rope_tabs(cos, sin, qkv.dtype)
     out = torch.empty((a, s, hd), dtype=qkv.dtype, device=qkv.device)
     lse2 = torch.empty((a * heads, s), dtype=torch.float32, device=qkv.device)
     nbytes = a * s * (c3 + hd) * qkv.element_size()
@@ -594,6 +613,7 @@ def spatial_attn_bwd_raw(qkv, out, lse2, dout, qs, ks, cos, sin, heads, eps=1e-6
     a, s, c3 = qkv.shape
     hd = c3 // 3
     d = hd // heads
+    cos, sin = _rope_tabs(cos, sin, qkv.dtype)
     dqkv = torch.empty((a, s, c3), dtype=qkv.dtype, device=qkv.device)
     part = torch.empty((a * heads, 2, d), dtype=torch.float32, device=qkv.device)
     nbytes = a * s * (2 * c3 + 2 * hd) * qkv.element_size()
