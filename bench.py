@@ -223,18 +223,31 @@ def main():
             for v in summ.values():
                 f = fam.setdefault(v["kernel"], dict(n=0, ms=0.0, bytes=0.0, flops=0.0))
                 f["n"] += v["n"]; f["ms"] += v["total_ms"]; f["bytes"] += v["bytes"] * v["n"]; f["flops"] += v["flops"] * v["n"]
+            def roof(kname, top, bound=None):
+                avg_ms = top["ms"] / top["n"]
+                b_l, f_l = top["bytes"] / top["n"], top["flops"] / top["n"]
+                gbs, tfs = b_l / (avg_ms * 1e-3) / 1e9, f_l / (avg_ms * 1e-3) / 1e12
+                if bound is None:
+                    bound = "mfma" if (b_l > 0 and f_l / b_l > MFMA_PEAK_TFS * 1e3 / HBM_PEAK_GBS) else "hbm"
+                mf = bound == "mfma"
+                return {"bound": bound, "achieved": tfs if mf else gbs, "peak": MFMA_PEAK_TFS if mf else HBM_PEAK_GBS,
+                        "unit": "TFLOP/s" if mf else "GB/s", "frac": (tfs / MFMA_PEAK_TFS) if mf else (gbs / HBM_PEAK_GBS),
+                        "traffic": measured_traffic(kname), "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
+                        "launches_per_step": top["n"] / nsteps_timed, "alg_bytes_per_launch": b_l, "alg_flops_per_launch": f_l,
+                        "alg_GBps": gbs, "alg_TFLOPps": tfs, "frac_mfma": tfs / MFMA_PEAK_TFS,
+                        "kernel_ms_per_step": top["ms"] / nsteps_timed, "timed_in": timed_in}
+
+            # `roofline`: the north-star kernel -- Conv3d forward + input gradient (conv3d_bf16_roll_kernel / conv3d_bf16_kernel, every UNet layer) --
+            # priced against HBM as BASELINE.json's north_star fixes it (V*(Cin+Cout)*e bytes per launch), with its
+            # matrix-core rate beside it.  `roofline_step_dominant`: the hand-written kernel with the largest total time per step
+            # (all its shapes together), bound set by arithmetic intensity against the machine balance (312 FLOP/B).
+            conv_k = next((k for k in fam if k.startswith("conv3d_bf16")), None) or next((k for k in fam if k.startswith("conv3d")), None)
             kname, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
-            avg_ms = top["ms"] / top["n"]
-            b_l, f_l = top["bytes"] / top["n"], top["flops"] / top["n"]
-            gbs, tfs = b_l / (avg_ms * 1e-3) / 1e9, f_l / (avg_ms * 1e-3) / 1e12
-            mfma_bound = b_l > 0 and f_l / b_l > MFMA_PEAK_TFS * 1e3 / HBM_PEAK_GBS
-            out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": tfs if mfma_bound else gbs,
-                               "peak": MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                               "frac": (tfs / MFMA_PEAK_TFS) if mfma_bound else (gbs / HBM_PEAK_GBS),
-                               "traffic": measured_traffic(kname), "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
-                               "launches_per_step": top["n"] / nsteps_timed, "alg_bytes_per_launch": b_l,
-                               "alg_flops_per_launch": f_l, "alg_GBps": gbs, "alg_TFLOPps": tfs,
-                               "kernel_ms_per_step": top["ms"] / nsteps_timed, "timed_in": timed_in}
+            if conv_k is not None:
+                out["roofline"] = roof(conv_k, fam[conv_k], "hbm")
+                out["roofline_step_dominant"] = roof(kname, top)
+            else:
+                out["roofline"] = roof(kname, top)
             rows = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]
             out["kernels"] = [{"launch": k, "kernel": v["kernel"], "per_step": v["n"] / nsteps_timed, "avg_ms": round(v["avg_ms"], 4),
                                "ms_per_step": round(v["total_ms"] / nsteps_timed, 3),

@@ -379,6 +379,36 @@ def _bf16_exact(shape, seed, scale):
     return (rnd(shape, seed, scale)).to(torch.bfloat16).float()
 
 
+ROLL_CASES = [
+    # cin, cout, kh, (n, t, h, w): every single-chunk shape the rolling time-column kernel owns, fwd and dgrad roles
+    (16, 16, 3, (2, 5, 20, 24)), (16, 32, 3, (1, 7, 9, 33)), (32, 16, 3, (1, 6, 17, 16)), (32, 32, 3, (2, 5, 18, 30)),
+    (16, 16, 7, (1, 5, 21, 40)),
+]
+
+
+@pytest.mark.parametrize("case", ROLL_CASES)
+@pytest.mark.parametrize("tchunk", [0, 1, 3, 16])
+def test_conv3d_rolling_kernel_matches_per_frame(dev, case, tchunk):
+    """The rolling time-column kernel multiplies the same fragments in the same order as the per-frame kernel: outputs must be
+    bitwise equal for any frames-per-workgroup split, ragged tiles included."""
+    from video_vae_amd import ops
+    from video_vae_amd._lib import lib
+    ci, co, kh, (n, t, h, w) = case
+    x = rnd((n, t, h, w, ci), 60, 1.0).to(dev, torch.bfloat16)
+    gy = rnd((n, t, h, w, co), 61, 1.0).to(dev, torch.bfloat16)
+    k = rnd((3, kh, kh, ci, co), 62, (3 * kh * kh * ci) ** -0.5).to(dev)
+    b = rnd((co,), 63, 0.1).to(dev)
+    try:
+        lib().vvae_conv3d_roll_config(0, 0)
+        y0, dx0 = ops.conv3d_fwd_raw(x, k, b), ops.conv3d_dgrad_raw(gy, k)
+        lib().vvae_conv3d_roll_config(1, tchunk)
+        y1, dx1 = ops.conv3d_fwd_raw(x, k, b), ops.conv3d_dgrad_raw(gy, k)
+    finally:
+        lib().vvae_conv3d_roll_config(1, 0)
+    assert torch.equal(y0, y1)
+    assert torch.equal(dx0, dx1)
+
+
 @pytest.mark.parametrize("case", FAST_CASES)
 def test_conv3d_bf16_fast_path(dev, case):
     """bf16 MFMA fwd/dgrad vs (a) the generic fp32-matrix-core path on the GPU and (b) the CPU oracle.

@@ -259,6 +259,11 @@ inline size_t packed_bytes(int CK, int CO, int kt, int kh, int kw)
 
 extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw);
 
+namespace {
+bool roll_enabled();
+int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s);
+}
+
 // which: 0 fwd (K = Cin, produced = Cout), 1 dgrad (K = Cout, produced = Cin), 2 wgrad (ld_in = ldx, ld_out = lddy).
 extern "C" int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out, int which, int flags)
 {
@@ -322,6 +327,10 @@ extern "C" int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, cons
         const int rc = vvae_conv3d_pack_bf16(w, ws, ws_bytes, Cin, Cout, kt, kh, kw, dgrad, stream);
         if (rc) return rc;
     }
+    if (roll_enabled() && CK == chunk_of(CK)) {                     // single channel chunk: rolling time-column kernel
+        const int rc = launch_roll_any(xp, ldx, wp, bp, yp, ldy, d, kh, s);
+        if (rc != VVAE_ERR_BAD_ARG) return rc;
+    }
     if (kh == 7) return launch_cfg<C377_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
     if (chunk_of(CK) == 16) {
         if (CO == 16) return launch_cfg<C333_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
@@ -374,7 +383,7 @@ struct WgDims { int N, T, H, W, CI, CO, tiles_h, tiles_w, ncols, cols_per_block;
 
 // One HR x WR halo plane of 16-byte channel parts held in registers between its global fetch and its LDS store, so the
 // fetch of step t+1 can be in flight while step t computes (register-staged software pipeline).
-template <int NTHREADS, int HR, int WR, int PARTS, int PITCH>
+template <int NTHREADS, int HR, int WR, int PARTS, int PITCH, bool SWZ = false>
 struct PlaneStager {
     static constexpr int ROW_ITEMS = WR * PARTS;
     static_assert(ROW_ITEMS <= NTHREADS, "a halo row must fit one pass");
@@ -399,12 +408,232 @@ struct PlaneStager {
     __device__ __forceinline__ void store(unsigned char* __restrict__ lds, int tid) const {
         const int rip = tid / ROW_ITEMS, item = tid - rip * ROW_ITEMS;
         const int wc = item / PARTS, part = item - wc * PARTS;
-        unsigned char* l = lds + (rip * WR + wc) * PITCH + part * 16;
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it)
-            if (rip < RPP && rip + it * RPP < HR) *reinterpret_cast<uint4*>(l + it * RPP * WR * PITCH) = v[it];
+        for (int it = 0; it < ITERS; ++it) {
+            const int lin = (rip + it * RPP) * WR + wc;                    // SWZ: part ^= ((voxel >> 2) & 1) << 1 (64-byte voxels)
+            const int p = SWZ ? (part ^ ((lin >> 1) & 2)) : part;
+            if (rip < RPP && rip + it * RPP < HR) *reinterpret_cast<uint4*>(lds + lin * PITCH + p * 16) = v[it];
+        }
     }
 };
+
+// =============================================================================================== rolling forward / input gradient
+// The same product as conv3d_bf16_kernel for layers whose K channels fit one chunk (CK = 16 or 32: every 256^2 / 128^2 layer
+// and the patch mixer), restructured around TIME: a workgroup owns a spatial tile and marches over a run of frames, keeping
+// the halo planes of frames t-1, t, t+1 in a ring of four LDS slots.  Each step fetches ONE new plane (t+2) into registers
+// while step t multiplies, and parks it after the barrier -- so a plane is read from L2 once per workgroup instead of three
+// times, the staging work per output tile drops 3x and its latency hides under the MFMAs of the previous step.  One barrier
+// per step (a slot is overwritten two steps after its last reader).
+//
+// Where the packed weights live decides what bounds the inner loop: re-fetched through the vector L1 (64 B/clk/CU) they cost
+// more than the MFMAs they feed, so a march keeps them either in registers (W_REG: <= 27 fragments per wave) or in LDS behind
+// the ring (W_LDS: 256 B/clk/CU with ds_read_b128, loaded once per workgroup).  32-channel voxels are stored at their natural
+// 64-byte pitch with the 16-byte part index XORed by ((voxel >> 2) & 1) << 1, which keeps every ds_read_b128 lane group
+// ({r 0-3, 12-15 | part p} + {r 4-11 | part p^1}) on 16 distinct slots of the 256-byte bank row for any tap shift.
+enum { W_REG = 1, W_LDS = 2 };
+
+template <int CKB_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_, int WMODE_, bool PF_>
+struct RollCfg {
+    static constexpr int CKB = CKB_, KT = 3, KH = KH_, KW = KW_, MT_W = MT_W_, NT_W = NT_W_, WM = WM_, WN = WN_, WMODE = WMODE_;
+    static constexpr bool PF = PF_;                          // request the fragments of k-step j+1 before multiplying k-step j
+    static constexpr int NTHREADS = 64 * WM * WN;
+    static constexpr int TH = MT_W * WM, TW = 16, HR = TH + KH - 1, WR = TW + KW - 1;
+    static constexpr int PITCH = 2 * CKB;
+    static constexpr bool SWZ = CKB == 32;
+    static constexpr int KSTEPS = (KT * KW * CKB + 31) / 32;
+    static constexpr int PLANE = HR * WR * PITCH;
+    static constexpr int CO_T = NT_W * WN, CO_BLK = 16 * CO_T;
+    static constexpr int WFRAGS = KH * KSTEPS * CO_T;
+    static constexpr int LDS_BYTES = 4 * PLANE + (WMODE == W_LDS ? WFRAGS * 1024 : 0);
+    static_assert(CKB == 16 || CKB == 32, "channel chunk");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wp,
+                                                                       const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy,
+                                                                       BfDims d, int tchunk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CKB = C::CKB, KT = C::KT, KH = C::KH, KW = C::KW, MT_W = C::MT_W, NT_W = C::NT_W;
+    constexpr int HR = C::HR, WR = C::WR, PITCH = C::PITCH, KSTEPS = C::KSTEPS, PLANE = C::PLANE, CO_T = C::CO_T;
+    constexpr bool WREG = C::WMODE == W_REG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int r = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);       // XCD-aware: neighbours share halo columns and planes
+    const int nch = (d.T + tchunk - 1) / tchunk;
+    const int tc = bid % nch; int q = bid / nch;
+    const int tw = q % d.tiles_w; q /= d.tiles_w;
+    const int th = q % d.tiles_h; const int n = q / d.tiles_h;
+    const int h0 = th * C::TH, w0 = tw * C::TW;
+    const int t_beg = tc * tchunk;
+    int t_end = t_beg + tchunk;
+    if (t_end > d.T) t_end = d.T;
+
+    const int co_tiles = d.CO / 16;
+    const int cb0 = blockIdx.y * CO_T;                                     // first output-channel tile of this workgroup
+    const int ct0 = cb0 + wn * NT_W;                                       // ... and of this wave
+
+    uint4* wl = reinterpret_cast<uint4*>(smem + 4 * PLANE);               // W_LDS: [dy][kstep][co tile of the block][lane]
+    if (!WREG) {
+        for (int i = tid; i < C::WFRAGS * 64; i += C::NTHREADS) {
+            const int l = i & 63, f = i >> 6;
+            const int c = f % CO_T, dyj = f / CO_T;
+            wl[i] = wp[((long)dyj * co_tiles + cb0 + c) * 64 + l];
+        }
+    }
+    bf16x8 wreg[WREG ? KSTEPS : 1][KH][NT_W];
+    if (WREG) {
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j)
+#pragma unroll
+            for (int dy = 0; dy < KH; ++dy)
+#pragma unroll
+                for (int i = 0; i < NT_W; ++i)
+                    wreg[j][dy][i] = __builtin_bit_cast(bf16x8, wp[((long)(dy * KSTEPS + j) * co_tiles + ct0 + i) * 64 + lane]);
+    }
+    float bv[NT_W][4];
+#pragma unroll
+    for (int i = 0; i < NT_W; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[i][e] = bias ? bias[(ct0 + i) * 16 + 4 * g + e] : 0.f;
+
+    PlaneStager<C::NTHREADS, HR, WR, CKB / 8, PITCH, C::SWZ> sx;
+    const int hx = h0 - KH / 2, wx = w0 - KW / 2;
+    sx.fetch(x, ldx, n, t_beg - 1, hx, wx, d.T, d.H, d.W, tid);            // out-of-range frames come back as zeros
+    sx.store(smem + ((t_beg - 1) & 3) * PLANE, tid);
+    sx.fetch(x, ldx, n, t_beg, hx, wx, d.T, d.H, d.W, tid);
+    sx.store(smem + (t_beg & 3) * PLANE, tid);
+    sx.fetch(x, ldx, n, t_beg + 1, hx, wx, d.T, d.H, d.W, tid);
+    const int wo = w0 + r;
+    const int lin_w = (wm * MT_W) * WR + r;                                // this lane's voxel in the wave's first halo row
+    for (int tt = t_beg; tt < t_end; ++tt) {
+        sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
+        __syncthreads();
+        if (tt + 1 < t_end) sx.fetch(x, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
+
+        f32x4 acc[MT_W][NT_W];
+#pragma unroll
+        for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+            for (int i = 0; i < NT_W; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // PF: operand fragments of k-step j+1 are requested before the MFMAs of k-step j are issued (the scheduling fences keep
+        // the compiler from folding the two buffers back into a depth-2 read/wait/multiply chain).  Worth ~15 % on the mixer,
+        // where weights come from LDS too; the 3x3x3 layers sit at the clock-limited MFMA rate without it and prefer the VGPRs.
+        constexpr int NX = MT_W + KH - 1;
+        bf16x8 xf[2][NX];
+        bf16x8 wf[2][KH][NT_W];
+        auto request = [&](int j, bf16x8 (&xo)[NX], bf16x8 (&wo)[KH][NT_W]) {
+            if (!WREG) {
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy)
+#pragma unroll
+                    for (int i = 0; i < NT_W; ++i)
+                        wo[dy][i] = __builtin_bit_cast(bf16x8, wl[((dy * KSTEPS + j) * CO_T + wn * NT_W + i) * 64 + lane]);
+            }
+            int slot, part;
+            if (CKB == 32) { slot = j < KT * KW ? j : 0; part = g; }
+            else { slot = 2 * j + (g >> 1); if (slot >= KT * KW) slot = 0; part = g & 1; }
+            const int dt = slot / KW, dx = slot - dt * KW;
+            const unsigned char* pbase = smem + ((tt + dt - 1) & 3) * PLANE;
+            const int lin0 = lin_w + dx;
+#pragma unroll
+            for (int hr = 0; hr < NX; ++hr) {
+                const int lin = lin0 + hr * WR;
+                const int p = C::SWZ ? (part ^ ((lin >> 1) & 2)) : part;
+                xo[hr] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pbase + lin * PITCH + p * 16));
+            }
+        };
+        if (C::PF) request(0, xf[0], wf[0]);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+            if (C::PF) {
+                if (j + 1 < KSTEPS) request(j + 1, xf[(j + 1) & 1], wf[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                request(j, xf[j & 1], wf[j & 1]);
+            }
+#pragma unroll
+            for (int hr = 0; hr < NX; ++hr) {
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy) {
+                    const int m = hr - dy;
+                    if (m >= 0 && m < MT_W) {
+#pragma unroll
+                        for (int i = 0; i < NT_W; ++i)
+                            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WREG ? wreg[WREG ? j : 0][dy][i] : wf[j & 1][dy][i],
+                                                                                xf[j & 1][hr], acc[m][i], 0, 0, 0);
+                    }
+                }
+            }
+            if (C::PF) __builtin_amdgcn_sched_barrier(0);
+        }
+        // D[row = co 4g+j][col = voxel r]; lane stores 4 consecutive channels (8 bytes) of one voxel
+#pragma unroll
+        for (int m = 0; m < MT_W; ++m) {
+            const int ho = h0 + wm * MT_W + m;
+            if (ho >= d.H || wo >= d.W) continue;
+            const long v = (((long)n * d.T + tt) * d.H + ho) * d.W + wo;
+#pragma unroll
+            for (int i = 0; i < NT_W; ++i) {
+                uint2 o;
+                o.x = (uint32_t)f2bf(acc[m][i][0] + bv[i][0]) | ((uint32_t)f2bf(acc[m][i][1] + bv[i][1]) << 16);
+                o.y = (uint32_t)f2bf(acc[m][i][2] + bv[i][2]) | ((uint32_t)f2bf(acc[m][i][3] + bv[i][3]) << 16);
+                *reinterpret_cast<uint2*>(y + v * ldy + (ct0 + i) * 16 + 4 * g) = o;
+            }
+        }
+    }
+}
+
+int g_roll = 1, g_roll_tchunk = 0;
+
+bool roll_enabled() { return g_roll != 0; }
+
+template <class C>
+int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s)
+{
+    d.tiles_h = ceil_div(d.H, C::TH);
+    d.tiles_w = ceil_div(d.W, C::TW);
+    const long cols = (long)d.N * d.tiles_h * d.tiles_w * (d.CO / C::CO_BLK);
+    const long want = C::LDS_BYTES > 80 * 1024 ? 512 : 2048;             // ~2 workgroups per CU slot
+    int tchunk = d.T;                                                      // whole clip per workgroup unless that starves the chip
+    while (tchunk > 2 && cols * ceil_div(d.T, tchunk) < want) tchunk = (tchunk + 1) / 2;
+    if (g_roll_tchunk > 0) tchunk = g_roll_tchunk;
+    dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk)), d.CO / C::CO_BLK);
+    auto k = conv3d_bf16_roll_kernel<C>;
+    static bool attr_done = false;
+    if (C::LDS_BYTES > 65536 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+//              CKB KH KW MT_W NT_W WM WN weights prefetch                 (per-layer sweep: tools/conv_bench.py)
+typedef RollCfg<16, 7, 7, 2, 1, 8, 1, W_LDS, true> R377;         // patch mixer: TH 16, 77 KB of weights behind a 61 KB ring
+typedef RollCfg<16, 3, 3, 4, 1, 4, 1, W_REG, false> R16_16;      // TH 16
+typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false> R16_32;      // TH 8, one output-channel tile per wave
+typedef RollCfg<32, 3, 3, 2, 1, 8, 1, W_REG, false> R32_16;      // TH 16, 8 waves
+typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false> R32_32;      // TH 16, 8 waves, one output-channel tile per wave
+
+#define ROLL(C) return launch_roll<C>(x, ldx, wp, bias, y, ldy, d, s)
+int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s)
+{
+    if (kh == 7) ROLL(R377);
+    if (d.CK == 16 && d.CO == 16) ROLL(R16_16);
+    if (d.CK == 16 && d.CO == 32) ROLL(R16_32);
+    if (d.CK == 32 && d.CO == 16) ROLL(R32_16);
+    if (d.CK == 32 && d.CO == 32) ROLL(R32_32);
+    return VVAE_ERR_BAD_ARG;                                               // >= 64 output channels: the per-frame kernel is as fast
+}
+#undef ROLL
 
 template <class C>
 __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy,
@@ -639,4 +868,11 @@ extern "C" int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, in
     if (i32) return launch_wgrad_cfg<W333_32_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     if (o32) return launch_wgrad_cfg<W333_16_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     return launch_wgrad_cfg<W333_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+}
+
+// Test / tuning hook: on = 0 routes single-chunk layers through the per-frame kernel again; tchunk > 0 forces the frames per workgroup.
+extern "C" int vvae_conv3d_roll_config(int on, int tchunk)
+{
+    g_roll = on; g_roll_tchunk = tchunk;
+    return 0;
 }

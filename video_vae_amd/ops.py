@@ -154,7 +154,7 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad):
         ws, wsb = _ws(wsb, x.device)
         check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, 1 if dgrad else 0, _stream()),
               "vvae_conv3d_pack_bf16")
-        check(_launch(tag, alg, flops, "conv3d_bf16_kernel",
+        check(_launch(tag, alg, flops, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
                       lambda: lib().vvae_conv3d_fwd_bf16(_p(x), ldx, None, _p(bias), _p(out), ldo, n, t, h, w, cin, cout, kt, kh,
                                                          kw, 1 if dgrad else 0, 1, _p(ws), wsb, _stream())),
               "vvae_conv3d_fwd_bf16")
