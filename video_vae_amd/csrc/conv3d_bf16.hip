@@ -368,13 +368,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int row16_byte
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CIB_, int COB_, int KH_, int KW_, int TH_>
+template <int CIB_, int COB_, int KH_, int KW_, int TH_, int MINW_ = 1>
 struct WgCfg {
+    static constexpr int MINW = MINW_;                                       // waves per SIMD the register allocation must leave room for
+    static constexpr int BLOCKS = 256 * MINW;                                // persistent grid = what the chip holds at once (3-wave workgroups)
     static constexpr int CIB = CIB_, COB = COB_, KT = 3, KH = KH_, KW = KW_, TH = TH_, TW = 32;
     static constexpr int CIT = CIB / 16, COT = COB / 16;
     static constexpr int HR = TH + KH - 1, WR = TW + KW - 1;
-    static constexpr int PX = CIB == 16 ? 32 : 96, PY = COB == 16 ? 32 : 96;
-    static constexpr int PLANE = HR * WR * PX, YBYTES = TH * TW * PY;      // one X halo plane, one dY tile
+    static constexpr int PX = 2 * CIB, PY = COB == 16 ? 32 : 96;             // 32-channel X voxels: 64-byte pitch, swizzled parts
+    static constexpr bool SWX = CIB == 32;
+    static constexpr int WRP = SWX ? ((WR + 7) & ~7) : WR;                  // rows a multiple of 8 voxels: the swizzle bit is row-independent
+    static constexpr int PLANE = HR * WRP * PX, YBYTES = TH * TW * PY;      // one X halo plane, one dY tile
     static constexpr int LDS_BYTES = 4 * PLANE + 2 * YBYTES;               // ring of 4 planes + double-buffered dY
     static constexpr int SLAB_FLOATS = KT * KH * KW * CIB * COB + COB;     // + dbias partial
 };
@@ -383,7 +387,7 @@ struct WgDims { int N, T, H, W, CI, CO, tiles_h, tiles_w, ncols, cols_per_block;
 
 // One HR x WR halo plane of 16-byte channel parts held in registers between its global fetch and its LDS store, so the
 // fetch of step t+1 can be in flight while step t computes (register-staged software pipeline).
-template <int NTHREADS, int HR, int WR, int PARTS, int PITCH, bool SWZ = false>
+template <int NTHREADS, int HR, int WR, int PARTS, int PITCH, bool SWZ = false, int WRP = WR>   // WRP: LDS row pitch in voxels
 struct PlaneStager {
     static constexpr int ROW_ITEMS = WR * PARTS;
     static_assert(ROW_ITEMS <= NTHREADS, "a halo row must fit one pass");
@@ -410,7 +414,7 @@ struct PlaneStager {
         const int wc = item / PARTS, part = item - wc * PARTS;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int lin = (rip + it * RPP) * WR + wc;                    // SWZ: part ^= ((voxel >> 2) & 1) << 1 (64-byte voxels)
+            const int lin = (rip + it * RPP) * WRP + wc;                   // SWZ: part ^= ((voxel >> 2) & 1) << 1 (64-byte voxels)
             const int p = SWZ ? (part ^ ((lin >> 1) & 2)) : part;
             if (rip < RPP && rip + it * RPP < HR) *reinterpret_cast<uint4*>(lds + lin * PITCH + p * 16) = v[it];
         }
@@ -636,7 +640,7 @@ int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias
 #undef ROLL
 
 template <class C>
-__global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(192, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy,
                                                                 int lddy, float* __restrict__ slab, WgDims d)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
     const int ci0 = (blockIdx.y / co_subs) * CIB, co0 = (blockIdx.y % co_subs) * COB;
     // transposed-read lane offsets: lane (g = l>>4, q = (l>>2)&3, p = l&3) addresses voxel row 4g+q, channels 4p..4p+3
     const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-    const int loffx = (4 * g + qq) * PX + 8 * pp, loffy = (4 * g + qq) * PY + 8 * pp;
+    const int lvox = 4 * g + qq, loffy = (4 * g + qq) * PY + 8 * pp;
 
     f32x4 acc[KH][KW][CIT][COT];
 #pragma unroll
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
     const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
-    PlaneStager<192, HR, WR, CIB / 8, PX> sx;
+    PlaneStager<192, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx;
     PlaneStager<192, TH, TW, COB / 8, PY> sy;
     const bf16_t* xsrc = x + ci0;
     const bf16_t* ysrc = dy + co0;
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
             }
             const unsigned char* ys = ybuf + (tt & 1) * C::YBYTES;
             bf16x8 bfr[KH][COT];                                  // rolling window of dY fragments: row h lives in slot h % KH
-            const unsigned char* xplane = ring + ((tt + wave - 1) & 3) * C::PLANE + loffx;
+            const unsigned char* xplane = ring + ((tt + wave - 1) & 3) * C::PLANE + 8 * pp;
 #pragma unroll
             for (int hr = 0; hr < HR; ++hr) {
                 if (hr < TH) {
@@ -711,8 +715,10 @@ __global__ __launch_bounds__(192) void conv3d_wgrad_bf16_kernel(const bf16_t* __
 #pragma unroll
                 for (int b = 0; b < KW; ++b) {
                     bf16x8 afr[CIT];
+                    const int lin = hr * C::WRP + b + lvox;                       // SWX: 32-byte half ^= (voxel >> 2) & 1, same for voxel + 16
+                    const int sw = C::SWX ? ((lin >> 2) & 1) << 5 : 0;
 #pragma unroll
-                    for (int i = 0; i < CIT; ++i) afr[i] = tr_frag(xplane + (hr * WR + b) * PX + i * 32, 16 * PX);
+                    for (int i = 0; i < CIT; ++i) afr[i] = tr_frag(xplane + lin * PX + ((i * 32) ^ sw), 16 * PX);
 #pragma unroll
                     for (int a = 0; a < KH; ++a) {
                         const int h = hr - a;
@@ -780,15 +786,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-typedef WgCfg<16, 16, 3, 3, 8> W333_16_16;
-typedef WgCfg<16, 32, 3, 3, 4> W333_16_32;
-typedef WgCfg<32, 16, 3, 3, 4> W333_32_16;
+typedef WgCfg<16, 16, 3, 3, 8, 2> W333_16_16;
+typedef WgCfg<32, 16, 3, 3, 4, 2> W333_32_16;
 typedef WgCfg<32, 32, 3, 3, 4> W333_32_32;
 typedef WgCfg<16, 16, 7, 7, 4> W377_16_16;
 
+int g_wg_cob16 = 0;                        // tuning: 1 = 16 output channels per workgroup even where Cin, Cout % 32 == 0
+int g_wg_blocks = 0;                       // tuning: > 0 overrides the persistent grid size
+
+template <class C>
 inline int wg_blocks_x(long ncols, int nsub)
 {
-    long nb = 768 / nsub;                 // ~3 workgroups per CU over the whole chip
+    long nb = (g_wg_blocks > 0 ? g_wg_blocks : C::BLOCKS) / nsub;
     if (nb < 16) nb = 16;
     if (nb > ncols) nb = ncols;
     return (int)nb;
@@ -800,7 +809,7 @@ size_t wg_ws_bytes(int N, int T, int H, int W, int CI, int CO)
     (void)T;
     const long ncols = (long)N * ceil_div(H, C::TH) * ceil_div(W, C::TW);
     const int nsub = (CI / C::CIB) * (CO / C::COB);
-    return (size_t)wg_blocks_x(ncols, nsub) * nsub * C::SLAB_FLOATS * sizeof(float);
+    return (size_t)wg_blocks_x<C>(ncols, nsub) * nsub * C::SLAB_FLOATS * sizeof(float);
 }
 
 template <class C>
@@ -810,7 +819,7 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
     WgDims d{N, T, H, W, CI, CO, ceil_div(H, C::TH), ceil_div(W, C::TW), 0, 0};
     const long ncols = (long)N * d.tiles_h * d.tiles_w;
     const int nsub = (CI / C::CIB) * (CO / C::COB);
-    const int nbx = wg_blocks_x(ncols, nsub);
+    const int nbx = wg_blocks_x<C>(ncols, nsub);
     d.ncols = (int)ncols;
     d.cols_per_block = ceil_div(ncols, nbx);
     const int nblk = ceil_div(ncols, d.cols_per_block);        // blocks that own at least one time-column
@@ -845,10 +854,9 @@ extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, in
 {
     if (!wgrad_shape_ok(Cin, Cout, kt, kh, kw)) return 0;
     if (kh == 7) return wg_ws_bytes<W377_16_16>(N, T, H, W, Cin, Cout);
-    const bool i32 = Cin % 32 == 0, o32 = Cout % 32 == 0;
+    const bool i32 = Cin % 32 == 0, o32 = i32 && Cout % 32 == 0 && !g_wg_cob16;
     if (i32 && o32) return wg_ws_bytes<W333_32_32>(N, T, H, W, Cin, Cout);
     if (i32) return wg_ws_bytes<W333_32_16>(N, T, H, W, Cin, Cout);
-    if (o32) return wg_ws_bytes<W333_16_32>(N, T, H, W, Cin, Cout);
     return wg_ws_bytes<W333_16_16>(N, T, H, W, Cin, Cout);
 }
 
@@ -863,11 +871,17 @@ extern "C" int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, in
     const bf16_t* xp = (const bf16_t*)x;
     const bf16_t* dyp = (const bf16_t*)dy;
     if (kh == 7) return launch_wgrad_cfg<W377_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
-    const bool i32 = Cin % 32 == 0, o32 = Cout % 32 == 0;
+    const bool i32 = Cin % 32 == 0, o32 = i32 && Cout % 32 == 0 && !g_wg_cob16;
     if (i32 && o32) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     if (i32) return launch_wgrad_cfg<W333_32_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
-    if (o32) return launch_wgrad_cfg<W333_16_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     return launch_wgrad_cfg<W333_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+}
+
+// Tuning hook for the weight-gradient kernel: output channels per workgroup (16 / 32 where Cout allows) and persistent grid size.
+extern "C" int vvae_conv3d_wgrad_config(int cob16, int blocks)
+{
+    g_wg_cob16 = cob16; g_wg_blocks = blocks;
+    return 0;
 }
 
 // Test / tuning hook: on = 0 routes single-chunk layers through the per-frame kernel again; tchunk > 0 forces the frames per workgroup.
