@@ -349,13 +349,18 @@ namespace {
 // GEMM view per tap: M = ci, N = co, K = voxels (millions).  Both operands are K-major in NDHWC memory, so the MFMA
 // fragments (8 consecutive k per lane) come from LDS through ds_read_b64_tr_b16 (hardware 4x16 transpose), with the
 // k -> voxel map chosen so that each 32-lane half reads 8 consecutive voxel rows = one conflict-free 256-byte bank row.
-//   * one workgroup = KT waves; wave `dt` owns the KH*KW taps of temporal offset dt for a CIB x COB block of the weight
-//     matrix, i.e. KH*KW*(CIB/16)*(COB/16) accumulator tiles that stay in registers for the block's whole life;
+//   * one wave owns the KH*KW (or, for the 7x7 mixer, 2*KW) taps of ONE temporal offset dt for ONE 16x16 (ci, co) tile
+//     -- 9..14 accumulator tiles that stay in registers for the workgroup's whole life -- and a workgroup is the
+//     3 * (CIB/16) * (COB/16) * dy-groups * row-groups waves that share a halo: 3, 12 or 12 light waves (<= 170 VGPRs),
+//     so every SIMD of a CU carries the same load (3-wave workgroups holding 36 tiles each left one SIMD in four idle);
 //   * workgroups are PERSISTENT: each walks a contiguous run of (n, h-tile, w-tile, t) tiles, staging the X halo
 //     (KT x (TH+KH-1) x (32+KW-1) voxels) and the dY tile (TH x 32 voxels) in LDS, so the accumulators are written out
 //     once per workgroup (fp32 slab) and a second tiny kernel sums the slabs -- deterministic, no float atomics;
 //   * the X fragment read for halo row r and column shift dx serves the KH taps (dy, dx) of output rows r-dy, and the dY
-//     fragment of a row serves all KH*KW taps: ~0.5 LDS fragment reads per MFMA instead of 4.
+//     fragment of a row serves all of the wave's taps: ~0.5 LDS fragment reads per MFMA instead of 4;
+//   * 32-channel X voxels sit at their natural 64-byte pitch with the 32-byte half XORed by (voxel >> 2) & 1 (rows padded to
+//     a multiple of 8 voxels so the bit is row-independent): conflict-free transposed reads without the 96-byte pitch that
+//     cost a third of the LDS budget.
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int row16_bytes)
@@ -368,12 +373,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int row16_byte
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CIB_, int COB_, int KH_, int KW_, int TH_, int MINW_ = 1>
+template <int CIB_, int COB_, int KH_, int KW_, int TH_, int AG_, int RG_, int MINW_, int BPC_>
 struct WgCfg {
-    static constexpr int MINW = MINW_;                                       // waves per SIMD the register allocation must leave room for
-    static constexpr int BLOCKS = 256 * MINW;                                // persistent grid = what the chip holds at once (3-wave workgroups)
     static constexpr int CIB = CIB_, COB = COB_, KT = 3, KH = KH_, KW = KW_, TH = TH_, TW = 32;
     static constexpr int CIT = CIB / 16, COT = COB / 16;
+    static constexpr int AG = AG_, AGS = (KH + AG - 1) / AG;                 // kernel rows dy are split into AG groups of AGS rows
+    static constexpr int RG = RG_, THR = TH / RG;                            // output rows are split into RG groups of THR rows (own slab each)
+    static constexpr int NW = KT * CIT * COT * AG * RG, NTHREADS = 64 * NW;  // one wave per (dt, ci tile, co tile, dy group, row group)
+    static_assert(TH % RG == 0 && NW <= 16, "wave grid");
+    static constexpr int MINW = MINW_;                                       // waves per SIMD the register allocation must leave room for
+    static constexpr int BLOCKS = 256 * BPC_;                                // persistent grid = what the chip holds at once
     static constexpr int HR = TH + KH - 1, WR = TW + KW - 1;
     static constexpr int PX = 2 * CIB, PY = COB == 16 ? 32 : 96;             // 32-channel X voxels: 64-byte pitch, swizzled parts
     static constexpr bool SWX = CIB == 32;
@@ -640,38 +649,40 @@ int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias
 #undef ROLL
 
 template <class C>
-__global__ __launch_bounds__(192, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy,
-                                                                int lddy, float* __restrict__ slab, WgDims d)
+__global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                                                 const bf16_t* __restrict__ dy, int lddy,
+                                                                                 float* __restrict__ slab, WgDims d)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int CIB = C::CIB, COB = C::COB, KH = C::KH, KW = C::KW, TH = C::TH, TW = C::TW;
+    constexpr int CIB = C::CIB, COB = C::COB, KH = C::KH, KW = C::KW, TH = C::TH, TW = C::TW, AGS = C::AGS;
     constexpr int CIT = C::CIT, COT = C::COT, HR = C::HR, WR = C::WR, PX = C::PX, PY = C::PY;
     unsigned char* ring = smem;                                   // 4 X halo planes: plane t lives in slot t & 3
     unsigned char* ybuf = smem + 4 * C::PLANE;                    // dY tile of step t in buffer t & 1
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // wave = dt
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave -> (dt, ci tile wi, co tile wj, dy group): every SIMD gets the same number of equally heavy waves
+    const int rgp = wave % C::RG, wv = wave / C::RG;
+    const int dt = wv / (CIT * COT * C::AG);
+    const int wr = wv % (CIT * COT * C::AG);
+    const int wi = wr / (COT * C::AG), wj = (wr / C::AG) % COT, a0 = (wr % C::AG) * AGS;
+    const int r0 = rgp * C::THR;                                             // first output row of this wave
+    const bool bias_wave = dt == 0 && wi == 0 && a0 == 0;
     const int co_subs = d.CO / COB;
     const int ci0 = (blockIdx.y / co_subs) * CIB, co0 = (blockIdx.y % co_subs) * COB;
     // transposed-read lane offsets: lane (g = l>>4, q = (l>>2)&3, p = l&3) addresses voxel row 4g+q, channels 4p..4p+3
     const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-    const int lvox = 4 * g + qq, loffy = (4 * g + qq) * PY + 8 * pp;
+    const int lvox = 4 * g + qq, loffy = (4 * g + qq) * PY + 8 * pp + wj * 32;
 
-    f32x4 acc[KH][KW][CIT][COT];
+    f32x4 acc[AGS][KW];
 #pragma unroll
-    for (int a = 0; a < KH; ++a)
+    for (int a = 0; a < AGS; ++a)
 #pragma unroll
-        for (int b = 0; b < KW; ++b)
-#pragma unroll
-            for (int i = 0; i < CIT; ++i)
-#pragma unroll
-                for (int j = 0; j < COT; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accb[COT];
-#pragma unroll
-    for (int j = 0; j < COT; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < KW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
     const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
-    PlaneStager<192, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx;
-    PlaneStager<192, TH, TW, COB / 8, PY> sy;
+    PlaneStager<C::NTHREADS, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx;
+    PlaneStager<C::NTHREADS, TH, TW, COB / 8, PY> sy;
     const bf16_t* xsrc = x + ci0;
     const bf16_t* ysrc = dy + co0;
 
@@ -700,60 +711,47 @@ __global__ __launch_bounds__(192, C::MINW) void conv3d_wgrad_bf16_kernel(const b
                 sx.fetch(xsrc, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
                 sy.fetch(ysrc, lddy, n, tt + 1, h0, w0, d.T, d.H, d.W, tid);
             }
-            const unsigned char* ys = ybuf + (tt & 1) * C::YBYTES;
-            bf16x8 bfr[KH][COT];                                  // rolling window of dY fragments: row h lives in slot h % KH
-            const unsigned char* xplane = ring + ((tt + wave - 1) & 3) * C::PLANE + 8 * pp;
+            const unsigned char* ys = ybuf + (tt & 1) * C::YBYTES + loffy + r0 * (TW * PY);
+            // halo rows r0 + a0 + rr, rr = 0 .. THR+AGS-2, meet kernel rows a0 + aa at output rows r0 + h, h = rr - aa
+            const unsigned char* xplane = ring + ((tt + dt - 1) & 3) * C::PLANE + (r0 + a0) * (C::WRP * PX) + 8 * pp;
+            bf16x8 bfr[AGS];                                      // rolling window of dY fragments: row h lives in slot h % AGS
 #pragma unroll
-            for (int hr = 0; hr < HR; ++hr) {
-                if (hr < TH) {
-#pragma unroll
-                    for (int j = 0; j < COT; ++j) {
-                        bfr[hr % KH][j] = tr_frag(ys + hr * TW * PY + j * 32 + loffy, 16 * PY);
-                        if (wave == 0) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[hr % KH][j], accb[j], 0, 0, 0);
-                    }
+            for (int rr = 0; rr < C::THR + AGS - 1; ++rr) {
+                if (rr < C::THR) {
+                    bfr[rr % AGS] = tr_frag(ys + rr * TW * PY, 16 * PY);
+                    if (bias_wave) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[rr % AGS], accb, 0, 0, 0);
                 }
+                if (KH % AGS != 0 && a0 + rr >= C::THR + KH - 1) continue;   // last dy group is short: its tail rows are not needed
 #pragma unroll
                 for (int b = 0; b < KW; ++b) {
-                    bf16x8 afr[CIT];
-                    const int lin = hr * C::WRP + b + lvox;                       // SWX: 32-byte half ^= (voxel >> 2) & 1, same for voxel + 16
+                    const int lin = rr * C::WRP + b + lvox;       // SWX: 32-byte half ^= (voxel >> 2) & 1, same for voxel + 16
                     const int sw = C::SWX ? ((lin >> 2) & 1) << 5 : 0;
+                    const bf16x8 afr = tr_frag(xplane + lin * PX + ((wi * 32) ^ sw), 16 * PX);
 #pragma unroll
-                    for (int i = 0; i < CIT; ++i) afr[i] = tr_frag(xplane + lin * PX + ((i * 32) ^ sw), 16 * PX);
-#pragma unroll
-                    for (int a = 0; a < KH; ++a) {
-                        const int h = hr - a;
-                        if (h >= 0 && h < TH) {
-#pragma unroll
-                            for (int i = 0; i < CIT; ++i)
-#pragma unroll
-                                for (int j = 0; j < COT; ++j)
-                                    acc[a][b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[h % KH][j], acc[a][b][i][j], 0, 0, 0);
-                        }
+                    for (int aa = 0; aa < AGS; ++aa) {
+                        const int h = rr - aa;
+                        if (h >= 0 && h < C::THR && (KH % AGS == 0 || a0 + aa < KH))
+                            acc[aa][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[h % AGS], acc[aa][b], 0, 0, 0);
                     }
                 }
             }
         }
     }
     // ---- write this workgroup's partial sums: slab[block][dt][dy][dx][ci_local][co_local] (+ COB dbias partials) ----
-    float* out = slab + ((long)blockIdx.x * gridDim.y + blockIdx.y) * C::SLAB_FLOATS;
+    float* out = slab + (((long)blockIdx.x * C::RG + rgp) * gridDim.y + blockIdx.y) * C::SLAB_FLOATS;
     const int col = lane & 15, rg = lane >> 4;
 #pragma unroll
-    for (int a = 0; a < KH; ++a)
+    for (int aa = 0; aa < AGS; ++aa) {
+        if (KH % AGS != 0 && a0 + aa >= KH) continue;
 #pragma unroll
         for (int b = 0; b < KW; ++b)
 #pragma unroll
-            for (int i = 0; i < CIT; ++i)
-#pragma unroll
-                for (int j = 0; j < COT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ci = i * 16 + rg * 4 + e, co = j * 16 + col;
-                        out[(((wave * KH + a) * KW + b) * CIB + ci) * COB + co] = acc[a][b][i][j][e];
-                    }
-    if (wave == 0 && rg == 0) {
-#pragma unroll
-        for (int j = 0; j < COT; ++j) out[C::KT * KH * KW * CIB * COB + j * 16 + col] = accb[j][0];
+            for (int e = 0; e < 4; ++e) {
+                const int ci = wi * 16 + rg * 4 + e, co = wj * 16 + col;
+                out[(((dt * KH + a0 + aa) * KW + b) * CIB + ci) * COB + co] = acc[aa][b][e];
+            }
     }
+    if (bias_wave && rg == 0) out[C::KT * KH * KW * CIB * COB + wj * 16 + col] = accb[0];
 }
 
 // dw[tap][ci][co] = sum_b slab[b][sub(ci,co)][tap][ci%CIB][co%COB];  dbias[co] = sum_b (ci-sub 0) slab dbias part
@@ -786,10 +784,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-typedef WgCfg<16, 16, 3, 3, 8, 2> W333_16_16;
-typedef WgCfg<32, 16, 3, 3, 4, 2> W333_32_16;
-typedef WgCfg<32, 32, 3, 3, 4> W333_32_32;
-typedef WgCfg<16, 16, 7, 7, 4> W377_16_16;
+//            CIB COB KH KW TH AG RG MINW workgroups/CU
+typedef WgCfg<16, 16, 3, 3, 8, 1, 1, 2, 2> W333_16_16;       //  3 waves
+typedef WgCfg<32, 16, 3, 3, 8, 1, 2, 3, 1> W333_32_16;       // 12 waves: two row groups of an 8-row tile
+typedef WgCfg<32, 32, 3, 3, 4, 1, 1, 3, 1> W333_32_32;       // 12 waves
+typedef WgCfg<16, 16, 7, 7, 4, 4, 1, 3, 1> W377_16_16;       // 12 waves: 3 temporal taps x 4 groups of kernel rows
 
 int g_wg_cob16 = 0;                        // tuning: 1 = 16 output channels per workgroup even where Cin, Cout % 32 == 0
 int g_wg_blocks = 0;                       // tuning: > 0 overrides the persistent grid size
@@ -809,7 +808,7 @@ size_t wg_ws_bytes(int N, int T, int H, int W, int CI, int CO)
     (void)T;
     const long ncols = (long)N * ceil_div(H, C::TH) * ceil_div(W, C::TW);
     const int nsub = (CI / C::CIB) * (CO / C::COB);
-    return (size_t)wg_blocks_x<C>(ncols, nsub) * nsub * C::SLAB_FLOATS * sizeof(float);
+    return (size_t)wg_blocks_x<C>(ncols, nsub) * C::RG * nsub * C::SLAB_FLOATS * sizeof(float);
 }
 
 template <class C>
@@ -823,7 +822,7 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
     d.ncols = (int)ncols;
     d.cols_per_block = ceil_div(ncols, nbx);
     const int nblk = ceil_div(ncols, d.cols_per_block);        // blocks that own at least one time-column
-    if (!ws || ws_bytes < (size_t)nblk * nsub * C::SLAB_FLOATS * sizeof(float)) return VVAE_ERR_WORKSPACE;
+    if (!ws || ws_bytes < (size_t)nblk * C::RG * nsub * C::SLAB_FLOATS * sizeof(float)) return VVAE_ERR_WORKSPACE;
     auto k = conv3d_wgrad_bf16_kernel<C>;
     static bool attr_done = false;                 // once per instantiation: keeps the launch path free of non-stream calls
     if (C::LDS_BYTES > 65536 && !attr_done) {      // (hipGraph capture of the training step replays only stream work)
@@ -831,11 +830,11 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(192), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d);
+    hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d);
     VVAE_LAUNCH_CHECK();
     const int taps = C::KT * C::KH * C::KW;
     const long total = (long)taps * CI * CO + CO;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 32)), dim3(256), 0, s, (const float*)ws, dw, dbias, nblk, taps, CI,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 32)), dim3(256), 0, s, (const float*)ws, dw, dbias, nblk * C::RG, taps, CI,
                        CO, C::CIB, C::COB);
     VVAE_LAUNCH_CHECK();
     return 0;
