@@ -183,9 +183,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
-    if graphed and rank == 0:
+    if graphed:
         # a replayed graph cannot host event records: time the same kernels (same shapes, same data) in eager steps
-        # run right after the timed region, on the same stream
+        # run right after the timed region, on the same stream.  Every rank runs them (their gradient all-reduces must
+        # pair up across ranks); only rank 0 records events.
         ops.TIMER = timer
         for _ in range(3):
             eager_step()

@@ -27,10 +27,15 @@ class GradReducer:
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.handles = []
+        # RCCL orders a collective after the work already queued on the current stream and its result before what is queued
+        # next; gloo's device path (CPU-side tests of this class with GPU tensors) is fenced by hand instead
+        self.fence = optimizer.p.is_cuda and dist.get_backend(process_group) != "nccl"
         optimizer.reducer = self
 
     def launch(self, b):
         s, e = self.opt.buckets[b]
+        if self.fence:
+            torch.cuda.synchronize()
         self.handles.append(dist.all_reduce(self.opt.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reset(self):
@@ -39,12 +44,18 @@ class GradReducer:
     def finish(self):
         for h in self.handles:
             h.wait()
+        if self.fence and self.handles:
+            torch.cuda.synchronize()
         self.handles = []
 
     def broadcast_parameters(self, src=0):
         """Replicate rank ``src``'s parameters (the reference's device_put(state, P()) / resume broadcast,
         distributed_train.py:339,378-380)."""
+        if self.opt.p.is_cuda:
+            torch.cuda.synchronize()          # one-time setup: no reliance on the transport's ordering against in-flight work
         dist.broadcast(self.opt.p, src=src, group=self.group)
+        if self.opt.p.is_cuda:
+            torch.cuda.synchronize()
         self.opt.refresh_shadow()
 
 

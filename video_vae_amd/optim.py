@@ -105,6 +105,8 @@ class Optimizer:
     # ---- gradient landing -------------------------------------------------------------------------------
     def _make_hook(self, i):
         def hook(param):
+            if param.grad is None:               # the engine also runs the hook for an undefined gradient (a backward that returned
+                return                           # None: parked weight gradients) -- those arrive through mark_external instead
             b = self.param_bucket[i]
             self.arrived[b] += 1
             if self.arrived[b] == len(self.bucket_params[b]) and not self.landed[b]:
@@ -155,6 +157,9 @@ class Optimizer:
         if dsts:
             torch._foreach_copy_(dsts, srcs)
         self.landed = [True] * len(self.buckets)
+        if self.reducer is not None and not self.defer_reduce:      # same contract as _land: a landed bucket goes to the reducer
+            for b in range(len(self.buckets)):
+                self.reducer.launch(b)
 
     def mark_external(self, param):
         """The gradient of ``param`` has been written straight into its flat-buffer slot for this step (ops.deferred_wgrad):
