@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--flavour", default="model", choices=["model", "rl"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured configuration); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-graph", action="store_true",
                     help="run the timed steps eagerly (default: forward+backward replayed from a captured hipGraph)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per clip of the bounded CPU sample")
@@ -109,10 +111,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    if args.backend != "nccl":               # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (gloo transport)
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     import video_vae_amd as V
