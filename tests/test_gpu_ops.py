@@ -788,3 +788,43 @@ def test_conv_transpose_bf16_fast_path(dev, ci, co, shape):
     buf = torch.zeros((n, t, 2 * h, 2 * w, 2 * co), dtype=torch.bfloat16, device=dev)
     ops.convt_fwd_raw(xg, kg, bg, out=buf[..., :co])
     assert torch.equal(buf[..., :co], y_fast) and float(buf[..., co:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("rows,mlp,out", [(1024, 1536, 768), (512, 1536, 768), (96, 64, 32)])
+def test_silu_linear_fused_backward(dev, rows, mlp, out):
+    """linear2(silu(h)) as one node (dh = (dy @ W2^T) * silu'(h) in a GEMM epilogue) vs the three-node chain; reference
+    train/layers.py:186-189."""
+    import video_vae_amd as V
+    from video_vae_amd import layers as LY, optim
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linear2 = LY.Linear(mlp, out, V.Rngs(1))
+    m = Two().to(dev)
+    opt = optim.Optimizer(m, 1e-3)                                 # gives the parameters their bf16 shadows
+    with torch.no_grad():
+        m.linear2.bias.copy_(rnd((out,), 3, 0.1).to(dev))
+    opt.refresh_shadow()
+    h = rnd((rows, mlp), 70, 1.5).to(dev, torch.bfloat16)
+    gy = rnd((rows, out), 71, 1.0).to(dev, torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        hh = h.clone().requires_grad_(True)
+        opt.zero_grad()
+        y = LY.silu_linear(hh, m.linear2) if fused else m.linear2(torch.nn.functional.silu(hh))
+        y.backward(gy)
+        for b in range(len(opt.buckets)):                          # gradients live in the optimizer's flat buffer
+            if not opt.landed[b]:
+                opt._land(b)
+        res.append((y.detach(), hh.grad, m.linear2.kernel.gview.clone(), m.linear2.bias.gview.clone()))
+    (y1, dh1, dw1, db1), (y0, dh0, dw0, db0) = res
+    assert torch.equal(y1, y0)
+    assert_close_scaled(dh1, dh0, rel=1e-2, what="dh fused vs chain")        # chain rounds dy @ W2^T to bf16 before the multiply
+    assert_close_scaled(dw1, dw0, rel=2e-5, what="dW2")
+    assert_close_scaled(db1, db0, rel=2e-5, what="db2")
+    # against fp32 math on the same bf16 operands
+    hf = h.float().requires_grad_(True)
+    yf = torch.nn.functional.silu(hf).to(torch.bfloat16).float() @ m.linear2.kernel.bf16.float() + m.linear2.bias.bf16.float()
+    yf.backward(gy.float())
+    assert_close_scaled(dh1, hf.grad, rel=1e-2, what="dh fused vs fp32")

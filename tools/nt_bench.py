@@ -52,4 +52,11 @@ for N, K in [(1536, 768), (768, 512), (768, 1536), (512, 768), (768, 768)]:
     t_res = tmg(lambda: ops.gemm_nt(a, b, bias, res, ops.EPI_RES))
     bb = bias.to(torch.bfloat16); bt = b.t()
     t_blas = tmg(lambda: torch.addmm(bb, a, bt))
+    t_silu = tmg(lambda: ops.gemm_nt(a, b, bias, None, ops.EPI_SILU))
+    t_dsilu = tmg(lambda: ops.gemm_nt(a, b, None, res, ops.EPI_MUL_DSILU))
+    hb = torch.addmm(bb, a, bt)
+    t_blas_silu = tmg(lambda: F.silu(torch.addmm(bb, a, bt)))
+    go = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+    t_blas_dsilu = tmg(lambda: torch.ops.aten.silu_backward(torch.mm(a, bt), res))
+    print(f"   fused silu {t_silu:.1f}us vs blas+silu {t_blas_silu:.1f}us | fused mul_dsilu {t_dsilu:.1f}us vs blas mm + silu_backward {t_blas_dsilu:.1f}us", flush=True)
     print(f"N{N} K{K}: maxerr {err:.3e} mismatch-vs-rounded-fp32 {mism:.4f} res {e1:.2e} silu {e2:.2e}/{e2h:.4f} dsilu {e3:.2e} | own {t_own:.1f}us {fl/t_own/1e6:.0f}TF  own+res {t_res:.1f}us | blas addmm {t_blas:.1f}us {fl/t_blas/1e6:.0f}TF", flush=True)

@@ -71,6 +71,55 @@ class _LinearBf16(torch.autograd.Function):
         return dx, dw, db
 
 
+class _SiluLinearBf16(torch.autograd.Function):
+    """linear2(silu(h)) of the MLP (reference train/layers.py:186-189) as one autograd node, so that its backward can form
+    dh = (dy @ W2^T) * silu'(h) in the epilogue of ONE product (ops.gemm_nt, EPI_MUL_DSILU: the input gradient never makes the
+    round trip through HBM that a separate silu_backward launch costs).  Forward = the library GEMM + the framework's SiLU."""
+
+    @staticmethod
+    def forward(ctx, h, kernel, bias):
+        wb, bb = kernel.bf16, bias.bf16
+        h2 = h.reshape(-1, h.shape[-1])
+        a = F.silu(h2)
+        ctx.save_for_backward(h2, a, wb)
+        ctx.hshape = h.shape
+        ctx.kparam, ctx.bparam = kernel, bias
+        return torch.addmm(bb, a, wb).view(*h.shape[:-1], wb.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        h2, a, wb = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != torch.bfloat16:
+            dy2 = dy2.to(torch.bfloat16)
+        dy2 = dy2.contiguous()
+        dh = None
+        if ctx.needs_input_grad[0]:
+            if ops.gemm_nt_supported(dy2, wb):                      # wb (mlp, out) is the (N, K) operand as stored
+                dh = ops.gemm_nt(dy2, wb, None, h2, ops.EPI_MUL_DSILU)
+            else:
+                dh = torch.ops.aten.silu_backward(torch.mm(dy2, wb.t()), h2)
+            dh = dh.view(ctx.hshape)
+        dw = db = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ops.wgrad_deferrable(a, dy2, ctx.kparam, ctx.bparam):
+            ops.WGRAD_QUEUE[0].append((a, dy2, ctx.kparam, ctx.bparam))
+            return dh, None, None
+        if ctx.needs_input_grad[1] and ops.gemm_tn_supported(a, dy2):
+            dw, db = ops.gemm_tn(a, dy2, ctx.needs_input_grad[2])
+        else:
+            dw = _mm_f32(a.t(), dy2) if ctx.needs_input_grad[1] else None
+            db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        return dh, dw, db
+
+
+def silu_linear(h, linear):
+    """linear(silu(h)); fused-backward form when the layer runs the bf16 GPU path with shadowed fp32 parameters."""
+    if (linear.dtype == torch.bfloat16 and h.is_cuda and h.dtype == torch.bfloat16 and linear.kernel.dtype == torch.float32
+            and getattr(linear.kernel, "bf16", None) is not None and getattr(linear.bias, "bf16", None) is not None):
+        return _SiluLinearBf16.apply(h, linear.kernel, linear.bias)
+    return linear(F.silu(h))
+
+
 class Linear(nn.Module):
     """nnx.Linear: y = x @ kernel + bias, kernel (in, out), lecun_normal init (variance_scaling(scale))."""
 
@@ -276,12 +325,12 @@ class MLP(nn.Module):
         self.linear2 = Linear(mlp_dim, in_features, rngs, dtype, param_dtype, kernel_scale=1e-2)
 
     def forward(self, x):
-        return self.linear2(F.silu(self.linear1(self.norm(x))))
+        return silu_linear(self.linear1(self.norm(x)), self.linear2)
 
     def residual(self, x, pending=None, defer=False):
         """x + self(x) with the skip gradient folded into the LayerNorm's backward (pending / defer: LayerNorm.fork)."""
         y, skip = self.norm.fork(x, pending)
-        o = self.linear2(F.silu(self.linear1(y)))
+        o = silu_linear(self.linear1(y), self.linear2)
         return (skip, o) if defer else skip + o
 
 
