@@ -21,20 +21,23 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 ka = prof.key_averages()
 rows = sorted(ka, key=lambda e: -e.count)
 print("%-60s %6s %10s %10s" % ("name", "count", "cpu_us", "cuda_us"))
-for e in rows[:70]:
+for e in rows[:0]:
     print("%-60s %6d %10.0f %10.0f" % (e.key[:60], e.count, e.cpu_time_total, e.device_time_total))
 # which ops launch memsets: walk events, find memset device events and their parent cpu op
 evs = prof.events()
 from collections import Counter
 cnt = Counter()
+dur = {}
 for ev in evs:
     if ev.device_type.name == "CPU" and ev.kernels:
         for k in ev.kernels:
-            if "fillBuffer" in k.name or "Memset" in k.name or "memset" in k.name or "copyBuffer" in k.name or "Memcpy" in k.name:
+            if any(t in k.name for t in ("fillBuffer", "Memset", "memset", "copyBuffer", "Memcpy", "elementwise_kernel", "vectorized_elementwise", "CatArray", "reduce_kernel")):
                 p = ev
                 names = []
                 while p is not None and len(names) < 4:
                     names.append(p.name); p = p.cpu_parent
-                cnt[(k.name[:30], " <- ".join(names))] += 1
-for k, v in cnt.most_common(40):
-    print(v, k)
+                key = (k.name[:70], " <- ".join(names))
+                cnt[key] += 1
+                dur[key] = dur.get(key, 0.0) + k.duration
+for k, v in sorted(cnt.items(), key=lambda kv: -dur[kv[0]])[:45]:
+    print(f"{v:4d} x {dur[k] / v:7.1f} us = {dur[k] / 1e3:6.3f} ms  {k[0]}  <-  {k[1]}")
