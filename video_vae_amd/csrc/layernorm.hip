@@ -49,11 +49,27 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
     // gamma / beta reach the lanes through LDS (one coalesced pass per workgroup): per-lane strided dword loads of the affine
     // cost ~30x the L1 line accesses of the row itself and were what bounded the first version of this kernel.
     __shared__ __attribute__((aligned(16))) float sg[LPR * VPL * V], sb[LPR * VPL * V];
-    for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) {
-        sg[i] = i < d.C ? gamma[i] : 0.f;
-        sb[i] = (beta && i < d.C) ? beta[i] : 0.f;
+    // The affine is requested first, the first rows right behind it, and only then is it parked in LDS and the workgroup
+    // synchronised (LDS-only wait + raw barrier): the row loads are already in flight while the staging completes.
+    constexpr int NG = (LPR * VPL * V + 255) / 256;
+    float gpre[NG], bpre[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int i = threadIdx.x + j * 256;
+        gpre[j] = (i < LPR * VPL * V && i < d.C) ? gamma[i] : 0.f;
+        bpre[j] = (beta && i < LPR * VPL * V && i < d.C) ? beta[i] : 0.f;
     }
-    __syncthreads();
+    bool staged = false;
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < LPR * VPL * V) { sg[i] = gpre[j]; sb[i] = bpre[j]; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0) only: the row loads stay in flight across the barrier
+        __builtin_amdgcn_s_barrier();
+        staged = true;
+    };
     // gamma / beta are re-read from LDS at the point of use: ~50 VGPRs instead of ~118, i.e. 8 waves per SIMD, twice the bytes
     // in flight per CU
     const long rstride = (long)gridDim.x * 4 * RPW;
@@ -79,6 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
                 for (int e = 0; e < V; ++e) { s += v[k][e]; ss += v[k][e] * v[k][e]; }
             }
         }
+        if (!staged) stage();
         s = group_sum<LPR>(s); ss = group_sum<LPR>(ss);
         const float mean = s / d.C;
         float var = ss / d.C - mean * mean;
@@ -97,6 +114,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
             }
         }
     }
+    if (!staged) stage();                                // a wave without rows still owes the workgroup its barrier
 }
 
 // dy rows contiguous (pitch C); dx rows contiguous.  part: fp32 [gridDim.x][2][C] = per-workgroup (sum dy*xhat | sum dy).
