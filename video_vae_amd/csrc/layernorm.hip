@@ -216,8 +216,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
     }
 }
 
-inline int ln_blocks(long rows, int lpr, int cap = 1024)
+int g_ln_bwd_cap = 1024;
+
+inline int ln_blocks(long rows, int lpr, int cap = 0)
 {
+    if (cap == 0) cap = g_ln_bwd_cap;
     // backward: <= 1024 workgroups (each emits one partial row of dgamma/dbeta).  forward has no epilogue, so it takes one
     // row-slot per wave (cap 16384): every row's loads are in flight at once instead of 4 rows queued behind each other.
     const long per = 4L * (64 / lpr);
@@ -321,5 +324,12 @@ extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* ga
         LN_SWITCH(layernorm_bwd_kernel, bf16_t, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, part, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tuning hook: workgroups (= partial rows) of the backward kernel.
+extern "C" int vvae_layernorm_config(int bwd_cap)
+{
+    g_ln_bwd_cap = bwd_cap > 0 ? bwd_cap : 1024;
     return 0;
 }
