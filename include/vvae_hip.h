@@ -221,6 +221,9 @@ int vvae_sum_rows(const float* part, int rows, int cols, float* out, void* strea
 /* n <= 64 partial buffers folded in one launch: part[i] fp32 (rows[i], cols[i]); columns [0, n0[i]) -> d0[i], the rest -> d1[i] (or NULL). */
 int vvae_fold_rows_grouped(const void* const* part, float* const* d0, float* const* d1, const int* rows, const int* cols,
                            const int* n0, int n, void* stream);
+/* n <= 64 contiguous fp32 ranges copied in one launch (gradients landing in the optimizer's flat buffer; replaces the
+   per-parameter copies of optax's tree_map update path, reference train/rl_nonadversarial.py:233-236) */
+int vvae_copy_grouped(const float* const* src, float* const* dst, const long* count, int n, void* stream);
 
 #ifdef __cplusplus
 }

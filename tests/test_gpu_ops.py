@@ -828,3 +828,18 @@ def test_silu_linear_fused_backward(dev, rows, mlp, out):
     yf = torch.nn.functional.silu(hf).to(torch.bfloat16).float() @ m.linear2.kernel.bf16.float() + m.linear2.bias.bf16.float()
     yf.backward(gy.float())
     assert_close_scaled(dh1, hf.grad, rel=1e-2, what="dh fused vs fp32")
+
+
+def test_copy_grouped(dev):
+    """Grouped landing copy: ragged sizes, unaligned ranges, more than one launch."""
+    from video_vae_amd import ops
+    sizes = [1, 3, 4, 1023, 1024, 1025, 4099, 70001] + [17 + 5 * i for i in range(70)]
+    flat_s = rnd((sum(sizes) + 8,), 90).to(dev)
+    flat_d = torch.zeros(sum(sizes) + 8, device=dev)
+    srcs, dsts, o = [], [], 3                                     # offset 3: ranges that are not 16-byte aligned
+    for n in sizes:
+        srcs.append(flat_s[o:o + n]); dsts.append(flat_d[o:o + n]); o += n
+    assert all(ops.copy_grouped_ok(d, s) for d, s in zip(dsts, srcs))
+    ops.copy_grouped(dsts, srcs)
+    assert torch.equal(flat_d[3:o], flat_s[3:o])
+    assert float(flat_d[:3].abs().max()) == 0 and float(flat_d[o:].abs().max()) == 0

@@ -427,3 +427,41 @@ extern "C" int vvae_fold_rows_grouped(const void* const* part, float* const* d0,
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
+// Grouped copy: up to 64 contiguous fp32 ranges in one launch (gradients landing in the optimizer's flat buffer).
+// Blocks [block_start_e, block_start_{e+1}) belong to entry e, 1024 floats each.
+struct CopyEntry { const float* src; float* dst; long n; int block_start; };
+struct CopyArgs { CopyEntry e[FOLD_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void copy_grouped_kernel(CopyArgs g)
+{
+    int ei = 0;
+    for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].block_start ? i : ei;
+    const CopyEntry& E = g.e[ei];
+    const long i0 = ((long)((int)blockIdx.x - E.block_start) * 256 + threadIdx.x) * 4;
+    if (i0 + 4 <= E.n && (((uintptr_t)E.src | (uintptr_t)E.dst) & 15) == 0) {
+        *reinterpret_cast<float4*>(E.dst + i0) = *reinterpret_cast<const float4*>(E.src + i0);
+    } else {
+        for (long i = i0; i < i0 + 4 && i < E.n; ++i) E.dst[i] = E.src[i];
+    }
+}
+}  // namespace
+
+// n <= 64 contiguous fp32 ranges copied in one launch: dst[i][0..count[i]) = src[i][0..count[i]).  Host arrays.
+extern "C" int vvae_copy_grouped(const float* const* src, float* const* dst, const long* count, int n, void* stream)
+{
+    if (!src || !dst || !count || n <= 0 || n > FOLD_MAX) return VVAE_ERR_BAD_ARG;
+    CopyArgs g;
+    g.n = n;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i] || count[i] <= 0) return VVAE_ERR_BAD_ARG;
+        g.e[i] = CopyEntry{src[i], dst[i], count[i], (int)blocks};
+        blocks += ceil_div(count[i], 1024L);
+        if (blocks > 0x7fffffffL) return VVAE_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(copy_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

@@ -69,6 +69,21 @@ def fold_partials(part, p0, p1, n0):
     return tot[:n0], tot[n0:]
 
 
+def copy_grouped(dsts, srcs):
+    """dst[i].copy_(src[i]) for lists of contiguous fp32 GPU tensors of equal sizes, 64 pairs per launch (gradient landing)."""
+    for i0 in range(0, len(dsts), FOLD_MAX):
+        d, s_ = dsts[i0:i0 + FOLD_MAX], srcs[i0:i0 + FOLD_MAX]
+        n = len(d)
+        VP, LA = ctypes.c_void_p * n, ctypes.c_long * n
+        check(lib().vvae_copy_grouped(VP(*[t.data_ptr() for t in s_]), VP(*[t.data_ptr() for t in d]), LA(*[t.numel() for t in d]), n,
+                                      _stream()), "vvae_copy_grouped")
+
+
+def copy_grouped_ok(dst, src):
+    return (dst.is_cuda and src.is_cuda and dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.is_contiguous()
+            and src.is_contiguous() and dst.numel() == src.numel() and dst.numel() > 0)
+
+
 def sum_rows(part):
     """Column sums of a (rows, ...) fp32 partial buffer in fixed order -> shape part.shape[1:] (no memset, no atomics).
 
@@ -189,13 +204,14 @@ def conv3d_dgrad_raw(dy, kernel, out=None):
     return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1)
 
 
-def conv3d_wgrad_raw(x, dy, kshape, want_bias=True):
+def conv3d_wgrad_raw(x, dy, kshape, want_bias=True, dw_out=None, db_out=None):
+    """-> (dw, db) fp32; dw_out / db_out: contiguous fp32 buffers to overwrite instead of fresh ones (flat-buffer slots)."""
     x, ldx = rows(x)
     dy, lddy = rows(dy)
     n, t, h, w, cin = x.shape
     kt, kh, kw, _, cout = kshape
-    dw = torch.empty(kshape, dtype=torch.float32, device=x.device)
-    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dw = dw_out if dw_out is not None else torch.empty(kshape, dtype=torch.float32, device=x.device)
+    db = (db_out if db_out is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)) if want_bias else None
     dt = _dt(x)
     wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 2)
     ws, wsb = _ws(wsb, x.device)
@@ -215,6 +231,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.save_for_backward(x, k32)
         ctx.has_bias = bias is not None
         ctx.kdtype = kernel.dtype
+        ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the gradient may be written directly
         return conv3d_fwd_raw(x, k32, b32)
 
     @staticmethod
@@ -224,6 +241,20 @@ class _Conv3d(torch.autograd.Function):
         dx = conv3d_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            q = WGRAD_QUEUE[0]
+            kp, bp = ctx.kparam, ctx.bparam
+            kt, kh, kw, cin, cout = k32.shape
+            if (q is not None and ctx.needs_input_grad[1] and getattr(kp, "gview", None) is not None and kp.dtype == torch.float32
+                    and (bp is None or (ctx.needs_input_grad[2] and getattr(bp, "gview", None) is not None and bp.dtype == torch.float32))
+                    and _bf16_fast(cin, cout, kt, kh, kw, x.stride(-2), dy.stride(-2), 2, _dt(x))):
+                # inside ops.deferred_wgrad the slab-reduce kernel overwrites the parameters' slots of the flat gradient buffer
+                # directly: no gradient tensor, no landing copy (and no clone by autograd.grad inside a captured graph)
+                q.claim(kp)
+                conv3d_wgrad_raw(x, dy, tuple(k32.shape), bp is not None, kp.gview, bp.gview if bp is not None else None)
+                q.opt.mark_external(kp)
+                if bp is not None:
+                    q.opt.mark_external(bp)
+                return dx, None, None
             dw, db = conv3d_wgrad_raw(x, dy, tuple(k32.shape), ctx.has_bias)
             dw = dw.to(ctx.kdtype)
         return dx, dw, db
@@ -1019,11 +1050,14 @@ class _WgradQueue:
             if p1 is not None:
                 self.opt.mark_external(p1)
 
+    def claim(self, kernel):
+        if id(kernel) in self.seen:                          # a weight used twice in one step would need accumulation
+            raise VvaeError("deferred_wgrad: a kernel was used twice in one backward pass")
+        self.seen.add(id(kernel))
+
     def append(self, item):
         x2, dy2, kernel, bias = item
-        if id(kernel) in self.seen:                          # a weight used twice in one step would need accumulation
-            raise VvaeError("deferred_wgrad: a Linear kernel was used twice in one backward pass")
-        self.seen.add(id(kernel))
+        self.claim(kernel)
         t = (x2.shape[1] // 256) * (dy2.shape[1] // 256)
         if self.items and (x2.shape[0] != self.k or len(self.items) == GROUP_MAX or self.tiles + t > GROUP_TILES):
             self.flush()
