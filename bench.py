@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--flavour", default="model", choices=["model", "rl"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="capture the step as two graphs cut at the encoder's last block even at N = 1 (the N > 1 default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-graph", action="store_true",
@@ -162,12 +164,13 @@ def main():
         if not args.no_graph:
             try:
                 from video_vae_amd.graph import GraphedTrainStep
-                gstep = GraphedTrainStep(model, opt, video, mask, L.HPARAMS, hw, rngs)
+                gstep = GraphedTrainStep(model, opt, video, mask, L.HPARAMS, hw, rngs, split=True if args.split_graph else None)
 
                 def step():
                     loss, _aux = gstep()
                     return loss
-                mode = "hipgraph(fwd+bwd) + eager all-reduce/clip/Adam"
+                mode = ("2 hipgraphs (fwd + decoder bwd | encoder bwd), decoder all-reduce under the second" if gstep.graph2 is not None
+                        else "hipgraph(fwd+bwd)") + " + eager all-reduce/clip/Adam"
             except Exception as e:                       # capture is an optimisation, never a requirement
                 print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 step, mode = eager_step, "eager"
@@ -180,7 +183,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    graphed = mode.startswith("hipgraph")
+    graphed = "hipgraph" in mode
     timer = ops.KernelTimer() if rank == 0 else None
     if not graphed:
         ops.TIMER = timer                      # eager: per-launch HIP events inside the timed region

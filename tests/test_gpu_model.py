@@ -201,8 +201,10 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert torch.allclose(opt.p, opt2.p, rtol=1e-4, atol=1e-6)
 
 
-def test_graphed_train_step_matches_eager(dev):
-    """hipGraph replay of forward+backward must produce the eager step's loss and gradients (same weights, same noise)."""
+@pytest.mark.parametrize("split", [False, True])
+def test_graphed_train_step_matches_eager(dev, split):
+    """hipGraph replay of forward+backward must produce the eager step's loss and gradients (same weights, same noise);
+    split = the two-graph form used under data parallelism (cut at the encoder's outputs)."""
     import video_vae_amd as V
     from video_vae_amd import optim, loss as L
     from video_vae_amd.graph import GraphedTrainStep
@@ -217,7 +219,8 @@ def test_graphed_train_step_matches_eager(dev):
     video = torch.rand((2, 8, 32, 32, 3), device=dev).to(torch.bfloat16)
     mask = torch.ones(2, 8, device=dev); mask[1, 5:] = 0
     ra, rb = V.Rngs(3), V.Rngs(3)
-    gstep = GraphedTrainStep(ma, oa, video, mask, L.HPARAMS, 16, ra, warmup=1)     # runs 1 + 1 + 1 updates on model a
+    gstep = GraphedTrainStep(ma, oa, video, mask, L.HPARAMS, 16, ra, warmup=1, split=split)     # runs 1 + 1 + 1 updates on model a
+    assert (gstep.graph2 is not None) == split
     with torch.no_grad():                                                         # re-align the two replicas
         oa.p.copy_(ob.p); oa.m.copy_(ob.m); oa.v.copy_(ob.v); oa.refresh_shadow()
     oa.count = ob.count

@@ -11,9 +11,10 @@ What the capture needs and how it gets it:
   * static inputs: ``video`` / ``mask`` are copied into fixed buffers before each replay;
   * stochastic ops: ``Rngs.draw`` is pointed at fixed noise buffers (its injection hook) that are refilled by the default
     CUDA generator before each replay, so every step still sees fresh noise of the right distribution;
-  * no collective inside the graph: with a ``GradReducer`` attached the all-reduce of the flat gradient buffer is issued
-    after the replay (bucketed, async), i.e. graph mode trades the backward/all-reduce overlap of eager mode for zero
-    launch overhead; eager mode (``loss.train_step``) keeps the overlap.
+  * no collective inside a graph: with a ``GradReducer`` attached the step is captured as TWO graphs cut at the output of the
+    encoder's last block -- (forward + decoder backward) and (encoder backward).  The buckets that hold only decoder-side gradients are
+    handed to the reducer between the two replays, so their all-reduce (RCCL's own stream) runs under the encoder's backward;
+    the remaining buckets follow after the second replay.  Without a reducer one graph holds the whole pass.
 """
 import gc
 
@@ -24,8 +25,23 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3):
+    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None):
         self.model, self.opt, self.hparams, self.hw, self.rngs = model, optimizer, hparams, hw, rngs
+        self.split = (optimizer.reducer is not None) if split is None else bool(split)
+        enc = model.encoder
+        if not (hasattr(enc, "layers") and hasattr(enc, "patch_embedding") and len(enc.layers) > 0):
+            self.split = False
+        self.graph2 = None
+        if self.split:
+            # the cut: the output of the encoder's last FactoredAttention block (ONE tensor; the mean / variance / selection
+            # heads behind it depend on each other and stay with stage 1).  Stage 2 owns the patch embedding and the blocks --
+            # the tail of the flat buffer, which is laid out in reverse registration order.
+            self.cut_module = enc.layers[-1]
+            late = {id(p) for mod in [enc.patch_embedding, *enc.layers] for p in mod.parameters()}
+            self.enc_idx = [i for i, p in enumerate(optimizer.params) if id(p) in late]
+            self.dec_idx = [i for i, p in enumerate(optimizer.params) if id(p) not in late]
+            dec = set(self.dec_idx)
+            self.early_buckets = [b for b, members in enumerate(optimizer.bucket_params) if all(i in dec for i in members)]
         self.video = video.clone()
         self.mask = mask.clone()
         self.rl = L._is_rl(model)
@@ -33,12 +49,65 @@ class GraphedTrainStep:
         self.graph = None
         self._capture(warmup)
 
-    def _fwd_bwd(self):
+    def _loss(self):
         emask = L.expand_mask(self.mask, self.hw)
         if self.rl:
-            loss, aux = L.loss_fn(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
-        else:
-            loss, aux = L.loss_fn_plain(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
+            return L.loss_fn(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
+        return L.loss_fn_plain(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
+
+    # ---- two-stage form (data parallel): cut at the encoder's outputs -----------------------------------------------
+    def _stage1(self):
+        """Forward + backward of everything downstream of the encoder's last block: those gradients land, the gradient of the
+        block's output is kept for stage 2."""
+        grabbed = []
+        hook = self.cut_module.register_forward_hook(lambda m, inp, out: grabbed.append(out))
+        try:
+            loss, aux = self._loss()
+        finally:
+            hook.remove()
+        if len(grabbed) != 1 or not isinstance(grabbed[0], torch.Tensor) or not grabbed[0].requires_grad:
+            raise RuntimeError("split capture expects the encoder's last block to run once and return one tensor")
+        self._cut = [grabbed[0]]
+        opt = self.opt
+        opt.external = set()
+        opt.hooks_active = False
+        dec_params = [opt.params[i] for i in self.dec_idx]
+        with ops.deferred_wgrad(opt):
+            grads = torch.autograd.grad(loss, dec_params + self._cut, allow_unused=True)
+        self._gcut = grads[len(dec_params):]
+        opt.land_subset(self.dec_idx, grads[:len(dec_params)])
+        return loss.detach(), {k: v.detach() for k, v in aux.items() if k != "reconstruction"}
+
+    def _stage2(self):
+        """Backward of the encoder's blocks and patch embedding from the kept gradient; the rest of the flat buffer lands."""
+        opt = self.opt
+        pairs = [(c, g) for c, g in zip(self._cut, self._gcut) if g is not None]
+        enc_params = [opt.params[i] for i in self.enc_idx]
+        with ops.deferred_wgrad(opt):
+            grads = torch.autograd.grad([c for c, _ in pairs], enc_params, grad_outputs=[g for _, g in pairs], allow_unused=True)
+        opt.land_subset(self.enc_idx, grads)
+        opt.landed = [True] * len(opt.buckets)
+        self._cut = self._gcut = None
+
+    def _prelaunch(self):
+        """Hand the decoder-only buckets to the reducer: their all-reduce overlaps stage 2."""
+        opt = self.opt
+        if opt.reducer is not None and opt.defer_reduce:
+            opt.reducer.reset()
+            for b in self.early_buckets:
+                opt.reducer.launch(b)
+                opt.prelaunched.add(b)
+
+    def _pass(self):
+        if not self.split:
+            return self._fwd_bwd()
+        out = self._stage1()
+        self._prelaunch()
+        self._stage2()
+        return out
+
+    def _fwd_bwd(self):
+        loss, aux = self._loss()
         # torch.autograd.grad instead of .backward(): no AccumulateGrad nodes take part, so nothing created on another stream
         # (e.g. by the optimizer's hooks at construction time) can leak a cross-stream dependency into the capture
         self.opt.external = set()
@@ -63,9 +132,10 @@ class GraphedTrainStep:
         gc.collect()
         with torch.cuda.stream(self.stream):
             # 1. discover the stochastic draws of one step and pin them to static buffers
+            opt.defer_reduce = True           # collectives are issued by _prelaunch / Optimizer.update, never by the landing
             self.rngs.recording = {}
             opt.zero_grad()
-            self._fwd_bwd()
+            self._pass()
             opt.update()
             for name, (kind, shape, dtype) in self.rngs.recording.items():
                 buf = torch.empty(shape, dtype=dtype, device=self.video.device)
@@ -73,11 +143,10 @@ class GraphedTrainStep:
                 self.rngs.inject(name, buf)
             self.rngs.recording = None
             # 2. warm up (allocator, hipBLASLt heuristics, one-time kernel attributes)
-            opt.defer_reduce = True
             for _ in range(warmup):
                 self._refill()
                 opt.zero_grad()
-                self._fwd_bwd()
+                self._pass()
                 opt.update()
             self._refill()
             opt.zero_grad()
@@ -85,8 +154,16 @@ class GraphedTrainStep:
         gc.collect()
         # 3. capture forward + backward + gradient landing on the same stream
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self.stream):
-            self.loss, self.aux = self._fwd_bwd()
+        if self.split:
+            with torch.cuda.graph(g, stream=self.stream):
+                self.loss, self.aux = self._stage1()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=self.stream, pool=g.pool()):
+                self._stage2()
+            self.graph2 = g2
+        else:
+            with torch.cuda.graph(g, stream=self.stream):
+                self.loss, self.aux = self._fwd_bwd()
         if not all(opt.landed):
             raise RuntimeError("a gradient bucket did not land inside the captured backward (parameter without gradient)")
         self.graph = g
@@ -99,5 +176,8 @@ class GraphedTrainStep:
             self.mask.copy_(mask)
         self._refill()
         self.graph.replay()
+        if self.graph2 is not None:
+            self._prelaunch()
+            self.graph2.replay()
         self.opt.update()
         return self.loss, self.aux

@@ -111,6 +111,7 @@ class Optimizer:
         self.hooks_active = True       # False while gradients arrive through land_all (graph capture) instead of the hooks
         self.reducer = None            # set by ddp.GradReducer
         self.defer_reduce = False      # graph mode: do not launch collectives from the landing hooks (see graph.py)
+        self.prelaunched = set()       # graph mode: buckets already handed to the reducer between the two replays of a step
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -173,6 +174,25 @@ class Optimizer:
             for b in range(len(self.buckets)):
                 self.reducer.launch(b)
 
+    @torch.no_grad()
+    def land_subset(self, indices, grads):
+        """land_all for a subset of ``self.params`` (indices, gradients in the same order); buckets are not marked landed."""
+        dsts, srcs = [], []
+        for i, gr in zip(indices, grads):
+            if i in self.external:
+                self.clean.discard(i)
+                continue
+            if gr is None:
+                if i not in self.clean:
+                    self.gviews[i].zero_()
+                    self.clean.add(i)
+            else:
+                self.clean.discard(i)
+                dsts.append(self.gviews[i])
+                srcs.append(gr)
+        if dsts:
+            _copy_all(dsts, srcs)
+
     def mark_external(self, param):
         """The gradient of ``param`` has been written straight into its flat-buffer slot for this step (ops.deferred_wgrad):
         it counts as arrived, so a completed bucket goes to the reducer while backward is still running."""
@@ -212,9 +232,12 @@ class Optimizer:
         gscale = 1.0
         if self.reducer is not None:
             if self.defer_reduce:
-                self.reducer.reset()
+                if not self.prelaunched:
+                    self.reducer.reset()
                 for b in range(len(self.buckets)):
-                    self.reducer.launch(b)
+                    if b not in self.prelaunched:
+                        self.reducer.launch(b)
+                self.prelaunched = set()
             self.reducer.finish()
             gscale = 1.0 / self.reducer.world_size
         if not self.p.is_cuda:
