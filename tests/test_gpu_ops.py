@@ -843,3 +843,32 @@ def test_copy_grouped(dev):
     ops.copy_grouped(dsts, srcs)
     assert torch.equal(flat_d[3:o], flat_s[3:o])
     assert float(flat_d[:3].abs().max()) == 0 and float(flat_d[o:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upblock_concat_elision_matches_cat(dev, dtype):
+    """UpBlock3D with the joint buffer (up-conv and the encoder's GroupNorm+SiLU write the two channel halves in place,
+    ops.join_channels) == the reference's concat form (train/unet.py:76-83): outputs and all gradients."""
+    import video_vae_amd as V
+    from video_vae_amd import ops, unet as U
+    c = 16
+    up = U.UpBlock3D(2 * c, c, V.Rngs(4), dtype=dtype).to(dev)
+    blk = U.ConvBlock3D(c, c, 3, V.Rngs(5), dtype=dtype).to(dev)            # stands for the encoder's conv2 (skip producer)
+    x = rnd((1, 3, 6, 10, 2 * c), 80).to(dev, dtype)
+    s_in = rnd((1, 3, 12, 20, c), 81).to(dev, dtype)
+    gy = rnd((1, 3, 12, 20, c), 82).to(dev, dtype)
+    res = []
+    for fused in (True, False):
+        xx, ss = x.clone().requires_grad_(True), s_in.clone().requires_grad_(True)
+        up.zero_grad(); blk.zero_grad()
+        if fused:
+            joint = torch.empty((1, 3, 12, 20, 2 * c), dtype=dtype, device=dev)
+            skip = blk(ss, out=joint[..., c:])
+            y = up(xx, skip, joint)
+        else:
+            y = up(xx, blk(ss), None)
+        (y.float() * gy.float()).sum().backward()
+        res.append([y.detach(), xx.grad, ss.grad] + [p.grad.clone() for p in list(up.parameters()) + list(blk.parameters())])
+    assert torch.equal(res[0][0], res[1][0])
+    for k, (a, b) in enumerate(zip(*res)):                  # gradients: the generic fp32 weight-gradient path sums with float atomics
+        assert_close_scaled(a, b, rel=2e-5 if dtype == torch.float32 else 1e-6, what=f"tensor {k}")

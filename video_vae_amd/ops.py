@@ -305,23 +305,24 @@ def gn_silu_bwd_raw(x, dy, sums, scale, bias, groups, eps, out=None):
 
 class _GnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scale, bias, groups, eps):
+    def forward(ctx, x, scale, bias, groups, eps, out=None):
         s32, b32 = _f32(scale), _f32(bias)
         sums = gn_stats_raw(x, groups)
         ctx.save_for_backward(x, sums, s32, b32)
         ctx.groups, ctx.eps, ctx.pdtype = groups, eps, scale.dtype
-        return gn_silu_fwd_raw(x, sums, s32, b32, groups, eps)
+        return gn_silu_fwd_raw(x, sums, s32, b32, groups, eps, out)
 
     @staticmethod
     def backward(ctx, dy):
         x, sums, s32, b32 = ctx.saved_tensors
         dx, dg, db = gn_silu_bwd_raw(x, dy.to(x.dtype), sums, s32, b32, ctx.groups, ctx.eps)
-        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None
+        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None, None
 
 
-def group_norm_silu(x, scale, bias, groups, eps=1e-6):
-    """silu(GroupNorm(x)) over (t,h,w,C/G) per sample (reference train/unet.py:22-23,28-29)."""
-    return _GnSilu.apply(x, scale, bias, groups, eps)
+def group_norm_silu(x, scale, bias, groups, eps=1e-6, out=None):
+    """silu(GroupNorm(x)) over (t,h,w,C/G) per sample (reference train/unet.py:22-23,28-29).  ``out``: a channel slice of a
+    wider NDHWC buffer to write into (see join_channels)."""
+    return _GnSilu.apply(x, scale, bias, groups, eps, out)
 
 
 # --------------------------------------------------------------------------------------------- max-pool (1,2,2)
@@ -453,11 +454,11 @@ def colsum_raw(x):
 
 class _ConvT(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias):
+    def forward(ctx, x, kernel, bias, out=None):
         k32, b32 = _f32(kernel), _f32(bias)
         ctx.save_for_backward(x, k32)
         ctx.kdtype = kernel.dtype
-        return convt_fwd_raw(x, k32, b32)
+        return convt_fwd_raw(x, k32, b32, out)
 
     @staticmethod
     def backward(ctx, dy):
@@ -465,12 +466,37 @@ class _ConvT(torch.autograd.Function):
         dy = dy.to(x.dtype)
         dx = convt_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
         dw, db = convt_wgrad_db_raw(x, dy, tuple(k32.shape))
-        return dx, dw.to(ctx.kdtype), db.to(ctx.kdtype)
+        return dx, dw.to(ctx.kdtype), db.to(ctx.kdtype), None
 
 
-def conv_transpose_1x2x2(x, kernel, bias):
-    """nnx.ConvTranspose((1,2,2), strides (1,2,2)) (reference train/unet.py:61-69)."""
-    return _ConvT.apply(x, kernel, bias)
+def conv_transpose_1x2x2(x, kernel, bias, out=None):
+    """nnx.ConvTranspose((1,2,2), strides (1,2,2)) (reference train/unet.py:61-69).  ``out``: a channel slice of a wider
+    NDHWC buffer to write into (see join_channels)."""
+    return _ConvT.apply(x, kernel, bias, out)
+
+
+class _JoinChannels(torch.autograd.Function):
+    """concat([a, b], -1) without the copy (reference train/unet.py:79): a and b ARE the two channel slices of ``buf`` -- their
+    producers wrote them there through the kernels' row pitch -- so forward only re-labels the buffer and backward hands each
+    producer its slice of the incoming gradient (a pitched view; every consumer takes a row pitch)."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ca, cb = a.shape[-1], b.shape[-1]
+        if (buf.shape[-1] != ca + cb or not buf.is_contiguous() or a.data_ptr() != buf.data_ptr()
+                or b.data_ptr() != buf.data_ptr() + ca * buf.element_size() or a.stride() != buf.stride() or b.stride() != buf.stride()
+                or a.shape[:-1] != buf.shape[:-1] or b.shape[:-1] != buf.shape[:-1]):
+            raise VvaeError("join_channels: operands are not the channel slices of the joint buffer")
+        ctx.ca = ca
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.ca], g[..., ctx.ca:], None
+
+
+def join_channels(a, b, buf):
+    return _JoinChannels.apply(a, b, buf)
 
 
 _ROPE_TABS = {}

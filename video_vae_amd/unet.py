@@ -39,8 +39,8 @@ class ConvTranspose(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features, dtype=param_dtype))
         self.dtype = dtype
 
-    def forward(self, x):
-        return ops.conv_transpose_1x2x2(x.to(self.dtype), self.kernel, self.bias)
+    def forward(self, x, out=None):
+        return ops.conv_transpose_1x2x2(x.to(self.dtype), self.kernel, self.bias, out)
 
 
 class GroupNorm(nn.Module):
@@ -62,10 +62,11 @@ class ConvBlock3D(nn.Module):
         self.conv = Conv(in_channels, out_channels, (temporal_kernel, kernel_size, kernel_size), rngs, dtype, param_dtype)
         self.norm = GroupNorm(min(8, out_channels), out_channels, param_dtype)
 
-    def forward(self, x, kernel=None):
+    def forward(self, x, kernel=None, out=None):
         # ``kernel``: optional stand-in for self.conv.kernel (UNet passes a zero-padded view for 16-channel alignment)
+        # ``out``: channel slice of a wider buffer for the block's output (the skip half of a decoder's concat buffer)
         x = ops.conv3d(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias)
-        return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6)
+        return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out)
 
 
 class DownBlock3D(nn.Module):
@@ -76,8 +77,8 @@ class DownBlock3D(nn.Module):
         self.conv1 = ConvBlock3D(in_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
         self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
 
-    def forward(self, x, kernel1=None):
-        x = self.conv2(self.conv1(x, kernel1))
+    def forward(self, x, kernel1=None, skip_out=None):
+        x = self.conv2(self.conv1(x, kernel1), out=skip_out)
         return ops.max_pool_1x2x2(x), x
 
 
@@ -90,9 +91,14 @@ class UpBlock3D(nn.Module):
         self.conv1 = ConvBlock3D(out_channels * 2, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
         self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
 
-    def forward(self, x, skip):
-        x = self.upsample(x)
-        x = torch.cat([x, skip], dim=-1)
+    def forward(self, x, skip, joint=None):
+        """joint: the (.., 2C) buffer whose upper channel half ``skip`` already is; the up-conv writes the lower half and the
+        concat of the reference (unet.py:79, a 268 MB copy at the 256^2 level) disappears."""
+        if joint is not None:
+            c = skip.shape[-1]
+            x = ops.join_channels(self.upsample(x, out=joint[..., :c]), skip, joint)
+        else:
+            x = torch.cat([self.upsample(x), skip], dim=-1)
         return self.conv2(self.conv1(x))
 
 
@@ -137,11 +143,18 @@ class UNet(nn.Module):
             k1 = F.pad(self.encoders[0].conv1.conv.kernel, (0, 0, 0, pad))
         else:
             x = self.patch_mixer(x)
-        skips = []
+        skips, joints = [], []
         for i, enc in enumerate(self.encoders):
-            x, skip = enc(x, k1 if i == 0 else None)
+            c = enc.conv2.norm.scale.shape[0]
+            joint = None
+            if x.is_cuda and x.shape[-3] % 2 == 0 and x.shape[-2] % 2 == 0:
+                # the decoder at this level will read concat([up, skip]): allocate that buffer now and let the encoder's
+                # last kernel write the skip straight into its upper channel half
+                joint = torch.empty((*x.shape[:-1], 2 * c), dtype=self.dtype, device=x.device)
+            x, skip = enc(x, k1 if i == 0 else None, None if joint is None else joint[..., c:])
             skips.append(skip)
+            joints.append(joint)
         x = self.bottleneck2(self.bottleneck1(x))
-        for dec, skip in zip(self.decoders, reversed(skips)):
-            x = dec(x, skip)
+        for dec, skip, joint in zip(self.decoders, reversed(skips), reversed(joints)):
+            x = dec(x, skip, joint)
         return self.final_conv(x)
