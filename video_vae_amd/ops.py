@@ -367,6 +367,30 @@ def max_pool_1x2x2(x):
     return _MaxPool.apply(x)
 
 
+class _MaxPoolFork(torch.autograd.Function):
+    """DownBlock3D's ``return max_pool(x), x`` (reference train/unet.py:50-51) as one node: the second output is x itself, so the
+    gradient of the skip connection arrives HERE and is added inside the pool-backward kernel (its ``dskip`` operand, any row
+    pitch) instead of by a separate add launch over the largest activations of the network."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        return maxpool_fwd_raw(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dpool, dskip):
+        (x,) = ctx.saved_tensors
+        if dpool is None:
+            return dskip
+        return maxpool_bwd_raw(x, dpool.to(x.dtype), None if dskip is None else dskip.to(x.dtype))
+
+
+def max_pool_fork(x):
+    """-> (max_pool_1x2x2(x), x) with the skip gradient folded into the pool's backward kernel."""
+    return _MaxPoolFork.apply(x)
+
+
 # --------------------------------------------------------------------------------------------- ConvTranspose (1,2,2)
 def _convt_fast(x, cin, cout, ld_in, ld_out):
     return (x.dtype == torch.bfloat16 and not _FORCE_GENERIC[0]

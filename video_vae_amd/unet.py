@@ -79,7 +79,7 @@ class DownBlock3D(nn.Module):
 
     def forward(self, x, kernel1=None, skip_out=None):
         x = self.conv2(self.conv1(x, kernel1), out=skip_out)
-        return ops.max_pool_1x2x2(x), x
+        return ops.max_pool_fork(x)
 
 
 class UpBlock3D(nn.Module):
