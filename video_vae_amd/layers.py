@@ -31,6 +31,19 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
+_MASK_U8 = [None]          # (mask tensor, its version, t, uint8 form): every block of a step is handed the same mask object
+
+
+def _mask_u8(mask, t):
+    """(rows, t) uint8 form of the temporal mask, converted once per mask tensor instead of once per attention block."""
+    hit = _MASK_U8[0]
+    if hit is not None and hit[0] is mask and hit[1] == mask._version and hit[2] == t:
+        return hit[3]
+    m8 = mask.reshape(-1, t).to(torch.uint8).contiguous()
+    _MASK_U8[0] = (mask, mask._version, t, m8)
+    return m8
+
+
 class _LinearBf16(torch.autograd.Function):
     """y = x @ W + b in bf16 on hipBLASLt with fp32 master weights: the forward reads the optimizer's bf16 shadow copy
     (``param.bf16``, refreshed by the fused Adam kernel) so no per-call weight cast runs, and the backward returns
@@ -266,7 +279,7 @@ class Attention(nn.Module):
         qkv = self.qkv_projection(x)
         m8, div = None, 1
         if mask is not None:
-            m8 = mask.reshape(-1, t).to(torch.uint8).contiguous()
+            m8 = _mask_u8(mask, t)
             div = (b * hw) // m8.shape[0]
         o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
                                         m8, div, self.num_heads, 1e-6, inner=hw)
