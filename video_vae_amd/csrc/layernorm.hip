@@ -118,28 +118,30 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
 }
 
 // dy rows contiguous (pitch C); dx rows contiguous.  part: fp32 [gridDim.x][2][C] = per-workgroup (sum dy*xhat | sum dy).
+constexpr int LN_BW = 8;                      // waves per workgroup of the backward kernel (one partial row per workgroup)
+
 template <typename T_, int LPR, int VPL>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict__ x, const T_* __restrict__ dy, const float* __restrict__ gamma,
+__global__ __launch_bounds__(64 * LN_BW) void layernorm_bwd_kernel(const T_* __restrict__ x, const T_* __restrict__ dy, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const T_* __restrict__ dres, T_* __restrict__ dx, float* __restrict__ part,
                                                             LnDims d)
 {
     constexpr int V = VecWidth<T_>::value, RPW = 64 / LPR;
-    __shared__ __attribute__((aligned(16))) float red[4][LPR][VPL * V];
+    __shared__ __attribute__((aligned(16))) float red[LN_BW][LPR][VPL * V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, ll = lane % LPR;
     // gamma stays in LDS (see the forward kernel for why it gets there in one coalesced pass) and is re-read per use:
     // registers go to the two column accumulators instead
     __shared__ __attribute__((aligned(16))) float sg[LPR * VPL * V];
-    for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) sg[i] = i < d.C ? gamma[i] : 0.f;
+    for (int i = threadIdx.x; i < LPR * VPL * V; i += 64 * LN_BW) sg[i] = i < d.C ? gamma[i] : 0.f;
     __syncthreads();
     float ag[VPL][V], ab[VPL][V];
 #pragma unroll
     for (int k = 0; k < VPL; ++k)
 #pragma unroll
         for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
-    const long rstride = (long)gridDim.x * 4 * RPW;
-    for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
+    const long rstride = (long)gridDim.x * LN_BW * RPW;
+    for (long r0 = ((long)blockIdx.x * LN_BW + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
         const bool rv = r < d.rows;
         const T_* xr = x + row_off(d, rv ? r : 0);
@@ -207,23 +209,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T_* __restrict
                 if (lane < LPR) red[wave][lane][k * V + e] = t;
             }
         __syncthreads();
-        for (int i = threadIdx.x; i < LPR * VPL * V; i += 256) {
+        for (int i = threadIdx.x; i < LPR * VPL * V; i += 64 * LN_BW) {
             const int l2 = i / (VPL * V), kv = i % (VPL * V);
             const int c = ((kv / V) * LPR + l2) * V + kv % V;
-            if (c < d.C) pg[pass * d.C + c] = (red[0][l2][kv] + red[1][l2][kv]) + (red[2][l2][kv] + red[3][l2][kv]);
+            if (c < d.C) {
+                float t = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < LN_BW; w2 += 2) t += red[w2][l2][kv] + red[w2 + 1][l2][kv];      // fixed order
+                pg[pass * d.C + c] = t;
+            }
         }
         __syncthreads();
     }
 }
 
-int g_ln_bwd_cap = 1024;
+int g_ln_bwd_cap = 512;
 
 inline int ln_blocks(long rows, int lpr, int cap = 0)
 {
+    const int waves = cap == 0 ? LN_BW : 4;
     if (cap == 0) cap = g_ln_bwd_cap;
     // backward: <= 1024 workgroups (each emits one partial row of dgamma/dbeta).  forward has no epilogue, so it takes one
     // row-slot per wave (cap 16384): every row's loads are in flight at once instead of 4 rows queued behind each other.
-    const long per = 4L * (64 / lpr);
+    const long per = (long)waves * (64 / lpr);
     long b = (rows + per - 1) / per;
     if (b > cap) b = cap;
     return (int)(b < 1 ? 1 : b);
@@ -252,7 +260,7 @@ bool ln_ok(const LnDims& d, const void* x, int& lpr, int& vpl)
 
 }  // namespace
 
-#define LN_CASE(KERNEL, T_, L, P, ...) case L * 8 + P: hipLaunchKernelGGL((KERNEL<T_, L, P>), grid, dim3(256), 0, s, __VA_ARGS__); break;
+#define LN_CASE(KERNEL, T_, L, P, ...) case L * 8 + P: hipLaunchKernelGGL((KERNEL<T_, L, P>), grid, dim3(ln_threads), 0, s, __VA_ARGS__); break;
 #define LN_SWITCH(KERNEL, T_, ...)                                                                                                   \
     do {                                                                                                                             \
         switch (lpr * 8 + vpl) {                                                                                                     \
@@ -294,10 +302,12 @@ extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, co
     if (dtype == VVAE_DT_F32) {
         if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr, 2048));
+        const int ln_threads = 256;
         LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, (const float*)addend, (float*)xsum, d);
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr, 1024));          // 4096 waves: all resident at 6 waves/SIMD (2048 left a third-full second round)
+        const int ln_threads = 256;
         LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
@@ -317,10 +327,12 @@ extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* ga
     if (dtype == VVAE_DT_F32) {
         if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr));
+        const int ln_threads = 64 * LN_BW;
         LN_SWITCH(layernorm_bwd_kernel, float, (const float*)x, (const float*)dy, gamma, mean, rstd, (const float*)dres, (float*)dx, part, d);
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr));
+        const int ln_threads = 64 * LN_BW;
         LN_SWITCH(layernorm_bwd_kernel, bf16_t, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, part, d);
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
@@ -330,6 +342,6 @@ extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* ga
 // Tuning hook: workgroups (= partial rows) of the backward kernel.
 extern "C" int vvae_layernorm_config(int bwd_cap)
 {
-    g_ln_bwd_cap = bwd_cap > 0 ? bwd_cap : 1024;
+    g_ln_bwd_cap = bwd_cap > 0 ? bwd_cap : 512;
     return 0;
 }
