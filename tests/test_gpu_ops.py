@@ -383,6 +383,8 @@ ROLL_CASES = [
     # cin, cout, kh, (n, t, h, w): every single-chunk shape the rolling time-column kernel owns, fwd and dgrad roles
     (16, 16, 3, (2, 5, 20, 24)), (16, 32, 3, (1, 7, 9, 33)), (32, 16, 3, (1, 6, 17, 16)), (32, 32, 3, (2, 5, 18, 30)),
     (16, 16, 7, (1, 5, 21, 40)),
+    # degenerate extents: one frame, tiles wider / taller than the volume, a single row
+    (16, 16, 3, (1, 1, 5, 7)), (32, 32, 3, (1, 2, 3, 50)), (32, 16, 3, (3, 1, 1, 1)), (16, 16, 7, (1, 2, 2, 3)),
 ]
 
 
