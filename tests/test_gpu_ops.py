@@ -372,6 +372,7 @@ FAST_CASES = [
     (32, 64, 3, 3, 3, (1, 2, 12, 20)), (64, 64, 3, 3, 3, (1, 3, 8, 16)), (64, 128, 3, 3, 3, (1, 2, 8, 16)),
     (128, 128, 3, 3, 3, (1, 2, 8, 8)), (128, 64, 3, 3, 3, (1, 2, 10, 16)), (64, 32, 3, 3, 3, (1, 2, 16, 16)),
     (32, 16, 3, 3, 3, (1, 3, 16, 32)), (16, 16, 3, 7, 7, (1, 3, 20, 24)), (16, 16, 3, 7, 7, (2, 1, 5, 40)),
+    (32, 16, 3, 3, 3, (1, 2, 3, 50)), (32, 32, 3, 3, 3, (2, 1, 1, 1)), (16, 16, 3, 7, 7, (1, 2, 2, 3)),      # degenerate extents
 ]
 
 
