@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--flavour", default="model", choices=["model", "rl"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="attach the gradient reducer and a process group even at world size 1 (launch under torch.distributed.run)")
     ap.add_argument("--split-graph", action="store_true",
                     help="capture the step as two graphs cut at the encoder's last block even at N = 1 (the N > 1 default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -113,11 +115,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    ddp_on = world > 1 or args.force_ddp     # --force-ddp: the whole process-group path with a single rank (RCCL rehearsal)
     if args.backend != "nccl":               # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (gloo transport)
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if ddp_on:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -129,7 +132,7 @@ def main():
     model, cfg = build_model(args, dev, dtype)
     opt = optim.Optimizer(model, optim.reference_schedule(batch_size=args.batch * world))
     reducer = None
-    if world > 1:
+    if ddp_on:
         reducer = ddp.GradReducer(opt)
         reducer.broadcast_parameters(0)
     nparams = sum(p.numel() for p in model.parameters())
@@ -176,7 +179,7 @@ def main():
                 step, mode = eager_step, "eager"
 
     def barrier():
-        if world > 1:
+        if ddp_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,9 +205,9 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.TIMER = None
-    if world > 1:
+    if ddp_on:
         dist.barrier()
-    if world > 1:
+    if ddp_on:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -279,7 +282,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if ddp_on:
         dist.destroy_process_group()
 
 

@@ -154,15 +154,18 @@ class GraphedTrainStep:
         gc.collect()
         # 3. capture forward + backward + gradient landing on the same stream
         g = torch.cuda.CUDAGraph()
+        # With a process group alive its watchdog thread polls events while we capture: only the capturing thread's own calls
+        # may invalidate the capture then ("thread_local"); the default mode would let that poll abort it.
+        mode = "thread_local" if opt.reducer is not None else "global"
         if self.split:
-            with torch.cuda.graph(g, stream=self.stream):
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
                 self.loss, self.aux = self._stage1()
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=self.stream, pool=g.pool()):
+            with torch.cuda.graph(g2, stream=self.stream, pool=g.pool(), capture_error_mode=mode):
                 self._stage2()
             self.graph2 = g2
         else:
-            with torch.cuda.graph(g, stream=self.stream):
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
                 self.loss, self.aux = self._fwd_bwd()
         if not all(opt.landed):
             raise RuntimeError("a gradient bucket did not land inside the captured backward (parameter without gradient)")
