@@ -373,38 +373,48 @@ extern "C" int vvae_sum_rows(const float* part, int rows, int cols, float* out, 
 namespace {
 // Grouped fold: up to 64 partial buffers in one launch (the dgamma / dbeta / q-k-scale partial rows of a whole backward pass).
 // Entry e: out[c] = sum_r part_e[r * cols_e + c]; columns < n0_e go to d0_e[c], the rest to d1_e[c - n0_e] (or nowhere if d1_e is
-// NULL).  Blocks [block_start_e, block_start_{e+1}) belong to entry e, 32 columns each; same row order as vvae_reduce_rows_kernel.
+// NULL).  Blocks [block_start_e, block_start_{e+1}) belong to entry e, 128 columns each (cols_e % 4 == 0); fixed row order.
 constexpr int FOLD_MAX = 64;
 struct FoldEntry { const float* part; float* d0; float* d1; int rows, cols, n0, block_start; };
 struct FoldArgs { FoldEntry e[FOLD_MAX]; int n; };
 
 __global__ __launch_bounds__(256) void fold_rows_grouped_kernel(FoldArgs g)
 {
-    __shared__ float red[8][32];
+    // 256 threads = 32 float4 columns (128 columns of the entry) x 8 row lanes; 8 sixteen-byte loads in flight per thread
+    __shared__ float4 red[8][32];
     int ei = 0;
     for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].block_start ? i : ei;
     const FoldEntry& E = g.e[ei];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = ((int)blockIdx.x - E.block_start) * 32 + cl;
-    float s = 0.f;
+    const int c = (((int)blockIdx.x - E.block_start) * 32 + cl) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < E.cols) {
         for (int r0 = rl; r0 < E.rows; r0 += 8 * 8) {
-            float v[8];
+            float4 v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int r = r0 + 8 * i;
-                v[i] = r < E.rows ? E.part[(long)r * E.cols + c] : 0.f;
+                v[i] = r < E.rows ? *reinterpret_cast<const float4*>(E.part + (long)r * E.cols + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += v[i];
+            for (int i = 0; i < 8; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
         }
     }
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < E.cols) {
-        const float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
-        if (c < E.n0) E.d0[c] = t;
-        else if (E.d1) E.d1[c - E.n0] = t;
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* q = reinterpret_cast<const float*>(&red[0][cl]) + e;          // element e of row lane j at q[j * 128]
+            t[e] = ((q[0] + q[128]) + (q[256] + q[384])) + ((q[512] + q[640]) + (q[768] + q[896]));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ce = c + e;
+            if (ce < E.n0) E.d0[ce] = t[e];
+            else if (E.d1) E.d1[ce - E.n0] = t[e];
+        }
     }
 }
 }  // namespace
@@ -421,7 +431,8 @@ extern "C" int vvae_fold_rows_grouped(const void* const* part, float* const* d0,
     for (int i = 0; i < n; ++i) {
         if (!part[i] || !d0[i] || rows[i] <= 0 || cols[i] <= 0 || n0[i] <= 0 || n0[i] > cols[i]) return VVAE_ERR_BAD_ARG;
         g.e[i] = FoldEntry{(const float*)part[i], d0[i], d1[i], rows[i], cols[i], n0[i], blocks};
-        blocks += ceil_div(cols[i], 32);
+        if (cols[i] % 4 || ((uintptr_t)part[i] % 16)) return VVAE_ERR_BAD_ARG;
+        blocks += ceil_div(cols[i], 128);
     }
     hipLaunchKernelGGL(fold_rows_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
     VVAE_LAUNCH_CHECK();

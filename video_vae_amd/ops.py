@@ -1083,18 +1083,38 @@ class _WgradQueue:
         if len(self.folds) == FOLD_MAX:
             self.flush_folds()
 
+    @staticmethod
+    def _fold_launch(entries):
+        """entries: (part pointer, d0 pointer, d1 pointer or None, rows, cols, n0), at most FOLD_MAX per launch."""
+        for i0 in range(0, len(entries), FOLD_MAX):
+            e = entries[i0:i0 + FOLD_MAX]
+            n = len(e)
+            VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+            check(lib().vvae_fold_rows_grouped(VP(*[x[0] for x in e]), VP(*[x[1] for x in e]), VP(*[x[2] for x in e]),
+                                               IA(*[x[3] for x in e]), IA(*[x[4] for x in e]), IA(*[x[5] for x in e]), n, _stream()),
+                  "vvae_fold_rows_grouped")
+
     def flush_folds(self):
         folds, self.folds = self.folds, []
         if not folds:
             return
-        n = len(folds)
-        VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
-        rows = [f[0].shape[0] for f in folds]
-        cols = [f[0].numel() // f[0].shape[0] for f in folds]
-        n0 = [f[1].numel() for f in folds]
-        check(lib().vvae_fold_rows_grouped(VP(*[f[0].data_ptr() for f in folds]), VP(*[f[1].gview.data_ptr() for f in folds]),
-                                           VP(*[(f[2].gview.data_ptr() if f[2] is not None else None) for f in folds]),
-                                           IA(*rows), IA(*cols), IA(*n0), n, _stream()), "vvae_fold_rows_grouped")
+        first, second, keep = [], [], []
+        for part, p0, p1 in folds:
+            rows = part.shape[0]
+            cols = part.numel() // rows
+            d0, d1 = p0.gview.data_ptr(), (p1.gview.data_ptr() if p1 is not None else None)
+            r, c, k = rows, cols, 1
+            while r > 1024 and r % 2 == 0 and c * 2 <= 8192:          # tall and narrow (one row per attention workgroup): read
+                r //= 2; c *= 2; k *= 2                               # (rows, cols) as (rows/k, k*cols) so that many workgroups
+            if k == 1:                                                # share the fold, then sum the k partial rows
+                first.append((part.data_ptr(), d0, d1, rows, cols, p0.numel()))
+            else:
+                tmp = torch.empty((k, cols), dtype=torch.float32, device=part.device)
+                keep.append(tmp)
+                first.append((part.data_ptr(), tmp.data_ptr(), None, r, c, c))
+                second.append((tmp.data_ptr(), d0, d1, k, cols, p0.numel()))
+        self._fold_launch(first)
+        self._fold_launch(second)
         for _, p0, p1 in folds:
             self.opt.mark_external(p0)
             if p1 is not None:
