@@ -875,3 +875,37 @@ def test_upblock_concat_elision_matches_cat(dev, dtype):
     assert torch.equal(res[0][0], res[1][0])
     for k, (a, b) in enumerate(zip(*res)):                  # gradients: the generic fp32 weight-gradient path sums with float atomics
         assert_close_scaled(a, b, rel=2e-5 if dtype == torch.float32 else 1e-6, what=f"tensor {k}")
+
+
+@pytest.mark.parametrize("ci,co,kh,hw", [(16, 16, 3, 256), (32, 16, 3, 256), (16, 16, 7, 256), (32, 32, 3, 128), (64, 32, 3, 128)])
+def test_conv3d_full_size_properties(dev, ci, co, kh, hw):
+    """BASELINE's full extent (B=4, 16 frames, 256^2 / 128^2): properties that need no oracle.  Scaling an operand by 2 is exact
+    in bf16 and in every fp32 partial sum, so fwd / dgrad / wgrad must scale bitwise; the rolling and per-frame kernels must agree
+    bitwise; a clip shifted by one frame gives the shifted output away from the temporal border."""
+    from video_vae_amd import ops
+    from video_vae_amd._lib import lib
+    g = torch.Generator(device="cpu").manual_seed(ci * 131 + co * 7 + kh)
+    x = (torch.randn((4, 16, hw, hw, ci), generator=g) * 0.5).to(dev, torch.bfloat16)
+    gy = (torch.randn((4, 16, hw, hw, co), generator=g) * 0.5).to(dev, torch.bfloat16)
+    k = (torch.randn((3, kh, kh, ci, co), generator=g) * (3 * kh * kh * ci) ** -0.5).to(dev)
+    zero_b = torch.zeros(co, device=dev)
+    y = ops.conv3d_fwd_raw(x, k, zero_b)
+    dx = ops.conv3d_dgrad_raw(gy, k)
+    dw, db = ops.conv3d_wgrad_raw(x, gy, tuple(k.shape))
+    assert torch.isfinite(y.float()).all() and torch.isfinite(dx.float()).all() and torch.isfinite(dw).all()
+    assert torch.equal(ops.conv3d_fwd_raw(x * 2, k, zero_b), y * 2)
+    assert torch.equal(ops.conv3d_dgrad_raw(gy * 2, k), dx * 2)
+    dw2, db2 = ops.conv3d_wgrad_raw(x, gy * 2, tuple(k.shape))
+    assert torch.equal(dw2, dw * 2) and torch.equal(db2, db * 2)
+    try:
+        lib().vvae_conv3d_roll_config(0, 0)
+        assert torch.equal(ops.conv3d_fwd_raw(x, k, zero_b), y)
+        assert torch.equal(ops.conv3d_dgrad_raw(gy, k), dx)
+    finally:
+        lib().vvae_conv3d_roll_config(1, 0)
+    xs = torch.zeros_like(x)
+    xs[:, 1:] = x[:, :-1]
+    ys = ops.conv3d_fwd_raw(xs, k, zero_b)
+    assert torch.equal(ys[:, 1:-1], y[:, :-2])              # frame 15 of the shifted clip misses x[15]: excluded
+    # db = column sums of gy: compare with a float64 reduction
+    assert_close_scaled(db, gy.double().sum((0, 1, 2, 3)).float(), rel=1e-5, what="db")
