@@ -144,19 +144,25 @@ __global__ __launch_bounds__(64 * LN_BW) void layernorm_bwd_kernel(const T_* __r
     for (long r0 = ((long)blockIdx.x * LN_BW + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
         const bool rv = r < d.rows;
-        const T_* xr = x + row_off(d, rv ? r : 0);
-        const T_* gr = dy + (rv ? r : 0) * d.C;
-        const float mean = rv ? mean_in[r] : 0.f, rstd = rv ? rstd_in[r] : 0.f;
+        const long rs = rv ? r : 0;
+        const T_* xr = x + row_off(d, rs);
+        const T_* gr = dy + rs * d.C;
+        const float mean = mean_in[rs], rstd = rstd_in[rs];
+        // x and dy are requested unconditionally (out-of-range lanes read row / column 0 and are zeroed afterwards): predicated
+        // loads compiled to one branch + one full memory wait per vector, i.e. several serialised latencies per iteration
         uint4 rx[VPL], rg[VPL];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             const int c = (k * LPR + ll) * V;
-            rx[k] = make_uint4(0, 0, 0, 0); rg[k] = make_uint4(0, 0, 0, 0);
-            if (rv && c < d.C) {
-                rx[k] = *reinterpret_cast<const uint4*>(xr + c);
-                rg[k] = *reinterpret_cast<const uint4*>(gr + c);
-            }
+            const int cs = c < d.C ? c : 0;
+            rx[k] = *reinterpret_cast<const uint4*>(xr + cs);
+            rg[k] = *reinterpret_cast<const uint4*>(gr + cs);
+        }
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = (k * LPR + ll) * V;
+            if (!(rv && c < d.C)) { rx[k] = make_uint4(0, 0, 0, 0); rg[k] = make_uint4(0, 0, 0, 0); }
         }
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
