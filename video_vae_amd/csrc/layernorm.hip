@@ -76,23 +76,38 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
     for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < d.rows; r0 += rstride) {
         const long r = r0 + sub;
         const bool rv = r < d.rows;
-        const T_* xr = x + row_off(d, rv ? r : 0);
-        float v[VPL][V];
+        const long rs = rv ? r : 0;
+        const T_* xr = x + row_off(d, rs);
+        const bool has_add = addend != nullptr;
+        // all of the row's loads are requested before any is consumed, unconditionally (out-of-range lanes read row / column 0
+        // and contribute zeros): predicated loads cost one branch + one full memory wait per vector
+        float v[VPL][V], a[VPL][V];
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             const int c = (k * LPR + ll) * V;
-            if (rv && c < d.C) {
-                VecIO<T_, V>::load(xr + c, v[k]);
-                if (addend) {
-                    float a[V];
-                    VecIO<T_, V>::load(addend + r * d.C + c, a);
+            VecIO<T_, V>::load(xr + (c < d.C ? c : 0), v[k]);
+        }
+        if (has_add) {
 #pragma unroll
-                    for (int e = 0; e < V; ++e) v[k][e] = round_to<T_>(v[k][e] + a[e]);
-                    VecIO<T_, V>::store(xsum + r * d.C + c, v[k]);
-                }
+            for (int k = 0; k < VPL; ++k) {
+                const int c = (k * LPR + ll) * V;
+                VecIO<T_, V>::load(addend + rs * d.C + (c < d.C ? c : 0), a[k]);
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < V; ++e) { s += v[k][e]; ss += v[k][e] * v[k][e]; }
+        for (int k = 0; k < VPL; ++k) {
+            const int c = (k * LPR + ll) * V;
+            const bool ok = rv && c < d.C;
+            if (has_add) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[k][e] = round_to<T_>(v[k][e] + a[k][e]);
+                if (ok) VecIO<T_, V>::store(xsum + r * d.C + c, v[k]);
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (!ok) v[k][e] = 0.f;
+                s += v[k][e]; ss += v[k][e] * v[k][e];
             }
         }
         if (!staged) stage();
