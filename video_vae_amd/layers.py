@@ -31,6 +31,33 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
+_BMM_F32_OUT = [None]
+
+
+def _dw_f32(x2, dy2):
+    """x2^T @ dy2 (K tokens x M, K x N -> M x N fp32) for the Linear layers the HIP weight-gradient kernels do not take
+    (M or N not a multiple of 128: patch embedding / un-embedding, the latent heads).  The library picks 64x64 tiles for such
+    products, i.e. a few dozen workgroups each walking all 16 384 tokens; splitting the tokens into independent batches first
+    (a batched product, then a fixed-order sum of the partial results) fills the chip: ~97 us -> ~20 us per product."""
+    k, m = x2.shape
+    n = dy2.shape[1]
+    tiles = -(-m // 64) * -(-n // 64)
+    split = 1
+    while split < 32 and tiles * split < 512 and k % (2 * split) == 0 and k // (2 * split) >= 512:
+        split *= 2
+    if split > 1 and x2.is_contiguous() and dy2.is_contiguous():
+        if _BMM_F32_OUT[0] is None:
+            try:
+                torch.bmm(x2[:2, :1].reshape(1, 1, 2), dy2[:2, :1].reshape(1, 2, 1), out_dtype=torch.float32)
+                _BMM_F32_OUT[0] = True
+            except Exception:
+                _BMM_F32_OUT[0] = False
+        if _BMM_F32_OUT[0]:
+            part = torch.bmm(x2.view(split, k // split, m).transpose(1, 2), dy2.view(split, k // split, n), out_dtype=torch.float32)
+            return part.sum(0)
+    return _mm_f32(x2.t(), dy2)
+
+
 _MASK_U8 = [None]          # (mask tensor, its version, t, uint8 form): every block of a step is handed the same mask object
 
 
@@ -79,7 +106,7 @@ class _LinearBf16(torch.autograd.Function):
             # split-K weight-gradient GEMM on the HIP kernel (bias gradient rides along): K = tokens >> M, N
             dw, db = ops.gemm_tn(x2, dy2, ctx.needs_input_grad[2])
         else:
-            dw = _mm_f32(x2.t(), dy2) if ctx.needs_input_grad[1] else None
+            dw = _dw_f32(x2, dy2) if ctx.needs_input_grad[1] else None
             db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
         return dx, dw, db
 
@@ -120,7 +147,7 @@ class _SiluLinearBf16(torch.autograd.Function):
         if ctx.needs_input_grad[1] and ops.gemm_tn_supported(a, dy2):
             dw, db = ops.gemm_tn(a, dy2, ctx.needs_input_grad[2])
         else:
-            dw = _mm_f32(a.t(), dy2) if ctx.needs_input_grad[1] else None
+            dw = _dw_f32(a, dy2) if ctx.needs_input_grad[1] else None
             db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
         return dh, dw, db
 
