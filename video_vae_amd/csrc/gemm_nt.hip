@@ -64,9 +64,9 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 // s_waitcnt vmcnt(0) only (expcnt / lgkmcnt left at their maxima)
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }      // v_rcp_f32: 1 ulp
 // d/dx silu(x) = s (1 + x (1 - s)), s = sigmoid(x)
-__device__ __forceinline__ float dsilu_f(float x) { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+__device__ __forceinline__ float dsilu_f(float x) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
 
 template <typename C>
 __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ Cout,
@@ -160,6 +160,19 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     if (!grp) __builtin_amdgcn_s_barrier();
     __syncthreads();                          // every wave is done with the operand buffers: reuse them for the C image
 
+    // the second operand of the tail (residual / saved pre-activation) does not depend on the product: request this thread's
+    // chunks now, so they arrive while the accumulators are parked in LDS (they were three exposed memory latencies per tile)
+    constexpr int CPR = C::BN * 2 / 16;                          // 16-byte chunks per row of the C tile
+    constexpr int NIT = C::BM * CPR / C::NT;                     // chunks per thread
+    const bool has_res = d.epi == EPI_RES || d.epi == EPI_MUL_DSILU;
+    uint4 rpre[NIT];
+    if (has_res) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int q = tid + it * C::NT;
+            rpre[it] = *reinterpret_cast<const uint4*>(res + (long)(m0 + q / CPR) * d.ldr + n0 + (q % CPR) * 8);
+        }
+    }
     // ---- epilogue pass 1: acc (+bias) -> bf16 image [BM][BN], pitch CP.  acc[i][j][r]: channel 32 i + 8 (r/4) + 4 kh + r%4,
     //      token 32 j + fr
 #pragma unroll
@@ -181,9 +194,9 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     }
     __syncthreads();
     // ---- epilogue pass 2: coalesced 16-byte rows, fused elementwise tail on the ROUNDED linear output
-    constexpr int CPR = C::BN * 2 / 16;                          // chunks per row
-#pragma unroll 4
-    for (int q = tid; q < C::BM * CPR; q += C::NT) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + it * C::NT;
         const int row = q / CPR, cc = q % CPR;
         uint4 v = *reinterpret_cast<const uint4*>(smem + row * C::CP + cc * 16);
         const long gm = m0 + row;
@@ -200,7 +213,11 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
                 for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
             } else {
                 float r[8];
-                VecIO<bf16_t, 8>::load(res + gm * d.ldr + gn, r);
+                {
+                    const uint32_t rw[4] = {rpre[it].x, rpre[it].y, rpre[it].z, rpre[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { r[2 * e] = __uint_as_float(rw[e] << 16); r[2 * e + 1] = __uint_as_float(rw[e] & 0xffff0000u); }
+                }
                 if (d.epi == EPI_RES) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = x[e] + r[e];
