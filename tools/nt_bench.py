@@ -28,7 +28,7 @@ def tmg(f, n=20):
     return e0.elapsed_time(e1) / (5 * n) * 1e3
 M = 16384
 torch.manual_seed(0)
-for N, K in [(1536, 768), (768, 512), (768, 1536), (512, 768), (768, 768)]:
+for N, K in [(768, 2304), (1536, 768), (768, 512), (768, 1536), (512, 768), (768, 768)]:
     a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
     b = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device=dev)
