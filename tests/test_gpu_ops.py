@@ -909,3 +909,33 @@ def test_conv3d_full_size_properties(dev, ci, co, kh, hw):
     assert torch.equal(ys[:, 1:-1], y[:, :-2])              # frame 15 of the shifted clip misses x[15]: excluded
     # db = column sums of gy: compare with a float64 reduction
     assert_close_scaled(db, gy.double().sum((0, 1, 2, 3)).float(), rel=1e-5, what="db")
+
+
+def test_unpatch_pad_matches_rearrange_then_pad(dev):
+    """PatchUnEmbedding.forward_padded (one strided copy: un-patchify + zero channel pad; the 1x1x1 down-projection through
+    zero-padded weight rows) == forward() followed by F.pad (reference train/layers.py:44-55): outputs and every gradient."""
+    import torch.nn.functional as F
+    import video_vae_amd as V
+    from video_vae_amd import layers as LY, optim
+    pu = LY.PatchUnEmbedding(32, 48, 3, 8, 4, V.Rngs(7)).to(dev)          # 12 feature channels -> padded to 16
+    optim.Optimizer(pu, 1e-3)                                            # bf16 shadows for the Linear layers
+    x = rnd((2, 3, 24, 192), 95).to(dev, torch.bfloat16)
+    g_feat = rnd((2, 3, 32, 48, 16), 96).to(dev, torch.bfloat16)
+    g_coarse = rnd((2, 3, 32, 48, 3), 97).to(dev, torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        xx = x.clone().requires_grad_(True)
+        pu.zero_grad()
+        if fused:
+            feat, coarse = pu.forward_padded(xx)
+        else:
+            feat, coarse = pu(xx)
+            feat = F.pad(feat, (0, 4))
+        assert feat.shape[-1] == 16 and float(feat[..., 12:].float().abs().max()) == 0
+        (feat.float() * g_feat.float()).sum().backward(retain_graph=True)
+        (coarse.float() * g_coarse.float()).sum().backward()
+        res.append([feat.detach(), coarse.detach(), xx.grad.clone()])
+    (f1, c1, gx1), (f0, c0, gx0) = res
+    assert torch.equal(f1, f0)
+    assert_close(c1, c0, rtol=1e-2, atol=1e-2, what="coarse")
+    assert_close_scaled(gx1, gx0, rel=2e-2, what="dx")

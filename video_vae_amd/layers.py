@@ -227,6 +227,28 @@ class PatchEmbedding(nn.Module):
         return self.linear(self.norm(x))
 
 
+class _UnpatchPad(torch.autograd.Function):
+    """"b t (h w) (p1 p2 c u) -> b t (h p1) (w p2) (c u)" (reference train/layers.py:48) into a buffer whose channel count is
+    rounded up to a multiple of 16, pad channels zero: one strided copy each way."""
+
+    @staticmethod
+    def forward(ctx, x, p, h, w, u, pad):
+        b, t = x.shape[:2]
+        cu = x.shape[-1] // (p * p)
+        src = rearrange(x, "b t (h w) (p1 p2 cu) -> b t (h p1) (w p2) cu", p1=p, p2=p, h=h, w=w)
+        out = torch.empty((b, t, h * p, w * p, cu + pad), dtype=x.dtype, device=x.device)
+        out[..., :cu].copy_(src)
+        out[..., cu:].zero_()
+        ctx.dims = (p, h, w, cu)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, h, w, cu = ctx.dims
+        gx = rearrange(g[..., :cu], "b t (h p1) (w p2) cu -> b t (h w) (p1 p2 cu)", p1=p, p2=p, h=h, w=w)
+        return gx.contiguous(), None, None, None, None, None
+
+
 class PatchUnEmbedding(nn.Module):
     """Reference train/layers.py:29-55 -> (conv features (b,t,H,W,c*u), coarse reconstruction (b,t,H,W,c))."""
 
@@ -238,6 +260,22 @@ class PatchUnEmbedding(nn.Module):
         self.upsample = Linear(d, d * upsample_rate, rngs, dtype, param_dtype)
         self.downsample = Linear(channels * upsample_rate, channels, rngs, dtype, param_dtype)
         self.linear = Linear(d, d, rngs, dtype, param_dtype)
+
+    def forward_padded(self, x):
+        """forward() for the decoder's bf16 GPU path: the features come back with their channels zero-padded to a multiple of 16
+        (what the UNet's matrix-core kernels want), written by ONE strided copy (un-patchify + pad) instead of a rearrange copy
+        followed by a pad copy, and the 1x1x1 down-projection reads the same buffer through zero-padded weight rows."""
+        p, u = self.patch_size, self.upsample_rate
+        cu = self.downsample.kernel.shape[0]
+        pad = (-cu) % 16
+        if not (x.is_cuda and self.upsample.dtype == torch.bfloat16 and self.upsample.kernel.dtype == torch.float32 and pad):
+            return None                                  # the caller falls back to forward()
+        x = self.upsample(self.linear(x))
+        feat = _UnpatchPad.apply(x, p, self.height // p, self.width // p, u, pad)
+        ds = self.downsample
+        kd = F.pad(ds.kernel, (0, 0, 0, pad))
+        coarse = ops.conv3d(feat.to(ds.dtype), kd.view(1, 1, 1, *kd.shape), ds.bias)
+        return feat, coarse
 
     def forward(self, x):
         x = self.upsample(self.linear(x))

@@ -82,7 +82,8 @@ class Decoder(nn.Module):
                 pend = r
             else:
                 x = r
-        feat, x = self.patch_unembedding(x)
+        out = self.patch_unembedding.forward_padded(x)              # bf16 GPU path: un-patchify + channel pad in one copy
+        feat, x = out if out is not None else self.patch_unembedding(x)
         return x + self.unet(feat)
 
 

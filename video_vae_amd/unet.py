@@ -132,13 +132,17 @@ class UNet(nn.Module):
 
     def forward(self, x):
         x = x.to(self.dtype)
-        c = x.shape[-1]
+        c = self.patch_mixer.kernel.shape[-2]
         pad = (-c) % 16 if (x.is_cuda and self.dtype == torch.bfloat16 and len(self.encoders) > 0) else 0
         k1 = None
         if pad:
             # bf16 MFMA kernels want channel counts in multiples of 16: run the mixer and the first encoder conv on
-            # zero-padded channels (zero weights in the pad rows/columns => identical results, grads sliced by autograd)
-            x = F.pad(x, (0, pad))
+            # zero-padded channels (zero weights in the pad rows/columns => identical results, grads sliced by autograd).
+            # A caller may hand the features over already padded (layers.PatchUnEmbedding.forward_padded).
+            if x.shape[-1] == c:
+                x = F.pad(x, (0, pad))
+            elif x.shape[-1] != c + pad:
+                raise ValueError(f"UNet expects {c} (or {c + pad} zero-padded) input channels, got {x.shape[-1]}")
             x = ops.conv3d(x, F.pad(self.patch_mixer.kernel, (0, pad, 0, pad)), F.pad(self.patch_mixer.bias, (0, pad)))
             k1 = F.pad(self.encoders[0].conv1.conv.kernel, (0, 0, 0, pad))
         else:
