@@ -58,6 +58,13 @@ int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, int Cin, in
 int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
                          int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
                          int prepacked, void* ws, size_t ws_bytes, void* stream);
+/* Forward Conv3d that also emits the GroupNorm statistics of its (rounded) output -- ConvBlock3D's conv + norm statistics in one
+   pass (reference train/unet.py:13-23).  vvae_conv3d_gn_blocks: rows per sample of the partial buffer (0 = layer not eligible,
+   use vvae_gn_stats); gn_part: N * blocks * groups * 2 floats, consumed by vvae_gn_finalize. */
+int vvae_conv3d_gn_blocks(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out, int groups);
+int vvae_conv3d_fwd_bf16_gn(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                            int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                            int prepacked, void* ws, size_t ws_bytes, float* gn_part, int groups, void* stream);
 size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw);
 int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
                            int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
@@ -80,6 +87,7 @@ int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, 
  *      sums: fp64 [N][G][2] (sum, sum of squares) produced by vvae_gn_stats; S = voxels per sample. ---- */
 size_t vvae_gn_part_floats(int N, long S, int C);   /* fp32 scratch floats for `part` below (per-workgroup partial sums) */
 int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, float* part, int dtype, void* stream);
+int vvae_gn_finalize(const float* part, int N, int nblk, int G, double* sums, void* stream);   /* second half of vvae_gn_stats for partials written by vvae_conv3d_fwd_bf16_gn */
 int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const double* sums, const float* gamma, const float* beta,
                      int N, long S, int C, int G, float eps, int dtype, void* stream);
 int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const double* sums,

@@ -939,3 +939,43 @@ def test_unpatch_pad_matches_rearrange_then_pad(dev):
     assert torch.equal(f1, f0)
     assert_close(c1, c0, rtol=1e-2, atol=1e-2, what="coarse")
     assert_close_scaled(gx1, gx0, rel=2e-2, what="dx")
+
+
+@pytest.mark.parametrize("ci,co,shape", [(16, 16, (2, 5, 20, 24)), (16, 32, (1, 4, 9, 33)), (32, 16, (2, 3, 17, 16)), (32, 32, (1, 6, 18, 30)),
+                                         (64, 32, (1, 2, 8, 16))])
+def test_conv_block_gn_statistics_from_conv_epilogue(dev, ci, co, shape):
+    """ConvBlock3D where the rolling conv kernel sums its own rounded outputs per GroupNorm group (no statistics pass over the
+    tensor) == the two-kernel form (vvae_gn_stats); (64, 32) is not eligible and must take the two-kernel form itself.
+    Reference train/unet.py:13-30."""
+    import video_vae_amd as V
+    from video_vae_amd import ops, unet as U
+    from video_vae_amd._lib import lib
+    blk = U.ConvBlock3D(ci, co, 3, V.Rngs(9)).to(dev)
+    with torch.no_grad():
+        blk.conv.bias.copy_(rnd((co,), 3, 0.2).to(dev)); blk.norm.scale.copy_((1 + rnd((co,), 4, 0.2)).to(dev)); blk.norm.bias.copy_(rnd((co,), 5, 0.2).to(dev))
+    n, t, h, w = shape
+    x = rnd((n, t, h, w, ci), 100).to(dev, torch.bfloat16)
+    gy = rnd((n, t, h, w, co), 101).to(dev, torch.bfloat16)
+    eligible = ops.conv3d_gn_blocks(x, blk.conv.kernel, blk.norm.num_groups)
+    assert (eligible > 0) == (ci <= 32)
+    # the fused partial sums against a direct fp64 reduction of the conv output
+    if eligible:
+        yc, part = ops.conv3d_fwd_gn_raw(x, blk.conv.kernel.detach(), blk.conv.bias.detach(), blk.norm.num_groups, eligible)
+        cpg = co // blk.norm.num_groups
+        ref = yc.double().reshape(n, -1, blk.norm.num_groups, cpg)
+        assert_close_scaled(part.double().sum(1)[..., 0], ref.sum((1, 3)), rel=1e-5, what="group sums")
+        assert_close_scaled(part.double().sum(1)[..., 1], (ref * ref).sum((1, 3)), rel=1e-5, what="group sums of squares")
+    res = []
+    for fused in (True, False):
+        try:
+            lib().vvae_conv3d_roll_config(1 if fused else 0, 0)
+            xx = x.clone().requires_grad_(True)
+            blk.zero_grad()
+            y = blk(xx)
+            y.backward(gy)
+            res.append([y.detach(), xx.grad] + [p.grad.clone() for p in blk.parameters()])
+        finally:
+            lib().vvae_conv3d_roll_config(1, 0)
+    for k, (a, b) in enumerate(zip(*res)):
+        assert_close_scaled(a, b, rel=2e-2 if k < 2 else 1e-3, what=f"tensor {k}")
+    assert float((res[0][0] != res[1][0]).float().mean()) < 0.02          # the statistics differ in fp32 summation order only

@@ -261,7 +261,9 @@ extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, in
 
 namespace {
 bool roll_enabled();
-int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s);
+int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s,
+                    float* gn_part = nullptr, int gn_groups = 0);
+int roll_gn_blocks_any(BfDims d, int kh, int groups);
 }
 
 // which: 0 fwd (K = Cin, produced = Cout), 1 dgrad (K = Cout, produced = Cin), 2 wgrad (ld_in = ldx, ld_out = lddy).
@@ -340,6 +342,37 @@ extern "C" int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, cons
     if (CO == 16) return launch_cfg<C333_k32_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
     if (CO == 32) return launch_cfg<C333_k32_o32>(xp, ldx, wp, bp, yp, ldy, d, s);
     return launch_cfg<C333_k32_o64>(xp, ldx, wp, bp, yp, ldy, d, s);
+}
+
+// Workgroups per sample of the rolling forward kernel for this layer = rows per sample of the GroupNorm partial buffer
+// vvae_conv3d_fwd_bf16_gn writes (part[N][blocks][groups][2] floats); 0: the layer does not take that path (use vvae_gn_stats).
+extern "C" int vvae_conv3d_gn_blocks(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out,
+                                     int groups)
+{
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || !vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ld_in, ld_out, 0, 0)) return 0;
+    if (Cin != chunk_of(Cin)) return 0;
+    BfDims d{N, T, H, W, Cin, Cout, 0, 0};
+    return roll_gn_blocks_any(d, kh, groups);
+}
+
+// vvae_conv3d_fwd_bf16 (forward only) that also emits the per-group sums of the rounded outputs, so the GroupNorm behind the
+// conv (reference train/unet.py:13-23) needs no statistics pass over the tensor: gn_part must hold
+// N * vvae_conv3d_gn_blocks(...) * groups * 2 floats and is consumed by vvae_gn_finalize.
+extern "C" int vvae_conv3d_fwd_bf16_gn(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                                       int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                                       int prepacked, void* ws, size_t ws_bytes, float* gn_part, int groups, void* stream)
+{
+    if (!x || (!w && !prepacked) || !y || !gn_part) return VVAE_ERR_BAD_ARG;
+    if (vvae_conv3d_gn_blocks(N, T, H, W, Cin, Cout, kt, kh, kw, ldx, ldy, groups) <= 0) return VVAE_ERR_BAD_ARG;
+    if (((uintptr_t)x % 16) || ((uintptr_t)y % 8) || ldx < Cin || ldy < Cout) return VVAE_ERR_BAD_ARG;
+    const size_t need = packed_bytes(Cin, Cout, kt, kh, kw);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
+    if (!prepacked) {
+        const int rc = vvae_conv3d_pack_bf16(w, ws, ws_bytes, Cin, Cout, kt, kh, kw, 0, stream);
+        if (rc) return rc;
+    }
+    BfDims d{N, T, H, W, Cin, Cout, 0, 0};
+    return launch_roll_any((const bf16_t*)x, ldx, (const uint4*)ws, bias, (bf16_t*)y, ldy, d, kh, (hipStream_t)stream, gn_part, groups);
 }
 
 namespace {
@@ -462,10 +495,12 @@ struct RollCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <class C>
+// GN: the workgroup also emits, per GroupNorm group, the sum and the sum of squares of the (bf16-rounded) outputs it wrote --
+// one row of the partial buffer gn_stats would have produced by re-reading the whole tensor: part[n][blk][group][2].
+template <class C, bool GN>
 __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wp,
                                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy,
-                                                                       BfDims d, int tchunk)
+                                                                       BfDims d, int tchunk, float* __restrict__ gn_part, int gn_groups)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CKB = C::CKB, KT = C::KT, KH = C::KH, KW = C::KW, MT_W = C::MT_W, NT_W = C::NT_W;
@@ -524,6 +559,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
     sx.fetch(x, ldx, n, t_beg + 1, hx, wx, d.T, d.H, d.W, tid);
     const int wo = w0 + r;
     const int lin_w = (wm * MT_W) * WR + r;                                // this lane's voxel in the wave's first halo row
+    float gs[GN ? NT_W : 1][4], gss[GN ? NT_W : 1][4];
+#pragma unroll
+    for (int i = 0; i < (GN ? NT_W : 1); ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[i][e] = 0.f; gss[i][e] = 0.f; }
     for (int tt = t_beg; tt < t_end; ++tt) {
         sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
         __syncthreads();
@@ -597,7 +637,46 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
                 o.x = (uint32_t)f2bf(acc[m][i][0] + bv[i][0]) | ((uint32_t)f2bf(acc[m][i][1] + bv[i][1]) << 16);
                 o.y = (uint32_t)f2bf(acc[m][i][2] + bv[i][2]) | ((uint32_t)f2bf(acc[m][i][3] + bv[i][3]) << 16);
                 *reinterpret_cast<uint2*>(y + v * ldy + (ct0 + i) * 16 + 4 * g) = o;
+                if (GN) {                                          // statistics of what GroupNorm will read: the rounded values
+                    const float q0 = __uint_as_float(o.x << 16), q1 = __uint_as_float(o.x & 0xffff0000u);
+                    const float q2 = __uint_as_float(o.y << 16), q3 = __uint_as_float(o.y & 0xffff0000u);
+                    gs[i][0] += q0; gs[i][1] += q1; gs[i][2] += q2; gs[i][3] += q3;
+                    gss[i][0] += q0 * q0; gss[i][1] += q1 * q1; gss[i][2] += q2 * q2; gss[i][3] += q3 * q3;
+                }
             }
+        }
+    }
+    if (GN) {
+        // fold: the 16 voxel lanes of a channel quad (xor-shuffles), then the WM waves that share the channels (LDS), then the
+        // channels of each group -- fixed order, no atomics
+        static_assert(!GN || C::CO_T * 16 * C::WM * 2 * 4 <= 4 * C::PLANE, "fold scratch fits the ring");
+        __syncthreads();                                           // every wave is done with the ring
+        float* red = reinterpret_cast<float*>(smem);               // [wm][channel][2]
+        const int CO = C::CO_BLK;
+#pragma unroll
+        for (int i = 0; i < NT_W; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = gs[i][e], b = gss[i][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (r == 0) {
+                    const int ch = (wn * NT_W + i) * 16 + 4 * g + e;
+                    red[(wm * CO + ch) * 2 + 0] = a;
+                    red[(wm * CO + ch) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < gn_groups) {
+            const int cpg = CO / gn_groups;
+            float a = 0.f, b = 0.f;
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c)
+#pragma unroll
+                for (int w2 = 0; w2 < C::WM; ++w2) { a += red[(w2 * CO + c) * 2]; b += red[(w2 * CO + c) * 2 + 1]; }
+            const long nblk = (long)d.tiles_h * d.tiles_w * nch;
+            const long blk = ((long)th * d.tiles_w + tw) * nch + tc;
+            float* pp = gn_part + ((n * nblk + blk) * gn_groups + tid) * 2;
+            pp[0] = a; pp[1] = b;
         }
     }
 }
@@ -607,7 +686,7 @@ int g_roll = 1, g_roll_tchunk = 0;
 bool roll_enabled() { return g_roll != 0; }
 
 template <class C>
-int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s)
+int roll_tchunk(BfDims& d)
 {
     d.tiles_h = ceil_div(d.H, C::TH);
     d.tiles_w = ceil_div(d.W, C::TW);
@@ -616,15 +695,32 @@ int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf
     int tchunk = d.T;                                                      // whole clip per workgroup unless that starves the chip
     while (tchunk > 2 && cols * ceil_div(d.T, tchunk) < want) tchunk = (tchunk + 1) / 2;
     if (g_roll_tchunk > 0) tchunk = g_roll_tchunk;
+    return tchunk;
+}
+
+// workgroups per sample = rows of the GroupNorm partial buffer per sample (0: this configuration cannot emit them)
+template <class C>
+int roll_gn_blocks(BfDims d, int groups)
+{
+    if (d.CO != C::CO_BLK || groups <= 0 || d.CO % groups || groups > C::NTHREADS) return 0;
+    const int tchunk = roll_tchunk<C>(d);
+    return d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk);
+}
+
+template <class C, bool GN>
+int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s,
+                float* gn_part = nullptr, int gn_groups = 0)
+{
+    const int tchunk = roll_tchunk<C>(d);
     dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk)), d.CO / C::CO_BLK);
-    auto k = conv3d_bf16_roll_kernel<C>;
+    auto k = conv3d_bf16_roll_kernel<C, GN>;
     static bool attr_done = false;
     if (C::LDS_BYTES > 65536 && !attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk);
+    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk, gn_part, gn_groups);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -636,10 +732,12 @@ typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false> R16_32;      // TH 8, one ou
 typedef RollCfg<32, 3, 3, 2, 1, 8, 1, W_REG, false> R32_16;      // TH 16, 8 waves
 typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false> R32_32;      // TH 16, 8 waves, one output-channel tile per wave
 
-#define ROLL(C) return launch_roll<C>(x, ldx, wp, bias, y, ldy, d, s)
-int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s)
+#define ROLL(C) do { if (gn_part) return launch_roll<C, true>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups); \
+                     return launch_roll<C, false>(x, ldx, wp, bias, y, ldy, d, s); } while (0)
+int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s,
+                    float* gn_part, int gn_groups)
 {
-    if (kh == 7) ROLL(R377);
+    if (kh == 7) { if (gn_part) return VVAE_ERR_BAD_ARG; return launch_roll<R377, false>(x, ldx, wp, bias, y, ldy, d, s); }
     if (d.CK == 16 && d.CO == 16) ROLL(R16_16);
     if (d.CK == 16 && d.CO == 32) ROLL(R16_32);
     if (d.CK == 32 && d.CO == 16) ROLL(R32_16);
@@ -647,6 +745,16 @@ int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias
     return VVAE_ERR_BAD_ARG;                                               // >= 64 output channels: the per-frame kernel is as fast
 }
 #undef ROLL
+
+int roll_gn_blocks_any(BfDims d, int kh, int groups)
+{
+    if (kh != 3 || !roll_enabled()) return 0;
+    if (d.CK == 16 && d.CO == 16) return roll_gn_blocks<R16_16>(d, groups);
+    if (d.CK == 16 && d.CO == 32) return roll_gn_blocks<R16_32>(d, groups);
+    if (d.CK == 32 && d.CO == 16) return roll_gn_blocks<R32_16>(d, groups);
+    if (d.CK == 32 && d.CO == 32) return roll_gn_blocks<R32_32>(d, groups);
+    return 0;
+}
 
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx,

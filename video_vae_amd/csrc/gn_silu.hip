@@ -349,6 +349,16 @@ extern "C" size_t vvae_gn_part_floats(int N, long S, int C)
     return (size_t)N * ceil_div(S, pick_vpb(S, N, 1024)) * C * 2;
 }
 
+// sums[n][g][2] (fp64) = fixed-order sum of the nblk partial rows part[n][blk][g][2] (fp32) -- the second half of vvae_gn_stats,
+// for partials that the producing convolution wrote itself (vvae_conv3d_fwd_bf16_gn).
+extern "C" int vvae_gn_finalize(const float* part, int N, int nblk, int G, double* sums, void* stream)
+{
+    if (!part || !sums || N <= 0 || nblk <= 0 || G <= 0 || G > 64) return VVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(2 * G, 32), N), dim3(256), 0, (hipStream_t)stream, part, sums, nblk, G);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
 // sums: fp64 [N][G][2], overwritten.  part: fp32 scratch, >= vvae_gn_part_floats(N, S, C) floats.
 extern "C" int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* sums, float* part, int dtype, void* stream)
 {

@@ -223,19 +223,56 @@ def conv3d_wgrad_raw(x, dy, kshape, want_bias=True, dw_out=None, db_out=None):
     return dw, db
 
 
+def conv3d_gn_blocks(x, kernel, groups):
+    """Rows per sample of the GroupNorm partial buffer the rolling forward kernel can emit for this layer; 0: not eligible."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16) or _FORCE_GENERIC[0] or groups <= 0:
+        return 0
+    n, t, h, w, cin = x.shape
+    kt, kh, kw, _, cout = kernel.shape
+    return lib().vvae_conv3d_gn_blocks(n, t, h, w, cin, cout, kt, kh, kw, x.stride(-2), cout, groups)
+
+
+def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk):
+    """conv3d_fwd_raw + the per-(sample, workgroup, group) sums of the rounded outputs: -> (y, part (n, nblk, groups, 2) fp32)."""
+    x, ldx = rows(x)
+    n, t, h, w, cin = x.shape
+    kt, kh, kw, _, cout = kernel.shape
+    out = torch.empty((n, t, h, w, cout), dtype=x.dtype, device=x.device)
+    part = torch.empty((n, nblk, groups, 2), dtype=torch.float32, device=x.device)
+    wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, 0)
+    ws, wsb = _ws(wsb, x.device)
+    vox = n * t * h * w
+    tag = f"conv3d_fwd {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
+    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+                  lambda: lib().vvae_conv3d_fwd_bf16_gn(_p(x), ldx, _p(kernel), _p(bias), _p(out), cout, n, t, h, w, cin, cout, kt, kh,
+                                                        kw, 0, _p(ws), wsb, _p(part), groups, _stream())), "vvae_conv3d_fwd_bf16_gn")
+    return out, part
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias):
+    def forward(ctx, x, kernel, bias, gn_groups=0, gn_blocks=0):
         k32 = _f32(kernel)
         b32 = _f32(bias) if bias is not None else None
         ctx.save_for_backward(x, k32)
         ctx.has_bias = bias is not None
         ctx.kdtype = kernel.dtype
         ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the gradient may be written directly
+        if gn_blocks:
+            y, part = conv3d_fwd_gn_raw(x, k32, b32, gn_groups, gn_blocks)
+            ctx.mark_non_differentiable(part)
+            ctx.with_part = True
+            return y, part
+        ctx.with_part = False
         return conv3d_fwd_raw(x, k32, b32)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpart=None):
+        dx, dw, db = _Conv3d._backward(ctx, dy)
+        return dx, dw, db, None, None
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, k32 = ctx.saved_tensors
         dy = dy.to(x.dtype)
         dx = conv3d_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
@@ -262,7 +299,18 @@ class _Conv3d(torch.autograd.Function):
 
 def conv3d(x, kernel, bias=None):
     """NDHWC Conv3d, SAME, stride 1 (nnx.Conv; reference train/unet.py:13-21)."""
-    return _Conv3d.apply(x, kernel, bias)
+    return _Conv3d.apply(x, kernel, bias, 0, 0)
+
+
+def conv3d_with_gn_stats(x, kernel, bias, groups):
+    """-> (conv3d(x), stats) where stats is None or (partial sums, rows per sample) for group_norm_silu(..., stats=...): on
+    the rolling bf16 kernel the conv's epilogue also sums its rounded outputs per GroupNorm group, so the norm behind it
+    (reference train/unet.py:13-23) skips its own statistics pass over the tensor."""
+    nblk = conv3d_gn_blocks(x, kernel, groups) if bias is not None else 0
+    if not nblk:
+        return _Conv3d.apply(x, kernel, bias, 0, 0), None
+    y, part = _Conv3d.apply(x, kernel, bias, groups, nblk)
+    return y, (part, nblk)
 
 
 # --------------------------------------------------------------------------------------------- GroupNorm + SiLU
@@ -305,9 +353,13 @@ def gn_silu_bwd_raw(x, dy, sums, scale, bias, groups, eps, out=None):
 
 class _GnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scale, bias, groups, eps, out=None):
+    def forward(ctx, x, scale, bias, groups, eps, out=None, part=None, nblk=0):
         s32, b32 = _f32(scale), _f32(bias)
-        sums = gn_stats_raw(x, groups)
+        if part is not None:                             # the producing conv already summed its outputs (conv3d_with_gn_stats)
+            sums = torch.empty((x.shape[0], groups, 2), dtype=torch.float64, device=x.device)
+            check(lib().vvae_gn_finalize(_p(part), x.shape[0], nblk, groups, _p(sums), _stream()), "vvae_gn_finalize")
+        else:
+            sums = gn_stats_raw(x, groups)
         ctx.save_for_backward(x, sums, s32, b32)
         ctx.groups, ctx.eps, ctx.pdtype = groups, eps, scale.dtype
         return gn_silu_fwd_raw(x, sums, s32, b32, groups, eps, out)
@@ -316,12 +368,14 @@ class _GnSilu(torch.autograd.Function):
     def backward(ctx, dy):
         x, sums, s32, b32 = ctx.saved_tensors
         dx, dg, db = gn_silu_bwd_raw(x, dy.to(x.dtype), sums, s32, b32, ctx.groups, ctx.eps)
-        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None, None
+        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None, None, None, None
 
 
-def group_norm_silu(x, scale, bias, groups, eps=1e-6, out=None):
+def group_norm_silu(x, scale, bias, groups, eps=1e-6, out=None, stats=None):
     """silu(GroupNorm(x)) over (t,h,w,C/G) per sample (reference train/unet.py:22-23,28-29).  ``out``: a channel slice of a
-    wider NDHWC buffer to write into (see join_channels)."""
+    wider NDHWC buffer to write into (see join_channels).  ``stats``: from conv3d_with_gn_stats."""
+    if stats is not None:
+        return _GnSilu.apply(x, scale, bias, groups, eps, out, stats[0], stats[1])
     return _GnSilu.apply(x, scale, bias, groups, eps, out)
 
 

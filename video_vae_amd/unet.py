@@ -65,8 +65,9 @@ class ConvBlock3D(nn.Module):
     def forward(self, x, kernel=None, out=None):
         # ``kernel``: optional stand-in for self.conv.kernel (UNet passes a zero-padded view for 16-channel alignment)
         # ``out``: channel slice of a wider buffer for the block's output (the skip half of a decoder's concat buffer)
-        x = ops.conv3d(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias)
-        return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out)
+        x, stats = ops.conv3d_with_gn_stats(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias,
+                                            self.norm.num_groups)
+        return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out, stats)
 
 
 class DownBlock3D(nn.Module):
