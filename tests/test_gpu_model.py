@@ -412,3 +412,22 @@ def test_unet_full_size_is_deterministic(dev):
         assert torch.isfinite(a.float()).all()
         assert torch.equal(a, b)
     assert float(runs[0][0].float().abs().max()) > 0 and float(runs[0][1].float().abs().max()) > 0
+
+
+def test_graphed_train_step_rl_flavour_captures(dev):
+    """The rl_model flavour (Bernoulli pairs + the trajectory-probability term, reference train/rl_nonadversarial.py:150-170)
+    must capture as a hipGraph too: its loss may not contain host read-backs (torch.prod's backward has one)."""
+    import video_vae_amd as V
+    from video_vae_amd import optim, loss as L, rl_model
+    from video_vae_amd.graph import GraphedTrainStep
+    torch.manual_seed(0)
+    m = rl_model.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **TINY).to(dev)
+    opt = optim.Optimizer(m, 1e-3)
+    video = torch.rand((2, 8, 32, 32, 3), device=dev).to(torch.bfloat16)
+    mask = torch.ones(2, 8, device=dev); mask[1, 6:] = 0
+    gstep = GraphedTrainStep(m, opt, video, mask, L.HPARAMS, 16, V.Rngs(3), warmup=1)
+    p0 = opt.p.clone()
+    for _ in range(2):
+        loss, aux = gstep()
+        assert torch.isfinite(loss) and torch.isfinite(aux["rl_loss"])
+    assert torch.isfinite(opt.p).all() and not torch.equal(opt.p, p0)

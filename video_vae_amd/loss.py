@@ -65,8 +65,11 @@ def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn
     rl_mask = rearrange(output_mask, "(b p) time -> b p time", p=2) > 0
     one = torch.ones((), device=probs.device, dtype=probs.dtype)
     probs = torch.where(rl_mask, probs, one)
-    raw_trajectory_probs = torch.where(rl_mask, raw_probs, one).prod(dim=2, keepdim=True)
-    probs = probs.prod(dim=2, keepdim=True)
+    raw_trajectory_probs = torch.where(rl_mask, raw_probs, one).detach().prod(dim=2, keepdim=True)      # logged only
+    # prod over time of factors that are all exactly 1.0 (x / stop_grad(x)): value 1, gradient sum_t d p_t -- written as
+    # 1 + sum(p - 1), which is the same number and the same gradient but needs no ProdBackward (its zero check reads a scalar
+    # back to the host, which a hipGraph capture of the step cannot contain)
+    probs = 1.0 + (probs - 1.0).sum(dim=2, keepdim=True)
     rl_loss = probs * rearrange(disadvantages, "b p -> b p 1").detach()
     loss = per_sample_loss.mean() + rl_loss.mean() * hparams["rl_loss_weight"]
     return loss, {
