@@ -267,7 +267,7 @@ def main():
                                "ms_per_step": round(v["total_ms"] / nsteps_timed, 3),
                                "GBps": round(v["bytes"] / v["avg_ms"] / 1e6, 1), "TFLOPps": round(v["flops"] / v["avg_ms"] / 1e9, 1)}
                               for k, v in rows]
-        conv = {k: v for k, v in summ.items() if k.startswith("conv3d")}
+        conv = {k: v for k, v in summ.items() if k.startswith(("conv3d", "convt"))}        # every conv-like launch of the UNet
         if conv:
             tot_ms = sum(v["total_ms"] for v in conv.values()) / nsteps_timed
             tot_b = sum(v["bytes"] * v["n"] for v in conv.values()) / nsteps_timed
