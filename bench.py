@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- video frames/sec (fwd+bwd+optimizer) of the video-VAE training step on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the
+driver's form) this process IS a rank.  Started bare (`python bench.py --gpus N`, WORLD_SIZE unset) it launches the ranks itself:
+a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` from a parent that never
+touches the GPU (no exec after a GPU call), relays rank 0's JSON line and exits non-zero if any rank failed -- the counterpart
+of the reference's self-initialising ranks (claude_distributed/distributed_train.py:79, distributed_run.sh:1-9).
 
 A "step" is one pass of the hot path over one synthetic batch: VideoVAE forward (Encoder -> reparameterise -> Decoder with
 the 3D-conv UNet), masked recon+KL loss, backward, clip-by-global-norm + Adam.  Workload at every N = BASELINE.json
@@ -21,6 +27,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+import socket  # noqa: E402
+import subprocess  # noqa: E402
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -107,14 +116,42 @@ def cpu_baseline(args):
                       f"1 step, {dt_s:.1f} s on {threads} threads (transformer trunk not included)"}
 
 
+def self_launch(n):
+    """Parent of a bare `bench.py --gpus N`: start N ranks under torch.distributed.run, relay rank 0's JSON line.
+
+    This process has not initialised the GPU (importing torch does not) and never will; the ranks are child processes."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:                                     # ranks' stderr passes straight through
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stdout.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        sys.exit(f"bench.py: a rank failed (torch.distributed.run exit code {rc})" if rc > 0 else f"bench.py: launcher killed by signal {-rc}")
+    if line is None:
+        sys.exit("bench.py: the ranks finished without printing a result line")
+    print(line, flush=True)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} (or bare, without WORLD_SIZE)")
     ddp_on = world > 1 or args.force_ddp     # --force-ddp: the whole process-group path with a single rank (RCCL rehearsal)
     if args.backend != "nccl":               # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (gloo transport)
         local %= torch.cuda.device_count()
@@ -219,6 +256,7 @@ def main():
             "metric": "video frames/sec (fwd+bwd) at Bx3x16x256x256", "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rccl_ranks": world if (ddp_on and args.backend == "nccl") else 0,
             "config": {"workload": ("C3: full VideoVAE (enc 9 / dec 12 FactoredAttention + 3D-conv UNet) train step, "
                                     if args.workload == "vae" else "Conv3d UNet stack alone (diagnostic), ")
                                    + f"B={B}/GPU x 3x{T}x{S}x{S}, {args.dtype} compute, fp32 params, recon+KL loss, clip+Adam",

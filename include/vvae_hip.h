@@ -12,7 +12,9 @@
  *     parameter gradients are always fp32 in Flax layout (Conv kernel (kt,kh,kw,Cin,Cout));
  *   - `stream` is a hipStream_t; everything is enqueued asynchronously on it, nothing synchronises;
  *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
- *   - no global mutable state except the vvae_conv3d_force_generic test hook.
+ *   - process-global mutable state is limited to five test / tuning hooks, none of which the product path calls:
+ *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config,
+ *     vvae_gemm_tn_use_big_tiles (each documented at its declaration); everything else is a pure function of its arguments.
  */
 #ifndef VVAE_HIP_H
 #define VVAE_HIP_H
@@ -187,14 +189,16 @@ int vvae_layernorm_bwd(const void* x, const void* dy, const float* gamma, const 
                        void* stream);
 
 /* ---- reparameterise + KL: train/model.py:124-128, train/rl_nonadversarial.py:146-147. ---- */
+size_t vvae_loss_part_floats(int B, long M);   /* fp32 scratch floats for `part` below (M = elements per sample): per-workgroup
+                                                  partial sums, folded in fixed order -- no float atomics, bitwise reproducible */
 int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, const float* mask, float* z, float* kl,
-                        int B, int T, long per, int dtype, void* stream);
+                        float* part, int B, int T, long per, int dtype, void* stream);
 int vvae_reparam_kl_bwd(const void* mean, const void* logvar, const float* eps, const float* mask, const float* dz,
                         const float* gkl, void* dmean, void* dlogvar, int B, int T, long per, int dtype, void* stream);
 
 /* ---- masked MSE / MAE: train/rl_nonadversarial.py:114-121.  video sample = b / video_div (pair doubling). ---- */
 int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* mask, float* mse, float* mae,
-                            int B, int T, long P, int video_div, int dtype, void* stream);
+                            float* part, int B, int T, long P, int video_div, int dtype, void* stream);
 int vvae_masked_mse_mae_bwd(const void* video, const void* recon, const float* mask, const float* gmse, const float* gmae,
                             void* drecon, int B, int T, long P, int video_div, int dtype, void* stream);
 
@@ -212,9 +216,14 @@ int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, const void* 
 int vvae_gemm_tn_use_big_tiles(int on);   /* test hook: 0 = 128x128 kernel for every shape */
 
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam) at train/rl_nonadversarial.py:248-251. ---- */
-int vvae_sqnorm_accum(const float* g, long n, double* out, void* stream);
-int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_sq,
-                        float gscale, float max_norm, float lr, float b1, float b2, float eps, long count, void* stream);
+/*      The global norm is reduced without atomics: vvae_sqnorm_partials writes vvae_sqnorm_blocks(n) fp64 partial sums of squares,
+ *      every workgroup of vvae_adam_clip_step folds them in one fixed order (so every rank of a data-parallel job, holding the
+ *      same all-reduced gradient, applies the bitwise-same clip factor) and the total lands in *gnorm_sq_out. */
+int vvae_sqnorm_blocks(long n);
+int vvae_sqnorm_partials(const float* g, long n, double* part, void* stream);
+int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_part, int nparts,
+                        double* gnorm_sq_out, float gscale, float max_norm, float lr, float b1, float b2, float eps, long count,
+                        void* stream);
 int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 /* ---- dense-layer GEMM, both operands K-contiguous: C (M,N) bf16 = epi(A (M,K) . B (N,K)^T + bias), fp32 accumulation.
  *      Linear forward (B = transposed bf16 weight shadow) and input gradient (B = the weight itself) of nnx.Linear at

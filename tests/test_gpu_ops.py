@@ -212,6 +212,8 @@ def test_temporal_attention_core(dev, a, t, heads, d, masked, dtype, generic):
     else:
         assert_close(yg, yo, rtol=3e-2, atol=3e-2, what="out")
         assert_close_scaled(xg.grad, xo.grad, rel=5e-2, what="dqkv")
+        assert_close_scaled(qsg.grad, qso.grad, rel=5e-2, what="dq_scale (bf16)")
+        assert_close_scaled(ksg.grad, kso.grad, rel=5e-2, what="dk_scale (bf16)")
 
 
 @pytest.mark.parametrize("a,s,heads,d", [(3, 256, 8, 64), (2, 100, 4, 32), (2, 40, 3, 16), (1, 70, 2, 8)])

@@ -1,0 +1,390 @@
+"""GPU parity above the single-op level for the kernels the benchmark actually runs ("next round" item 1).
+
+* production-shaped bf16 FactoredAttention blocks (C = 768, 8 heads x 64, MLP 1536, hw = 256, T = 16, masked tail) -- forward
+  and EVERY gradient against the CPU oracle: reaches tattn_*_fast<64>, sattn_*, gemm_nt's silu' epilogue, the deferred
+  gemm_tn256_grouped launch, add+LayerNorm at C = 768 and the pending/defer residual protocol;
+* bf16 UNet at C1 size: forward and every parameter gradient against the oracle's bf16 emulation (conv3d_bf16_roll / wgrad /
+  GroupNorm-statistics epilogue / ConvTranspose MFMA kernels);
+* loss-curve parity (north_star: "recon+KL loss curve matching the CPU reference"; property source
+  claude_distributed/test_training_loop.py:168-178): 20 optimizer steps on the GPU and on the oracle from the same weights,
+  batch and noise -- curves within 1e-3 relative;
+* configs C2 (B=4, 3x16x128x128, fp32) and C5 (B=2, 3x32x256x256, bf16) at full extent and full depth on one GPU.
+
+bf16 bar.  The oracle is evaluated twice on the CPU: in fp32 (``ref``) and with the reference's mixed-precision rules emulated
+(``emu``: inputs / kernels rounded to bf16, fp32 accumulation, result rounded -- SURVEY.md Appendix A.10).  The product's error
+against ``ref`` must stay within BF16_FACTOR x the emulation's own error against ``ref`` (+ BF16_FLOOR): the HIP path may round at
+different points than XLA would, it may not be less accurate than a faithful bf16 execution of the reference by more than that.
+"""
+import zlib
+
+import pytest
+import torch
+
+from oracle import layers as OL
+from oracle import loss as OLoss
+from oracle import model as OM
+from oracle import optim as OOpt
+from oracle import unet as OU
+from util import assert_close, assert_close_scaled, rnd
+
+pytestmark = pytest.mark.gpu
+
+BF16_FACTOR, BF16_FLOOR, BF16_ABS = 3.0, 2e-3, 6e-2
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def check_bf16(name, got, emu, ref, report, floor_scale=None):
+    """``got`` (GPU bf16 path) vs ``ref`` (fp32 oracle), priced against ``emu`` (oracle with bf16 emulation) vs ``ref``."""
+    if floor_scale is not None and float(ref.abs().max()) < 1e-6 * floor_scale:
+        # a gradient that is zero in exact arithmetic (conv bias in front of a GroupNorm): pure rounding noise on every path;
+        # bound it against the scale of the companion kernel gradient instead of against itself
+        assert float(got.detach().float().abs().max()) <= 5e-2 * floor_scale, name
+        return
+    e_got, e_emu = rel_l2(got, ref), rel_l2(emu, ref)
+    report.append((name, e_got, e_emu))
+    assert torch.isfinite(got.detach().float()).all(), name
+    assert e_got <= BF16_FACTOR * e_emu + BF16_FLOOR and e_got <= BF16_ABS, \
+        f"{name}: |gpu - fp32 oracle| / |oracle| = {e_got:.3e}, bf16-emulated oracle {e_emu:.3e} (allowed {BF16_FACTOR} x + {BF16_FLOOR})"
+
+
+def _load(module, params, dev):
+    sd = module.state_dict()
+    assert set(sd) == set(params), (set(sd) ^ set(params))
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(v)
+    return module.to(dev)
+
+
+def _perturb(p):
+    """Move biases / scales off their init values (zeros / ones) so that their gradients and their use are both exercised."""
+    for k in p:
+        if k.endswith("bias") or k.endswith("scale"):
+            p[k] = p[k] + 0.1 * rnd(p[k].shape, zlib.crc32(k.encode()) % 1000)
+    return p
+
+
+# ------------------------------------------------------------------------------------ production-shaped transformer blocks
+def test_factored_attention_production_shape_bf16_vs_oracle(dev):
+    """Two FactoredAttention(1536, 768, 8, 512, 64, 256) blocks chained through the pending/defer protocol on (1, 16, 256, 768)
+    with a masked tail, backward inside ops.deferred_wgrad (as train_step runs it): output, input gradient and all 2 x 36
+    parameter gradients vs the oracle (reference train/layers.py:131-224)."""
+    import video_vae_amd as V
+    from video_vae_amd import layers as LY, ops, optim
+
+    mlp, c, heads, qkvf, tmax, hw, t = 1536, 768, 8, 512, 64, 256, 16
+    gen = torch.Generator().manual_seed(11)
+    p = {}
+    for i in range(2):
+        OL.init_factored_attention(p, f"layers.{i}", mlp, c, heads, qkvf, gen)
+    _perturb(p)
+    # the reference initialises the out-projection / second MLP layer at 1e-2 scale; keep that, but give the branches enough
+    # weight that an error in them is visible next to the residual stream
+    x = rnd((1, t, hw, c), 50, 1.0)
+    gy = rnd((1, t, hw, c), 51, 1.0)
+    mask_bt = torch.ones(1, t)
+    mask_bt[0, 12:] = 0
+    emask = OLoss.expand_mask(mask_bt.bool(), hw)
+
+    def oracle(dtype):
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        xo = x.clone().requires_grad_(True)
+        y = xo
+        for i in range(2):
+            y = OL.factored_attention(OU.sub(po, f"layers.{i}"), y, emask, heads, tmax, hw, dtype)
+        y.backward(gy)
+        return y.detach(), xo.grad, {k: v.grad for k, v in po.items()}
+    y_ref, dx_ref, g_ref = oracle(torch.float32)
+    y_emu, dx_emu, g_emu = oracle(torch.bfloat16)
+
+    class Stack(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            r = V.Rngs(0)
+            self.layers = torch.nn.ModuleList([LY.FactoredAttention(mlp, c, heads, qkvf, tmax, hw, r) for _ in range(2)])
+
+        def forward(self, x, mask):
+            pend = self.layers[0](x, mask, pending=None, defer=True)
+            return self.layers[1](None, mask, pending=pend, defer=False)
+
+    m = _load(Stack(), p, dev)
+    opt = optim.Optimizer(m, 1e-3)
+    xg = x.to(dev, torch.bfloat16).requires_grad_(True)
+    names = []
+    orig = ops._launch
+
+    def spy(tag, *a):
+        names.append(tag)
+        return orig(tag, *a)
+    ops._launch = spy
+    try:
+        opt.zero_grad()
+        yg = m(xg, emask.to(dev))
+        with ops.deferred_wgrad(opt):
+            yg.backward(gy.to(dev, torch.bfloat16))
+        for b in range(len(opt.buckets)):
+            if not opt.landed[b]:
+                opt._land(b)
+    finally:
+        ops._launch = orig
+    torch.cuda.synchronize()
+    # the production instantiations were the ones that ran
+    seen = " | ".join(sorted(set(names)))
+    for must in ("temporal_attn_fwd T16 D64", "temporal_attn_bwd T16 D64", "spatial_attn_fwd S256 D64", "spatial_attn_bwd S256 D64",
+                 "gemm_tn_grouped", "add_layernorm_fwd C768", "layernorm_bwd C768+skip"):
+        assert must in seen, (must, seen)
+    report = []
+    check_bf16("out", yg, y_emu, y_ref, report)
+    check_bf16("dx", xg.grad, dx_emu, dx_ref, report)
+    grads = dict(zip(opt.names, opt.gviews))
+    assert set(grads) == set(g_ref)
+    for k in sorted(g_ref):
+        check_bf16("d" + k, grads[k], g_emu[k], g_ref[k], report)
+    worst = sorted(report, key=lambda r: -r[1] / (BF16_FACTOR * r[2] + BF16_FLOOR))[:5]
+    print("\nworst (name, gpu vs fp32, emulation vs fp32):", [(n, f"{a:.2e}", f"{b:.2e}") for n, a, b in worst])
+
+
+# ------------------------------------------------------------------------------------ bf16 UNet, forward and every gradient
+def test_unet_bf16_fwd_and_param_grads_vs_emulated_oracle(dev):
+    """C1-sized UNet (B=1, 8 x 64 x 64 x 12 features, 3 levels, base 16) in bf16: output, input gradient and every parameter
+    gradient (reference train/unet.py:155-188)."""
+    import video_vae_amd as V
+    p = _perturb(OU.init_unet(12, 16, 3, 3, seed=5, zero_final=False))
+    x = rnd((1, 8, 64, 64, 12), 40, 0.5)
+    gy = rnd((1, 8, 64, 64, 3), 41)
+
+    def oracle(dtype):
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        xo = x.clone().requires_grad_(True)
+        y = OU.unet(po, xo, dtype)
+        y.backward(gy)
+        return y.detach(), xo.grad, {k: v.grad for k, v in po.items()}
+    y_ref, dx_ref, g_ref = oracle(torch.float32)
+    y_emu, dx_emu, g_emu = oracle(torch.bfloat16)
+    m = _load(V.UNet(12, 16, 3, 3, V.Rngs(0), dtype=torch.bfloat16), p, dev)
+    xg = x.to(dev, torch.bfloat16).requires_grad_(True)
+    yg = m(xg)
+    assert yg.dtype == torch.bfloat16
+    yg.backward(gy.to(dev, torch.bfloat16))
+    report = []
+    check_bf16("out", yg, y_emu, y_ref, report)
+    check_bf16("dx", xg.grad, dx_emu, dx_ref, report)
+    for k, prm in m.named_parameters():
+        floor = float(g_ref[k[:-4] + "kernel"].abs().max()) if k.endswith("conv.bias") else None
+        check_bf16("d" + k, prm.grad, g_emu[k], g_ref[k], report, floor_scale=floor)
+    worst = sorted(report, key=lambda r: -r[1] / (BF16_FACTOR * r[2] + BF16_FLOOR))[:5]
+    print("\nworst (name, gpu vs fp32, emulation vs fp32):", [(n, f"{a:.2e}", f"{b:.2e}") for n, a, b in worst])
+
+
+# ------------------------------------------------------------------------------------ loss-curve parity (row N1)
+TINY = dict(height=32, width=32, channels=3, patch_size=8, encoder_depth=1, decoder_depth=1, mlp_dim=64, num_heads=4,
+            qkv_features=32, max_temporal_len=8, spatial_compression_rate=4, unembedding_upsample_rate=4)
+
+
+def _step_noise(cfg, b, t, step, flavour):
+    """Injected noise for one step.  The gates are hard thresholds (round(sigmoid(logits + logit(u))) / u < p), so the uniform
+    draws come from two values far from any threshold the slowly moving logits can reach within 20 steps: a last-bit difference
+    between the two implementations cannot flip a frame (a discrete O(1) change that is not a parity question)."""
+    g = torch.Generator().manual_seed(1000 + step)
+    n = {"reparam_eps": torch.randn((b, t, cfg.hw, cfg.latent_dim), generator=g)}
+    if flavour == "model":
+        keep = torch.rand((b, t, 1), generator=g) < 0.6
+        keep[:, 0] = True
+        n["gumbel_u"] = torch.where(keep, torch.full((), 0.9), torch.full((), 0.02))
+    else:
+        keep = torch.rand((2 * b, t, 1, 1), generator=g) < 0.6
+        keep[0::2, 0] = True                      # the two members of a pair always differ in frame 0: their losses differ by a
+        keep[1::2, 0] = False                     # real amount and (loss - mean) / (std + 1e-6) is well conditioned
+        n["bernoulli_u"] = torch.where(keep, torch.full((), 0.01), torch.full((), 0.995))
+    return n
+
+
+@pytest.mark.parametrize("flavour", ["model", "rl"])
+def test_loss_curve_matches_cpu_oracle(dev, flavour):
+    """20 train steps (fwd + bwd + clip_by_global_norm + Adam, lr 1e-3 as claude_distributed/test_training_loop.py:71) of the tiny
+    VAE in fp32 on the GPU and on the CPU oracle from the same weights, the same fixed batch and the same per-step noise: the
+    two loss curves (total, MSE, KL) agree within 1e-3 relative at every step, and the loss goes down."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, optim, rl_model
+    cfg = OM.VAEConfig(**TINY)
+    p0 = OM.init_video_vae(cfg, seed=3, zero_final=False)
+    b, t, steps, lr = 2, 8, 20, 1e-3
+    video = torch.rand((b, t, 32, 32, 3), generator=torch.Generator().manual_seed(0))
+    mask = torch.ones(b, t)
+    mask[1, 6:] = 0
+    emask = OLoss.expand_mask(mask.bool(), cfg.hw)
+    # ---- CPU oracle
+    po = {k: v.clone() for k, v in p0.items()}
+    adam = OOpt.Adam(po)
+    curve_o = []
+    for s in range(steps):
+        noise = _step_noise(cfg, b, t, s, flavour)
+        pr = {k: v.clone().requires_grad_(True) for k, v in po.items()}
+        if flavour == "model":
+            loss, aux = OLoss.loss_fn_plain(OM.video_vae(pr, cfg, video, emask, noise), video, mask)
+        else:
+            loss, aux = OLoss.loss_fn_rl(OM.video_vae_rl(pr, cfg, video, emask, noise), video, mask)
+        loss.backward()
+        grads = {k: v.grad for k, v in pr.items()}
+        clipped, _gn = OOpt.clip_by_global_norm(grads, 1.0)
+        po = adam.update(po, clipped, lr)
+        curve_o.append((float(loss), float(aux["MSE"]), float(aux["kl_loss"])))
+    # ---- GPU product
+    cls = V.VideoVAE if flavour == "model" else rl_model.VideoVAE
+    m = _load(cls(rngs=V.Rngs(2), dtype=torch.float32, **TINY), p0, dev)
+    opt = optim.Optimizer(m, lr)
+    rngs = V.Rngs(3)
+    vg, mg = video.to(dev), mask.to(dev)
+    curve_g = []
+    for s in range(steps):
+        for k, v in _step_noise(cfg, b, t, s, flavour).items():
+            rngs.inject(k, v)
+        loss, aux = L.train_step(m, opt, vg, mg, L.HPARAMS, cfg.hw, rngs)
+        curve_g.append((float(loss), float(aux["MSE"]), float(aux["kl_loss"])))
+    for s, (g, o) in enumerate(zip(curve_g, curve_o)):
+        for name, a, c in zip(("loss", "MSE", "kl_loss"), g, o):
+            assert abs(a - c) <= 1e-3 * abs(c) + 1e-7, f"step {s} {name}: gpu {a:.7g} vs oracle {c:.7g}"
+    first, last = sum(c[1] for c in curve_g[:5]) / 5, sum(c[1] for c in curve_g[-5:]) / 5
+    assert last < first, curve_g
+    # the trained weights agree too (conv biases in front of a GroupNorm have exactly-zero true gradients: Adam turns their
+    # rounding noise into +-lr steps of random sign on either side, they do not influence the output and are left out)
+    for k, prm in m.named_parameters():
+        if k.endswith("conv.bias") and "final_conv" not in k and "patch_mixer" not in k:
+            continue
+        assert_close(prm, po[k], rtol=2e-2, atol=20 * lr * 0.05, what=f"after {steps} steps: {k}")
+
+
+def test_eval_step_is_loss_with_train_true_and_no_grad(dev):
+    """eval_step calls the loss with train=True on purpose (reference train/rl_nonadversarial.py:200-208) and records no graph."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, rl_model
+    cfg = OM.VAEConfig(**TINY)
+    m = rl_model.VideoVAE(rngs=V.Rngs(2), dtype=torch.float32, **TINY).to(dev)
+    video = torch.rand((2, 8, 32, 32, 3), device=dev)
+    mask = torch.ones(2, 8, device=dev)
+    noise = _step_noise(cfg, 2, 8, 0, "rl")
+    r1, r2 = V.Rngs(1), V.Rngs(1)
+    for k, v in noise.items():
+        r1.inject(k, v); r2.inject(k, v)
+    loss_e, aux_e = L.eval_step(m, video, mask, L.HPARAMS, cfg.hw, r1)
+    assert not loss_e.requires_grad and set(aux_e) == {"MSE", "perceptual_loss", "selection_loss", "kl_loss", "reconstruction",
+                                                      "kept_frame_density", "mean_trajectory_prob", "rl_loss", "per_sample_MAE"}
+    loss_t, _ = L.loss_fn(m, video, L.expand_mask(mask, cfg.hw), mask, r2, L.HPARAMS, train=True)
+    assert torch.equal(loss_e, loss_t.detach())
+    # train=True means the reparameterisation noise is applied: with a different eps the loss changes
+    r3 = V.Rngs(1)
+    r3.inject("bernoulli_u", noise["bernoulli_u"])
+    r3.inject("reparam_eps", noise["reparam_eps"] + 1.0)
+    loss_n, _ = L.eval_step(m, video, mask, L.HPARAMS, cfg.hw, r3)
+    assert not torch.equal(loss_n, loss_e)
+
+
+# ------------------------------------------------------------------------------------ configs C2 and C5 at full extent
+PROD = dict(channels=3, patch_size=16, encoder_depth=9, decoder_depth=12, mlp_dim=1536, num_heads=8, qkv_features=512,
+            max_temporal_len=64, spatial_compression_rate=8, unembedding_upsample_rate=4)
+
+
+def _nonzero_final(m, dev):
+    with torch.no_grad():
+        fc = m.decoder.unet.final_conv
+        fc.kernel.copy_(rnd(tuple(fc.kernel.shape), 5, 0.2).to(dev))
+
+
+def test_c2_full_depth_fp32_128(dev):
+    """Config C2: the full production-depth VAE (enc 9 / dec 12 + UNet) in fp32 at 128 x 128.
+    (a) B=1, T=4: reconstruction, loss terms and a spread of parameter gradients against the CPU oracle (the CPU side is ~0.3
+        TFLOP); (b) B=4, T=16 (the config's full extent): one train step, finite loss and gradients, parameters move."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, optim
+    kw = dict(PROD, height=128, width=128)
+    cfg = OM.VAEConfig(**kw)
+    p = OM.init_video_vae(cfg, seed=3, zero_final=False)
+    b, t = 1, 4
+    g = torch.Generator().manual_seed(0)
+    video = torch.rand((b, t, 128, 128, 3), generator=g)
+    mask = torch.ones(b, t)
+    mask[0, 3:] = 0
+    noise = {"gumbel_u": torch.where(torch.rand((b, t, 1), generator=g) < 0.6, torch.full((), 0.9), torch.full((), 0.02)),
+             "reparam_eps": torch.randn((b, t, cfg.hw, cfg.latent_dim), generator=g)}
+    emask = OLoss.expand_mask(mask.bool(), cfg.hw)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss_o, aux_o = OLoss.loss_fn_plain(OM.video_vae(po, cfg, video, emask, noise), video, mask)
+    loss_o.backward()
+    m = _load(V.VideoVAE(rngs=V.Rngs(2), dtype=torch.float32, **kw), p, dev)
+    rngs = V.Rngs(3)
+    for k, v in noise.items():
+        rngs.inject(k, v)
+    vg, mg = video.to(dev), mask.to(dev)
+    loss_g, aux_g = L.loss_fn_plain(m, vg, L.expand_mask(mg.bool(), cfg.hw), mg, rngs, L.HPARAMS)
+    loss_g.backward()
+    assert_close(aux_g["reconstruction"], aux_o["reconstruction"], what="reconstruction (21 blocks + UNet, fp32)")
+    for k in ("MSE", "kl_loss", "selection_loss", "kept_frame_density"):
+        assert_close(aux_g[k], aux_o[k], rtol=1e-3, atol=1e-5, what=k)
+    assert_close(loss_g, loss_o, rtol=1e-3, atol=1e-5, what="loss")
+    names = [k for k, _ in m.named_parameters()]
+    picked = names[::max(1, len(names) // 60)]
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+        if k in picked and not k.endswith("conv.bias"):
+            assert_close_scaled(prm.grad, po[k].grad, rel=1e-2, what=f"d{k}")
+    del po, loss_o, aux_o, loss_g, aux_g
+    # (b) full extent of the config
+    opt = optim.Optimizer(m, 1e-4)
+    p_before = opt.p.clone()
+    video4 = torch.rand((4, 16, 128, 128, 3), generator=g).to(dev)
+    mask4 = torch.ones(4, 16, device=dev)
+    mask4[3, 11:] = 0
+    loss, aux = L.train_step(m, opt, video4, mask4, L.HPARAMS, cfg.hw, V.Rngs(4))
+    assert torch.isfinite(loss) and torch.isfinite(opt.g).all() and torch.isfinite(opt.p).all()
+    assert float(opt.g.abs().max()) > 0 and not torch.equal(opt.p, p_before)
+    assert aux["reconstruction"].shape == (4, 16, 128, 128, 3)
+
+
+def test_c5_full_model_bf16_t32(dev):
+    """Config C5 on one GPU: B=2 clips of 3x32x256x256, bf16, production depth, temporal attention over T=32 with a masked tail.
+    Finite loss / gradients; two passes from the same state are bitwise identical (loss and the whole flat gradient buffer);
+    and masking the last 8 frames equals truncating the clip to 24 frames through the WHOLE encoder (reference property
+    train/scratch.py:46-57 lifted from one attention call to 9 blocks)."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, ops, optim
+    kw = dict(PROD, height=256, width=256)
+    torch.manual_seed(0)
+    m = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **kw).to(dev)
+    _nonzero_final(m, dev)
+    opt = optim.Optimizer(m, 1e-4)
+    hw = 256
+    g = torch.Generator().manual_seed(1)
+    video = torch.rand((2, 32, 256, 256, 3), generator=g).to(dev, torch.bfloat16)
+    mask = torch.ones(2, 32, device=dev)
+    mask[1, 24:] = 0
+    noise = {"gumbel_u": torch.rand((2, 32, 1), generator=g).to(dev),
+             "reparam_eps": torch.randn((2, 32, hw, 96), generator=g).to(dev)}
+    runs = []
+    for _ in range(2):
+        rngs = V.Rngs(3)
+        for k, v in noise.items():
+            rngs.inject(k, v)
+        opt.zero_grad()
+        loss, aux = L.loss_fn_plain(m, video, L.expand_mask(mask, hw), mask, rngs, L.HPARAMS)
+        with ops.deferred_wgrad(opt):
+            loss.backward()
+        for b in range(len(opt.buckets)):
+            if not opt.landed[b]:
+                opt._land(b)
+        runs.append((loss.detach().clone(), opt.g.clone()))
+    assert torch.isfinite(runs[0][0]) and torch.isfinite(runs[0][1]).all() and float(runs[0][1].abs().max()) > 0
+    assert torch.equal(runs[0][0], runs[1][0]), "loss not bitwise reproducible"
+    nbad = int((runs[0][1] != runs[1][1]).sum())
+    assert nbad == 0, f"flat gradient not bitwise reproducible: {nbad} of {runs[0][1].numel()} elements differ"
+    del runs
+    # masked == truncated through the encoder (sample 1 has 24 real frames)
+    with torch.no_grad():
+        enc = m.encoder
+        mean_m, lv_m, _ = enc._trunk(video[1:2], L.expand_mask(mask[1:2], hw))
+        mean_t, lv_t, _ = enc._trunk(video[1:2, :24].contiguous(), L.expand_mask(mask[1:2, :24], hw))
+    assert_close_scaled(mean_m[:, :24], mean_t, rel=4e-2, what="encoder mean, masked vs truncated")
+    assert_close_scaled(lv_m[:, :24], lv_t, rel=4e-2, what="encoder log-variance, masked vs truncated")

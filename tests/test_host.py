@@ -1,6 +1,7 @@
 """CPU: host logic of the product package -- C-ABI surface, Rngs stand-in, schedule, gradient bucketing, and the
 world_size=2 gloo rehearsal of the data-parallel reducer.  No HIP compute is called here (there is no GPU)."""
 import ctypes
+import json
 import math
 import os
 import socket
@@ -198,3 +199,111 @@ def test_ddp_gloo_world2(tmp_path):
         assert torch.allclose(r0[f"g{step}"], want, rtol=1e-5, atol=1e-7)
         with torch.no_grad():
             opt.p.add_(want, alpha=-0.05 / 2)
+
+
+def _adam_standin(opt, lr_fn):
+    """What the fused HIP clip+Adam kernel does to (p, m, v, count), in torch ops (CPU stand-in for the resume test)."""
+    lr = lr_fn(opt.count)
+    opt.count += 1
+    with torch.no_grad():
+        opt.m.mul_(0.9).add_(opt.g, alpha=0.1)
+        opt.v.mul_(0.999).addcmul_(opt.g, opt.g, value=0.001)
+        c1, c2 = 1 - 0.9 ** opt.count, 1 - 0.999 ** opt.count
+        opt.p.sub_(lr * (opt.m / c1) / ((opt.v / c2).sqrt() + 1e-8))
+
+
+def _resume_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        import video_vae_amd as V
+        from video_vae_amd import optim, ddp
+        torch.set_num_threads(1)
+        sched = optim.warmup_cosine_decay_schedule(0.0, 1e-2, 10, 100, 1e-3)
+        ck = os.path.join(out, "ck")
+        if rank == 0:                                   # a run that took 3 updates and checkpointed
+            m0 = _toy()
+            o0 = optim.Optimizer(m0, sched, bucket_bytes=256, bf16_shadow=False)
+            g = torch.Generator().manual_seed(7)
+            for _ in range(3):
+                o0.zero_grad()
+                m0(torch.randn((5, 6), generator=g)).square().mean().backward()
+                for b in range(len(o0.buckets)):
+                    if not o0.landed[b]:
+                        o0._land(b)
+                _adam_standin(o0, sched)
+            V.save_checkpoint(m0, o0, ck)
+        dist.barrier()
+        # resume as video_vae_amd/train.py does: fresh model on every rank, rank 0 restores, state is broadcast
+        torch.manual_seed(100 + rank)
+        m = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+        opt = optim.Optimizer(m, sched, bucket_bytes=256, bf16_shadow=False)
+        red = ddp.GradReducer(opt)
+        if rank == 0:
+            V.load_checkpoint(m, opt, ck)
+        red.broadcast_state(0)
+        res = {"count0": opt.count, "p0": opt.p.clone(), "m0": opt.m.clone(), "v0": opt.v.clone()}
+        x = torch.randn((5, 6), generator=torch.Generator().manual_seed(200 + rank))
+        opt.zero_grad()
+        m(x).square().mean().backward()
+        for b in range(len(opt.buckets)):
+            if not opt.landed[b]:
+                opt._land(b)
+        red.finish()
+        with torch.no_grad():
+            opt.g.div_(world)
+        _adam_standin(opt, sched)
+        res.update(count1=opt.count, p1=opt.p.clone(), m1=opt.m.clone(), v1=opt.v.clone())
+        torch.save(res, os.path.join(out, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_resume_broadcasts_optimizer_state(tmp_path):
+    """Multi-rank resume: rank 0 restores the checkpoint, parameters AND Adam moments AND the update count are broadcast
+    (reference claude_distributed/distributed_train.py:321-341 broadcasts {"model", "optimizer"}); after the next update the
+    replicas are bit-identical.  With parameters only, rank 1 would restart at count 0 (lr = schedule(0) = 0, zero moments)."""
+    port = _free_port()
+    mp.spawn(_resume_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["count0"] == 3 and r1["count0"] == 3
+    assert float(r0["m0"].abs().max()) > 0 and float(r0["v0"].abs().max()) > 0
+    for k in ("p0", "m0", "v0", "p1", "m1", "v1"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert r0["count1"] == 4 and r1["count1"] == 4
+    assert not torch.equal(r0["p0"], r0["p1"])
+
+
+def test_bench_self_launch_relays_rank0_line(tmp_path):
+    """`bench.py --gpus N` started bare (no WORLD_SIZE) must start the ranks itself: here the launcher half is exercised with a
+    stand-in rank script (no GPU): the parent relays the one JSON line and propagates a failing rank's exit code."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text(
+        "import os, sys, json\n"
+        "r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "if '--fail' in sys.argv and r == 1: sys.exit(3)\n"
+        "if r == 0: print(json.dumps({'metric': 'm', 'n_gpus': w, 'argv': sys.argv[1:]}))\n")
+    drv = tmp_path / "drv.py"
+    drv.write_text(
+        "import sys, importlib.util\n"
+        f"spec = importlib.util.spec_from_file_location('bench_mod', {os.path.join(ROOT, 'bench.py')!r})\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        f"b.__file__ = {str(fake)!r}\n"
+        "b.self_launch(2)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    ok = subprocess.run([sys.executable, str(drv), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = [l for l in ok.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    rec = json.loads(line[0])
+    assert rec["n_gpus"] == 2 and rec["argv"] == ["--gpus", "2", "--steps", "1"]
+    bad = subprocess.run([sys.executable, str(drv), "--gpus", "2", "--fail"], capture_output=True, text=True, env=env, timeout=300)
+    assert bad.returncode != 0 and "rank failed" in bad.stderr

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Which kernel is not bitwise reproducible when two processes share one GPU?  
+
+    python tools/nondet_probe.py [--procs 2] [--passes 40]
+
+Every process builds the Linear + LayerNorm stack of tests/test_gpu_model.py::_linear_stack, runs forward + backward
+(inside ops.deferred_wgrad) ``passes`` times on the SAME input and records a bitwise checksum of every intermediate in
+execution order: Linear outputs (library GEMM + bias), LayerNorm outputs (layernorm_fwd_kernel), gradient of every
+LayerNorm output (tanh backward, framework), of every Linear output (layernorm_bwd_kernel), of every Linear input
+(library GEMM), and the flat-buffer slots (gemm_tn256_grouped_kernel, fold_rows_grouped_kernel).  Pass k is compared with
+pass 0; the first tensor that differs, whose inputs did not, names the kernel.  Prints one JSON line per process.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PRODUCER = {"lin_out": "library GEMM (torch.addmm)", "ln_out": "layernorm_fwd_kernel", "d_ln_out": "framework tanh backward",
+            "d_lin_out": "layernorm_bwd_kernel", "d_lin_in": "library GEMM (torch.mm dgrad)",
+            "g_kernel": "gemm_tn256_grouped_kernel", "g_bias": "gemm_tn256_grouped_kernel (db row)",
+            "g_ln": "layernorm_bwd_kernel partials + fold_rows_grouped_kernel"}
+
+
+def checksum(t):
+    t = t.detach()
+    v = t.contiguous().view(torch.int16 if t.element_size() == 2 else torch.int32)
+    return v.to(torch.int64).sum()
+
+
+def stack():
+    import video_vae_amd as V
+    from video_vae_amd import layers as LY
+
+    class Stack(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            r = V.Rngs(0)
+            dims = [768, 1536, 768, 1536, 512, 768, 1536, 768, 1536, 768, 768, 1536, 1536, 768, 768, 1536, 1536, 768]
+            self.lins = torch.nn.ModuleList([LY.Linear(a, b, r) for a, b in zip(dims[:-1], dims[1:])])
+            self.norms = torch.nn.ModuleList([LY.LayerNorm(b) for b in dims[1:]])
+
+        def forward(self, x, rec):
+            for i, (lin, nrm) in enumerate(zip(self.lins, self.norms)):
+                x.register_hook(lambda g, i=i: rec(f"d_lin_in[{i}]", g))
+                x = lin(x)
+                rec(f"lin_out[{i}]", x)
+                x.register_hook(lambda g, i=i: rec(f"d_lin_out[{i}]", g))
+                x = nrm(x)
+                rec(f"ln_out[{i}]", x)
+                x.register_hook(lambda g, i=i: rec(f"d_ln_out[{i}]", g))
+                x = torch.tanh(x)
+            return x
+    return Stack()
+
+
+def worker(rank, args, out_dir):
+    from video_vae_amd import ops, optim
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = stack().to(dev)
+    opt = optim.Optimizer(m, 1e-3, bucket_bytes=8 << 20)
+    g = torch.Generator().manual_seed(20 + rank)
+    x = torch.randn((args.rows, 768), generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    gy = torch.randn((args.rows, 768), generator=torch.Generator().manual_seed(8)).to(dev, torch.bfloat16)
+    runs = []
+    for _ in range(args.passes):
+        names, sums = [], []
+
+        def rec(name, t):
+            names.append(name)
+            sums.append(checksum(t))
+        opt.zero_grad()
+        y = m(x, rec)
+        with ops.deferred_wgrad(opt):
+            y.backward(gy)
+        for b in range(len(opt.buckets)):
+            if not opt.landed[b]:
+                opt._land(b)
+        for n, gv in zip(opt.names, opt.gviews):
+            kind = "g_kernel" if n.endswith("kernel") else "g_bias" if n.startswith("lins") else "g_ln"
+            rec(f"{kind}:{n}", gv)
+        runs.append((names, torch.stack(sums)))
+    torch.cuda.synchronize()
+    names0, s0 = runs[0][0], runs[0][1].cpu()
+    report = {"rank": rank, "procs": args.procs, "passes": args.passes, "rows": args.rows, "tensors_per_pass": len(names0), "mismatching_passes": 0,
+              "first_differing": {}}
+    for k in range(1, args.passes):
+        names, s = runs[k][0], runs[k][1].cpu()
+        if names != names0:                       # hook order may differ between passes: compare by name, report in pass-0 order
+            assert sorted(names) == sorted(names0), (set(names) ^ set(names0))
+            pos = {n: i for i, n in enumerate(names)}
+            s = s[torch.tensor([pos[n] for n in names0])]
+            report["reordered_passes"] = report.get("reordered_passes", 0) + 1
+        bad = (s != s0).nonzero().flatten().tolist()
+        if bad:
+            report["mismatching_passes"] += 1
+            first = names0[bad[0]]
+            key = first.split("[")[0].split(":")[0]
+            e = report["first_differing"].setdefault(first, {"count": 0, "producer": PRODUCER.get(key, "?"), "n_differing_tensors": []})
+            e["count"] += 1
+            e["n_differing_tensors"].append(len(bad))
+    with open(os.path.join(out_dir, f"nondet_r{rank}.json"), "w") as f:
+        json.dump(report, f)
+    print(json.dumps(report), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--procs", type=int, default=2)
+    ap.add_argument("--passes", type=int, default=40)
+    ap.add_argument("--rows", type=int, default=1024)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    if args.procs == 1:
+        worker(0, args, args.out)
+        return
+    import torch.multiprocessing as mp
+    mp.spawn(worker, args=(args, args.out), nprocs=args.procs, join=True)
+
+
+if __name__ == "__main__":
+    main()

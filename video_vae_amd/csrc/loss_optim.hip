@@ -5,7 +5,8 @@
 // MSE/MAE : mean_{h,w,c}[ sum_t ((v - r) m_t)^2 / len ], |.| too   rl_nonadversarial.py:114-121
 // optimiser: optax.chain(clip_by_global_norm(1.0), adam(...))      rl_nonadversarial.py:248-251
 //
-// One read of each operand; per-sample sums go wave-shuffle -> LDS -> one fp32 atomic per block.
+// One read of each operand; per-sample sums go wave-shuffle -> LDS -> one partial per workgroup, folded in fixed order by a
+// second tiny kernel (no float atomics: every loss term and the gradient norm are bitwise reproducible run to run and rank to rank).
 #include "common.hpp"
 
 namespace {
@@ -31,9 +32,10 @@ __device__ __forceinline__ float seq_len(const float* __restrict__ mrow, int T) 
 template <typename T_>
 __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const T_* __restrict__ mean, const T_* __restrict__ logvar,
                                                              const float* __restrict__ eps, const float* __restrict__ mask,
-                                                             float* __restrict__ z, float* __restrict__ kl, int T, long per,
+                                                             float* __restrict__ z, float* __restrict__ kl_part, int T, long per,
                                                              int elems_per_block)
 {
+    float* kl = kl_part;
     __shared__ float red[4];
     const int b = blockIdx.y;
     const long M = (long)T * per;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const T_* __restric
         const float t = block_sum(acc, red);
         if (threadIdx.x == 0) {
             const float len = mrow ? seq_len(mrow, T) : (float)T;
-            atomicAdd(kl + b, t / (len * (float)M));
+            kl_part[(long)b * gridDim.x + blockIdx.x] = t / (len * (float)M);
         }
     }
 }
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const T_* __restric
 // grid (chunks, B).  P = h*w*c elements per frame.  video sample index = b / video_div (pair doubling).
 template <typename T_, int VEC>
 __global__ __launch_bounds__(256) void masked_mse_mae_fwd_kernel(const T_* __restrict__ video, const T_* __restrict__ recon,
-                                                                 const float* __restrict__ mask, float* __restrict__ mse,
-                                                                 float* __restrict__ mae, int T, long P, int video_div,
+                                                                 const float* __restrict__ mask, float* __restrict__ mse_part,
+                                                                 float* __restrict__ mae_part, int T, long P, int video_div,
                                                                  int elems_per_block)
 {
     __shared__ float red[4];
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(256) void masked_mse_mae_fwd_kernel(const T_* __res
     const float t1 = block_sum(a1, red);
     if (threadIdx.x == 0) {
         const float sc = 1.f / (seq_len(mrow, T) * (float)P);
-        atomicAdd(mse + b, t2 * sc);
-        atomicAdd(mae + b, t1 * sc);
+        mse_part[(long)b * gridDim.x + blockIdx.x] = t2 * sc;
+        mae_part[(long)b * gridDim.x + blockIdx.x] = t1 * sc;
     }
 }
 
@@ -158,8 +160,22 @@ __global__ __launch_bounds__(256) void masked_mse_mae_bwd_kernel(const T_* __res
     }
 }
 
+// out[b] = sum_c part[b][c], c in fixed order (lane-strided, then the wave's shuffle tree): the second half of the per-sample
+// loss reductions above.  grid B, one wave.
+__global__ __launch_bounds__(64) void sum_chunks_kernel(const float* __restrict__ part, int nchunks, float* __restrict__ out)
+{
+    const float* row = part + (long)blockIdx.x * nchunks;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < nchunks; c += 64) acc += row[c];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------- optimiser
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out)
+constexpr int SQN_MAX_BLOCKS = 1024;
+
+// part[blockIdx] = sum of squares of this workgroup's grid-stride share, fixed order (no atomics).
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ part)
 {
     __shared__ float red[4];
     float acc = 0.f;
@@ -171,19 +187,33 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     }
     if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) { const float t = g[n4 * 4 + threadIdx.x]; acc += t * t; }
     const float t = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, (double)t);
+    if (threadIdx.x == 0) part[blockIdx.x] = (double)t;
 }
 
 // p, m, v updated in place; optional bf16 shadow copy of p.  gscale: grads are multiplied by gscale first (1/world).
-// clip: g *= max_norm/||g|| only if ||g|| >= max_norm, with ||g|| = gscale*sqrt(*gnorm_sq)  (optax semantics).
+// clip: g *= max_norm/||g|| only if ||g|| >= max_norm, with ||g|| = gscale*sqrt(sum of gnorm_part)  (optax semantics).
+// Every workgroup folds the <= 1024 partial sums of squares itself, in one fixed order (8 KB out of L2), so all of them -- and all
+// ranks of a data-parallel job, which hold the same all-reduced gradient -- apply the bitwise-same clip factor.
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n,
-                                                        const double* __restrict__ gnorm_sq, float gscale, float max_norm, float lr,
+                                                        const double* __restrict__ gnorm_part, int nparts,
+                                                        double* __restrict__ gnorm_sq_out, float gscale, float max_norm, float lr,
                                                         float b1, float b2, float eps, float c1, float c2)
 {
     float clip = gscale;
-    if (gnorm_sq) {
-        const float gn = gscale * (float)sqrt(*gnorm_sq);
+    if (gnorm_part) {
+        __shared__ double dred[256];
+        double a = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 256) a += gnorm_part[i];
+        dred[threadIdx.x] = a;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) dred[threadIdx.x] += dred[threadIdx.x + st];
+            __syncthreads();
+        }
+        const double tot = dred[0];
+        if (gnorm_sq_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_sq_out = tot;
+        const float gn = gscale * (float)sqrt(tot);
         if (gn >= max_norm) clip = gscale * max_norm / gn;
     }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -211,22 +241,30 @@ inline int pick_epb(long M, int B) {
 
 }  // namespace
 
-// mean/logvar (B, T, per) in `dtype`; eps, z fp32; mask fp32 (B,T) or NULL; kl fp32 [B] overwritten.  z or kl may be NULL.
-extern "C" int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, const float* mask, float* z, float* kl,
-                                   int B, int T, long per, int dtype, void* stream)
+// fp32 scratch floats the per-sample loss reductions below need for their per-workgroup partials (M = elements per sample).
+extern "C" size_t vvae_loss_part_floats(int B, long M)
 {
-    if (!mean || !logvar || (!z && !kl) || (z && !eps) || B <= 0 || T <= 0 || per <= 0) return VVAE_ERR_BAD_ARG;
+    if (B <= 0 || M <= 0) return 0;
+    return (size_t)2 * B * ceil_div(M, (long)pick_epb(M, B));
+}
+
+// mean/logvar (B, T, per) in `dtype`; eps, z fp32; mask fp32 (B,T) or NULL; kl fp32 [B] overwritten.  z or kl may be NULL.
+// part: vvae_loss_part_floats(B, T * per) floats of scratch (needed when kl != NULL).
+extern "C" int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, const float* mask, float* z, float* kl,
+                                   float* part, int B, int T, long per, int dtype, void* stream)
+{
+    if (!mean || !logvar || (!z && !kl) || (z && !eps) || (kl && !part) || B <= 0 || T <= 0 || per <= 0) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (kl && (e = vvae_zero_async(kl, sizeof(float) * B, s)) != hipSuccess) return (int)e;
     const long M = (long)T * per;
     const int epb = pick_epb(M, B);
     dim3 grid(ceil_div(M, epb), B);
+    float* klp = kl ? part : nullptr;
     if (dtype == VVAE_DT_F32)
-        hipLaunchKernelGGL((reparam_kl_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)mean, (const float*)logvar, eps, mask, z, kl, T, per, epb);
+        hipLaunchKernelGGL((reparam_kl_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)mean, (const float*)logvar, eps, mask, z, klp, T, per, epb);
     else if (dtype == VVAE_DT_BF16)
-        hipLaunchKernelGGL((reparam_kl_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)mean, (const bf16_t*)logvar, eps, mask, z, kl, T, per, epb);
+        hipLaunchKernelGGL((reparam_kl_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)mean, (const bf16_t*)logvar, eps, mask, z, klp, T, per, epb);
     else return VVAE_ERR_BAD_ARG;
+    if (kl) hipLaunchKernelGGL(sum_chunks_kernel, dim3(B), dim3(64), 0, s, part, (int)grid.x, kl);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -250,17 +288,17 @@ extern "C" int vvae_reparam_kl_bwd(const void* mean, const void* logvar, const f
 }
 
 // video (B/video_div, T, P), recon (B, T, P) in `dtype`; mask fp32 (B,T); mse, mae fp32 [B] overwritten.
-extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* mask, float* mse, float* mae,
-                                       int B, int T, long P, int video_div, int dtype, void* stream)
+// part: vvae_loss_part_floats(B, T * P) floats of scratch.
+extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* mask, float* mse_out, float* mae_out,
+                                       float* part, int B, int T, long P, int video_div, int dtype, void* stream)
 {
-    if (!video || !recon || !mask || !mse || !mae || B <= 0 || T <= 0 || P <= 0 || video_div <= 0) return VVAE_ERR_BAD_ARG;
+    if (!video || !recon || !mask || !mse_out || !mae_out || !part || B <= 0 || T <= 0 || P <= 0 || video_div <= 0) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if ((e = vvae_zero_async(mse, sizeof(float) * B, s)) != hipSuccess) return (int)e;
-    if ((e = vvae_zero_async(mae, sizeof(float) * B, s)) != hipSuccess) return (int)e;
     const long M = (long)T * P;
     const int epb = pick_epb(M, B);
     dim3 grid(ceil_div(M, epb), B);
+    float* mse = part;
+    float* mae = part + (size_t)B * grid.x;
     const bool al = ((uintptr_t)video % 16) == 0 && ((uintptr_t)recon % 16) == 0;
     if (dtype == VVAE_DT_F32) {
         if (al && M % 4 == 0) hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)video, (const float*)recon, mask, mse, mae, T, P, video_div, epb);
@@ -269,6 +307,8 @@ extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, con
         if (al && M % 8 == 0) hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
         else hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
     } else return VVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(B), dim3(64), 0, s, mse, (int)grid.x, mse_out);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(B), dim3(64), 0, s, mae, (int)grid.x, mae_out);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -294,25 +334,34 @@ extern "C" int vvae_masked_mse_mae_bwd(const void* video, const void* recon, con
     return 0;
 }
 
-// *out (fp64, device) += sum g[i]^2.  Caller zeroes *out once, then calls this per flat gradient buffer.
-extern "C" int vvae_sqnorm_accum(const float* g, long n, double* out, void* stream)
+// Number of fp64 partials vvae_sqnorm_partials writes for a buffer of n floats (<= 1024).
+extern "C" int vvae_sqnorm_blocks(long n)
 {
-    if (!g || !out || n <= 0 || ((uintptr_t)g % 16) != 0) return VVAE_ERR_BAD_ARG;
-    long blocks = n / 1024 + 1; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    if (n <= 0) return 0;
+    long blocks = n / 1024 + 1; if (blocks > SQN_MAX_BLOCKS) blocks = SQN_MAX_BLOCKS;
+    return (int)blocks;
+}
+
+// part[0 .. vvae_sqnorm_blocks(n)) (fp64, device) = per-workgroup sums of g[i]^2, each in a fixed order; vvae_adam_clip_step folds them.
+extern "C" int vvae_sqnorm_partials(const float* g, long n, double* part, void* stream)
+{
+    if (!g || !part || n <= 0 || ((uintptr_t)g % 16) != 0) return VVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)vvae_sqnorm_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, n, part);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
 
-// One optimizer.update over a flat fp32 buffer.  gnorm_sq: device fp64 (sum of squares of the *unscaled* grads) or NULL (no clip).
-extern "C" int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_sq,
-                                   float gscale, float max_norm, float lr, float b1, float b2, float eps, long count, void* stream)
+// One optimizer.update over a flat fp32 buffer.  gnorm_part: nparts device fp64 partial sums of squares of the *unscaled* grads
+// (vvae_sqnorm_partials) or NULL (no clip); gnorm_sq_out: device fp64 that receives their sum (for logging), or NULL.
+extern "C" int vvae_adam_clip_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const double* gnorm_part,
+                                   int nparts, double* gnorm_sq_out, float gscale, float max_norm, float lr, float b1, float b2,
+                                   float eps, long count, void* stream)
 {
-    if (!p || !g || !m || !v || n <= 0 || count < 1) return VVAE_ERR_BAD_ARG;
+    if (!p || !g || !m || !v || n <= 0 || count < 1 || (gnorm_part && (nparts <= 0 || nparts > SQN_MAX_BLOCKS))) return VVAE_ERR_BAD_ARG;
     const float c1 = 1.f - powf(b1, (float)count), c2 = 1.f - powf(b2, (float)count);
     long blocks = n / 1024 + 1; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n,
-                       gnorm_sq, gscale, max_norm, lr, b1, b2, eps, c1, c2);
+                       gnorm_part, nparts, gnorm_sq_out, gscale, max_norm, lr, b1, b2, eps, c1, c2);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

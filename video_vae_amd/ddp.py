@@ -48,15 +48,26 @@ class GradReducer:
             torch.cuda.synchronize()
         self.handles = []
 
-    def broadcast_parameters(self, src=0):
-        """Replicate rank ``src``'s parameters (the reference's device_put(state, P()) / resume broadcast,
-        distributed_train.py:339,378-380)."""
-        if self.opt.p.is_cuda:
+    def broadcast_state(self, src=0):
+        """Replicate rank ``src``'s parameters AND optimizer state -- Adam moments and the update count that indexes the
+        learning-rate schedule and the bias correction -- the reference's resume broadcast of {"model", "optimizer"}
+        (claude_distributed/distributed_train.py:321-341) and its device_put(state, P()) at start-up (:378-380).  Without the
+        moments and the count, ranks other than ``src`` would apply a different update from the first step after a resume."""
+        opt = self.opt
+        cuda = opt.p.is_cuda
+        if cuda:
             torch.cuda.synchronize()          # one-time setup: no reliance on the transport's ordering against in-flight work
-        dist.broadcast(self.opt.p, src=src, group=self.group)
-        if self.opt.p.is_cuda:
+        count = torch.tensor([opt.count], dtype=torch.int64, device=opt.p.device)
+        for t in (opt.p, opt.m, opt.v, count):
+            dist.broadcast(t, src=src, group=self.group)
+        if cuda:
             torch.cuda.synchronize()
-        self.opt.refresh_shadow()
+        opt.count = int(count.item())
+        opt.refresh_shadow()
+
+    def broadcast_parameters(self, src=0):
+        """Kept name: replicates the whole training state (see broadcast_state)."""
+        self.broadcast_state(src)
 
 
 def all_reduce_mean_scalars(values, process_group=None):

@@ -9,12 +9,22 @@ the graph only removes launch overhead.
 
 What the capture needs and how it gets it:
   * static inputs: ``video`` / ``mask`` are copied into fixed buffers before each replay;
-  * stochastic ops: ``Rngs.draw`` is pointed at fixed noise buffers (its injection hook) that are refilled by the default
-    CUDA generator before each replay, so every step still sees fresh noise of the right distribution;
+  * stochastic ops: ``Rngs.draw`` is pointed at fixed noise buffers (its injection hook) that are refilled before each replay
+    from a device generator seeded from ``rngs.seed`` (per-rank under data parallelism: the driver builds ``Rngs(3 + rank)``),
+    so every step still sees fresh noise of the right distribution and ranks draw different noise, as in eager mode;
   * no collective inside a graph: with a ``GradReducer`` attached the step is captured as TWO graphs cut at the output of the
     encoder's last block -- (forward + decoder backward) and (encoder backward).  The buckets that hold only decoder-side gradients are
     handed to the reducer between the two replays, so their all-reduce (RCCL's own stream) runs under the encoder's backward;
     the remaining buckets follow after the second replay.  Without a reducer one graph holds the whole pass.
+  * streams: capture happens on a private stream (autograd's stream bookkeeping needs one that nothing else has used), but the
+    graphs are REPLAYED on the caller's current stream, on purpose: the input copies, the noise refill, the eager clip+Adam and --
+    the part that matters next to RCCL -- the collectives all order themselves against the current stream (ProcessGroupNCCL makes
+    its internal stream wait on an event recorded on the current stream when ``all_reduce`` is called, and ``work.wait()`` makes
+    the current stream wait for the collective).  A replay on the capture stream would need hand-written event edges to and
+    from RCCL's stream for every bucket; on the current stream the framework's own edges are the correct ones.
+  * discovery, warm-up and capture run real optimizer updates (they exercise the eager half of the step); the parameters, Adam
+    moments and update count are snapshotted before and restored after, so constructing a GraphedTrainStep does not advance
+    training: step 0 of the run starts from the weights the caller built (or resumed) and schedule(count) is unchanged.
 """
 import gc
 
@@ -119,7 +129,7 @@ class GraphedTrainStep:
 
     def _refill(self):
         for name, (kind, buf) in self.noise.items():
-            buf.normal_() if kind == "normal" else buf.uniform_()
+            buf.normal_(generator=self.gen) if kind == "normal" else buf.uniform_(generator=self.gen)
 
     def _capture(self, warmup):
         opt = self.opt
@@ -130,6 +140,11 @@ class GraphedTrainStep:
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         gc.collect()
+        # per-rank noise stream for the static buffers (eager mode draws from Rngs(seed) keys; same distributions here)
+        self.gen = torch.Generator(device=self.video.device)
+        self.gen.manual_seed((0x9E3779B97F4A7C15 * (self.rngs.seed + 1)) & 0x7FFFFFFFFFFFFFFF)
+        # the passes below apply real updates: keep the training state they start from and put it back afterwards
+        snap = (opt.p.clone(), opt.m.clone(), opt.v.clone(), opt.count)
         with torch.cuda.stream(self.stream):
             # 1. discover the stochastic draws of one step and pin them to static buffers
             opt.defer_reduce = True           # collectives are issued by _prelaunch / Optimizer.update, never by the landing
@@ -170,7 +185,11 @@ class GraphedTrainStep:
         if not all(opt.landed):
             raise RuntimeError("a gradient bucket did not land inside the captured backward (parameter without gradient)")
         self.graph = g
-        opt.update()                      # the captured pass produced real gradients: apply them
+        opt.update()                      # the captured pass produced real gradients and left buckets to reduce: run the eager half once
+        with torch.no_grad():             # ... then put the training state back where the caller left it
+            opt.p.copy_(snap[0]); opt.m.copy_(snap[1]); opt.v.copy_(snap[2])
+        opt.count = snap[3]
+        opt.refresh_shadow()
 
     def __call__(self, video=None, mask=None):
         if video is not None:

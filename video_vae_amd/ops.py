@@ -845,6 +845,11 @@ def spatial_attention_core(qkv, q_scale, k_scale, cos, sin, heads, eps=1e-6):
 
 
 # --------------------------------------------------------------------------------------------- reparameterise + KL
+def _loss_part(b, m, device):
+    """Scratch for the per-workgroup partial sums of a per-sample loss reduction (folded in fixed order: no float atomics)."""
+    return torch.empty((lib().vvae_loss_part_floats(b, m),), dtype=torch.float32, device=device)
+
+
 class _ReparamKl(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean, logvar, eps, mask, want_z, want_kl):
@@ -855,8 +860,9 @@ class _ReparamKl(torch.autograd.Function):
         kl = torch.empty((b,), dtype=torch.float32, device=mean.device) if want_kl else None
         eps = eps.to(torch.float32).contiguous() if eps is not None else None
         mask = mask.to(torch.float32).contiguous() if mask is not None else None
-        check(lib().vvae_reparam_kl_fwd(_p(mean), _p(logvar), _p(eps), _p(mask), _p(z), _p(kl), b, t, per, _dt(mean), _stream()),
-              "vvae_reparam_kl_fwd")
+        part = _loss_part(b, t * per, mean.device) if want_kl else None
+        check(lib().vvae_reparam_kl_fwd(_p(mean), _p(logvar), _p(eps), _p(mask), _p(z), _p(kl), _p(part), b, t, per, _dt(mean),
+                                        _stream()), "vvae_reparam_kl_fwd")
         ctx.save_for_backward(mean, logvar, eps, mask)
         ctx.flags = (want_z, want_kl)
         outs = tuple(o for o in (z, kl) if o is not None)
@@ -906,8 +912,9 @@ class _MaskedMseMae(torch.autograd.Function):
         assert video.shape[0] * video_div == b and video.shape[1:] == recon.shape[1:]
         mse = torch.empty((b,), dtype=torch.float32, device=recon.device)
         mae = torch.empty((b,), dtype=torch.float32, device=recon.device)
-        check(lib().vvae_masked_mse_mae_fwd(_p(video), _p(recon), _p(mask), _p(mse), _p(mae), b, t, p, video_div, _dt(recon),
-                                            _stream()), "vvae_masked_mse_mae_fwd")
+        part = _loss_part(b, t * p, recon.device)
+        check(lib().vvae_masked_mse_mae_fwd(_p(video), _p(recon), _p(mask), _p(mse), _p(mae), _p(part), b, t, p, video_div,
+                                            _dt(recon), _stream()), "vvae_masked_mse_mae_fwd")
         ctx.save_for_backward(video, recon, mask)
         ctx.video_div = video_div
         return mse, mae

@@ -78,6 +78,7 @@ class Optimizer:
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.gnorm_part = torch.zeros(max(1, lib().vvae_sqnorm_blocks(off)) if dev.type == "cuda" else 1, dtype=torch.float64, device=dev)
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if bf16_shadow else None
         self.gviews = []
         for p, o in zip(self.params, self.offsets):
@@ -245,12 +246,13 @@ class Optimizer:
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         lr = float(self.schedule(self.count))
         self.count += 1
-        self.gnorm_sq.zero_()
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
-        check(lib().vvae_sqnorm_accum(vp(self.g), self.numel, vp(self.gnorm_sq), s), "vvae_sqnorm_accum")
+        # global norm without atomics: per-workgroup partial sums of squares, folded in one fixed order inside the Adam kernel
+        check(lib().vvae_sqnorm_partials(vp(self.g), self.numel, vp(self.gnorm_part), s), "vvae_sqnorm_partials")
         check(lib().vvae_adam_clip_step(vp(self.p), vp(self.g), vp(self.m), vp(self.v),
-                                        vp(self.shadow) if self.shadow is not None else None, self.numel, vp(self.gnorm_sq),
-                                        gscale, self.max_norm, lr, self.b1, self.b2, self.eps, self.count, s),
+                                        vp(self.shadow) if self.shadow is not None else None, self.numel, vp(self.gnorm_part),
+                                        self.gnorm_part.numel(), vp(self.gnorm_sq), gscale, self.max_norm, lr, self.b1, self.b2,
+                                        self.eps, self.count, s),
               "vvae_adam_clip_step")
         self.last_lr = lr
         return lr

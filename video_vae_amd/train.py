@@ -81,7 +81,9 @@ def main():
             V.load_checkpoint(model, opt, args.model_path)
         hparams["max_compression_rate"] = 100000                  # rl_nonadversarial.py:265-268
     if red is not None:
-        red.broadcast_parameters(0)                               # replicate (and resume: rank-0 restore + broadcast)
+        # replicate rank 0's parameters, Adam moments and update count (start-up and resume: rank-0 restore + broadcast of
+        # {"model", "optimizer"}, claude_distributed/distributed_train.py:321-341,378-380)
+        red.broadcast_state(0)
     if rank == 0:
         print(f"Trainable Parameters: {sum(p.numel() for p in model.parameters()) / 1e6} Million", flush=True)
 
