@@ -71,6 +71,9 @@ def parse():
                     help="nccl = RCCL over xGMI (the measured configuration); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-graph", action="store_true",
                     help="run the timed steps eagerly (default: forward+backward replayed from a captured hipGraph)")
+    ap.add_argument("--with-input-pipeline", action="store_true",
+                    help="feed every timed step from the host input pipeline (video_vae_amd/data.py: worker processes -> pinned uint8 "
+                         "-> H2D on a side stream) instead of a batch resident in HBM; the line reports the same metric")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per clip of the bounded CPU sample")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips of the bounded CPU sample (4 x 16 frames = one GPU batch)")
     return ap.parse_args()
@@ -196,8 +199,28 @@ def main():
         mask = torch.ones((B, T), device=dev)
         hw = (S // cfg["patch_size"]) ** 2
 
+        feed = None
+        if args.with_input_pipeline:
+            # every step's batch comes off disk through worker processes, pinned uint8 staging and an H2D copy on a side stream
+            import tempfile
+            from video_vae_amd import data as D
+            clip_dir = tempfile.mkdtemp(prefix=f"vvae_bench_clips_r{rank}_")
+            D.write_synthetic_clips(clip_dir, max(48, 4 * B), T + 4, S + 32, S + 32, seed=rank)
+            workers = max(2, min(8, (os.cpu_count() or 8) // max(1, world)))
+            host = D.create_batched_dataloader(clip_dir, batch_size=B, max_frames=T, resize=(S, S), crop_size=S, shuffle=True, seed=0,
+                                               num_workers=workers, prefetch_size=4 * workers, drop_remainder=True, rank=rank,
+                                               num_epochs=None, as_uint8=True)
+            feed = D.DevicePrefetcher(host, dev, dtype=dtype)
+
+        def batch():
+            if feed is None:
+                return video, mask
+            b = next(feed)
+            return b["video"], b["mask"]
+
         def eager_step():
-            loss, _aux = L.train_step(model, opt, video, mask, L.HPARAMS, hw, rngs)
+            v, m = batch()
+            loss, _aux = L.train_step(model, opt, v, m, L.HPARAMS, hw, rngs)
             return loss
 
         step, mode = eager_step, "eager"
@@ -207,7 +230,7 @@ def main():
                 gstep = GraphedTrainStep(model, opt, video, mask, L.HPARAMS, hw, rngs, split=True if args.split_graph else None)
 
                 def step():
-                    loss, _aux = gstep()
+                    loss, _aux = gstep(*batch()) if feed is not None else gstep()
                     return loss
                 mode = ("2 hipgraphs (fwd + decoder bwd | encoder bwd), decoder all-reduce under the second" if gstep.graph2 is not None
                         else "hipgraph(fwd+bwd)") + " + eager all-reduce/clip/Adam"
@@ -255,7 +278,9 @@ def main():
         out = {
             "metric": "video frames/sec (fwd+bwd) at Bx3x16x256x256", "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" if not args.with_input_pipeline else
+                    "synthetic clips on disk through the host input pipeline (worker processes -> pinned uint8 -> H2D on a side stream)",
             "rccl_ranks": world if (ddp_on and args.backend == "nccl") else 0,
             "config": {"workload": ("C3: full VideoVAE (enc 9 / dec 12 FactoredAttention + 3D-conv UNet) train step, "
                                     if args.workload == "vae" else "Conv3d UNet stack alone (diagnostic), ")

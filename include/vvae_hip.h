@@ -12,9 +12,9 @@
  *     parameter gradients are always fp32 in Flax layout (Conv kernel (kt,kh,kw,Cin,Cout));
  *   - `stream` is a hipStream_t; everything is enqueued asynchronously on it, nothing synchronises;
  *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
- *   - process-global mutable state is limited to five test / tuning hooks, none of which the product path calls:
+ *   - process-global mutable state is limited to six test / tuning hooks, none of which the product path calls:
  *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config,
- *     vvae_gemm_tn_use_big_tiles (each documented at its declaration); everything else is a pure function of its arguments.
+ *     vvae_layernorm_fwd_mode, vvae_gemm_tn_use_big_tiles (each documented at its declaration); everything else is a pure function of its arguments.
  */
 #ifndef VVAE_HIP_H
 #define VVAE_HIP_H
@@ -181,6 +181,7 @@ int vvae_spatial_attn_bwd(const void* qkv, int ld, const void* out, int ldo, con
 int vvae_layernorm_supported(int C, int dtype);
 int vvae_layernorm_bwd_blocks(long rows, int C, int dtype);
 int vvae_layernorm_config(int bwd_cap);   /* tuning hook: workgroups (= partial rows) of the backward kernel, default 512 (8 waves each) */
+int vvae_layernorm_fwd_mode(int late_stage);   /* test hook: 1 = round-1 forward variant (affine parked behind the first rows' loads, raw s_barrier) */
 int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                        const void* addend, void* xsum, long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps,
                        int dtype, void* stream);   /* addend/xsum non-NULL: normalise round(x + addend), write the sum to xsum */
@@ -213,6 +214,10 @@ int vvae_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, 
  * are host arrays of device pointers / ints. */
 int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C,
                               float* const* db, const int* M, const int* N, int n, int K, void* stream);
+/* 1 if the products (in this order) can be dealt to the 8 XCDs as WHOLE products (tiles that share an operand panel then walk K
+ * side by side behind one L2; a product cut by an XCD boundary fetches the shared panels twice): the grouping policy of the caller
+ * closes a group when adding a product would make this 0.  vvae_gemm_tn_grouped_bf16 itself accepts any list. */
+int vvae_gemm_tn_grouped_plan(const int* M, const int* N, int n);
 int vvae_gemm_tn_use_big_tiles(int on);   /* test hook: 0 = 128x128 kernel for every shape */
 
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam) at train/rl_nonadversarial.py:248-251. ---- */

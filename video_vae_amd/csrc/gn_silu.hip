@@ -105,8 +105,19 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     const int el = threadIdx.x & 31, bl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + el;
     double s = 0.0;
-    if (i < 2 * J)
-        for (int b = bl; b < nblk; b += 8) s += (double)part[((long)n * nblk + b) * 2 * J + i];
+    if (i < 2 * J) {
+        // the partials sit in L2: what this loop pays is latency, so 8 loads are in flight per thread (same summation order)
+        const float* p = part + (long)n * nblk * 2 * J + i;
+        int b = bl;
+        for (; b + 56 < nblk; b += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(b + 8 * u) * 2 * J];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; b < nblk; b += 8) s += (double)p[(long)b * 2 * J];
+    }
     red[bl][el] = s;
     __syncthreads();
     if (bl == 0 && i < 2 * J)

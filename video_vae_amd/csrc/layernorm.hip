@@ -37,7 +37,7 @@ __device__ __forceinline__ void opaque(uint4& r) { asm volatile("" : "+v"(r.x), 
 // y rows are written contiguously (pitch C).  mean / rstd: fp32 [rows] (saved for backward).
 // addend != NULL: the row normalised is round(x + addend) (addend, xsum contiguous (rows, C)) and that sum is written to xsum: the
 // residual add that closes one pre-norm block, fused with the LayerNorm that opens the next (one pass over the stream, not two).
-template <typename T_, int LPR, int VPL>
+template <typename T_, int LPR, int VPL, bool LATE_STAGE>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict__ x, T_* __restrict__ y, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, const T_* __restrict__ addend, T_* __restrict__ xsum,
@@ -66,10 +66,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T_* __restrict
             const int i = threadIdx.x + j * 256;
             if (i < LPR * VPL * V) { sg[i] = gpre[j]; sb[i] = bpre[j]; }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0) only: the row loads stay in flight across the barrier
-        __builtin_amdgcn_s_barrier();
+        if (LATE_STAGE) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0) only: the row loads stay in flight across the barrier
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
+        }
         staged = true;
     };
+    if (!LATE_STAGE) stage();                           // affine parked and the workgroup synchronised BEFORE any row is requested
     // gamma / beta are re-read from LDS at the point of use: ~50 VGPRs instead of ~118, i.e. 8 waves per SIMD, twice the bytes
     // in flight per CU
     const long rstride = (long)gridDim.x * 4 * RPW;
@@ -245,6 +250,7 @@ __global__ __launch_bounds__(64 * LN_BW) void layernorm_bwd_kernel(const T_* __r
 }
 
 int g_ln_bwd_cap = 512;
+int g_ln_fwd_late = 0;        // forward kernel: 1 = stage the affine behind the first rows' loads (LDS-only wait + raw barrier)
 
 inline int ln_blocks(long rows, int lpr, int cap = 0)
 {
@@ -281,7 +287,8 @@ bool ln_ok(const LnDims& d, const void* x, int& lpr, int& vpl)
 
 }  // namespace
 
-#define LN_CASE(KERNEL, T_, L, P, ...) case L * 8 + P: hipLaunchKernelGGL((KERNEL<T_, L, P>), grid, dim3(ln_threads), 0, s, __VA_ARGS__); break;
+#define LN_CASE(KERNEL, T_, L, P, ...) case L * 8 + P: hipLaunchKernelGGL((KERNEL<T_, L, P LN_EXTRA>), grid, dim3(ln_threads), 0, s, __VA_ARGS__); break;
+#define LN_EXTRA
 #define LN_SWITCH(KERNEL, T_, ...)                                                                                                   \
     do {                                                                                                                             \
         switch (lpr * 8 + vpl) {                                                                                                     \
@@ -289,6 +296,18 @@ bool ln_ok(const LnDims& d, const void* x, int& lpr, int& vpl)
             LN_CASE(KERNEL, T_, 8, 4, __VA_ARGS__) LN_CASE(KERNEL, T_, 16, 3, __VA_ARGS__) LN_CASE(KERNEL, T_, 16, 4, __VA_ARGS__)   \
             LN_CASE(KERNEL, T_, 32, 3, __VA_ARGS__) LN_CASE(KERNEL, T_, 32, 4, __VA_ARGS__) LN_CASE(KERNEL, T_, 64, 3, __VA_ARGS__)  \
             LN_CASE(KERNEL, T_, 64, 4, __VA_ARGS__)                                                                                  \
+            default: return VVAE_ERR_BAD_ARG;                                                                                        \
+        }                                                                                                                            \
+    } while (0)
+
+#define LN_FCASE(LATE, T_, L, P, ...) case L * 8 + P: hipLaunchKernelGGL((layernorm_fwd_kernel<T_, L, P, LATE>), grid, dim3(ln_threads), 0, s, __VA_ARGS__); break;
+#define LN_FWD_SWITCH(LATE, T_, ...)                                                                                                  \
+    do {                                                                                                                             \
+        switch (lpr * 8 + vpl) {                                                                                                     \
+            LN_FCASE(LATE, T_, 8, 1, __VA_ARGS__) LN_FCASE(LATE, T_, 8, 2, __VA_ARGS__) LN_FCASE(LATE, T_, 8, 3, __VA_ARGS__)     \
+            LN_FCASE(LATE, T_, 8, 4, __VA_ARGS__) LN_FCASE(LATE, T_, 16, 3, __VA_ARGS__) LN_FCASE(LATE, T_, 16, 4, __VA_ARGS__)   \
+            LN_FCASE(LATE, T_, 32, 3, __VA_ARGS__) LN_FCASE(LATE, T_, 32, 4, __VA_ARGS__) LN_FCASE(LATE, T_, 64, 3, __VA_ARGS__)  \
+            LN_FCASE(LATE, T_, 64, 4, __VA_ARGS__)                                                                                  \
             default: return VVAE_ERR_BAD_ARG;                                                                                        \
         }                                                                                                                            \
     } while (0)
@@ -324,12 +343,14 @@ extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, co
         if (!ln_ok<float>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr, 2048));
         const int ln_threads = 256;
-        LN_SWITCH(layernorm_fwd_kernel, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, (const float*)addend, (float*)xsum, d);
+        if (g_ln_fwd_late) { LN_FWD_SWITCH(true, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, (const float*)addend, (float*)xsum, d); }
+        else { LN_FWD_SWITCH(false, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, (const float*)addend, (float*)xsum, d); }
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
         dim3 grid(ln_blocks(rows, lpr, 1024));          // 4096 waves: all resident at 6 waves/SIMD (2048 left a third-full second round)
         const int ln_threads = 256;
-        LN_SWITCH(layernorm_fwd_kernel, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d);
+        if (g_ln_fwd_late) { LN_FWD_SWITCH(true, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d); }
+        else { LN_FWD_SWITCH(false, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d); }
     } else return VVAE_ERR_BAD_ARG;
     VVAE_LAUNCH_CHECK();
     return 0;
@@ -364,5 +385,13 @@ extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* ga
 extern "C" int vvae_layernorm_config(int bwd_cap)
 {
     g_ln_bwd_cap = bwd_cap > 0 ? bwd_cap : 512;
+    return 0;
+}
+
+// Test hook: forward-kernel variant.  0 (default): gamma / beta are parked in LDS and the workgroup synchronised (__syncthreads)
+// before any row is requested.  1: the round-1 form -- parked behind the first rows' loads, LDS-only wait + raw s_barrier.
+extern "C" int vvae_layernorm_fwd_mode(int late_stage)
+{
+    g_ln_fwd_late = late_stage ? 1 : 0;
     return 0;
 }

@@ -7,8 +7,9 @@ loop claude_distributed/distributed_train.py (:433-583), for one node of MI355X 
 
 Same constants (rl_nonadversarial.py:36-57), model config (:234-236), optimizer (:241-253), hparams (:255-263), batch/frames
 curriculum (:287-295) and log keys (:344-359).  Data: any iterable of {"video": float32 (B,T,H,W,3) in [0,1], "mask": float32
-(B,T)} batches (the reference's dataloader contract, train/dataloader.py:387-390); without --data this driver feeds seeded
-synthetic clips.  One process per GPU; gradients are all-reduced over RCCL overlapped with backward (ddp.py); rank 0 logs;
+(B,T)} batches (the reference's dataloader contract, train/dataloader.py:387-390): ``--data DIR`` streams clips from DIR through
+video_vae_amd/data.py (worker processes -> pinned uint8 batches -> H2D on a side stream, per-rank shuffle seed + rank); without
+--data this driver feeds seeded synthetic clips.  One process per GPU; gradients are all-reduced over RCCL overlapped with backward (ddp.py); rank 0 logs;
 SIGTERM/SIGINT flips a flag and the loop checkpoints and exits (distributed_train.py:58-67,489-494).
 """
 import argparse
@@ -53,6 +54,8 @@ def main():
     ap.add_argument("--model_path", type=str, default=None, help="checkpoint directory to resume from")
     ap.add_argument("--save_dir", type=str, default=None)
     ap.add_argument("--small", action="store_true", help="tiny model (depth 1) for smoke runs")
+    ap.add_argument("--data", type=str, default=None, help="directory of clips (videos{i}/*.npy|npz|mp4...): the host input pipeline")
+    ap.add_argument("--num_workers", type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,8 +96,16 @@ def main():
         max_mult = min(int(math.log2(max(args.per_device_batch_size, 1))), int(math.log2(64 / args.max_frames)) - 1)
         mult = max(0, min(epoch, max_mult))                       # batch <-> frames curriculum, :287-295
         bsz, frames = args.per_device_batch_size // (2 ** mult), args.max_frames * (2 ** mult)
-        for i, batch in enumerate(synthetic_batches(bsz, frames, (size, size), SEED + epoch + 1000 * rank, args.steps, dev)):
-            if _SHOULD_STOP:
+        if args.data:
+            from video_vae_amd import data as D
+            host = D.create_batched_dataloader(args.data, batch_size=bsz, max_frames=frames, resize=(size, size), crop_size=size,
+                                               shuffle=True, seed=SEED + epoch, num_workers=args.num_workers, prefetch_size=16,
+                                               drop_remainder=True, rank=rank, num_epochs=1, as_uint8=True)
+            batches = D.DevicePrefetcher(host, dev, dtype=torch.float32)
+        else:
+            batches = synthetic_batches(bsz, frames, (size, size), SEED + epoch + 1000 * rank, args.steps, dev)
+        for i, batch in enumerate(batches):
+            if _SHOULD_STOP or i >= args.steps:
                 break
             if i > NEGATIVE_PENALTY_TRAINING_STEPS:
                 hparams["max_compression_rate"] = 10000
