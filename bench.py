@@ -40,14 +40,42 @@ PROD = dict(height=256, width=256, channels=3, patch_size=16, encoder_depth=9, d
             qkv_features=512, max_temporal_len=64, spatial_compression_rate=8, unembedding_upsample_rate=4)
 
 
+TRAFFIC_FILE = "r02_traffic.json"
+
+
 def measured_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: separate
-    FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None."""
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (profiles/r02_traffic.json: separate
+    FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- or None, with the
+    reason, when there is no figure or the kernel's sources have changed since the passes were taken (the file carries the
+    sha256 of the .hip files the kernel is built from: a stale counter figure is refused, not quoted)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+        with open(os.path.join(here, "profiles", TRAFFIC_FILE)) as f:
+            rec = json.load(f).get(kernel)
     except (OSError, ValueError):
-        return None
+        return None, f"profiles/{TRAFFIC_FILE} missing"
+    if not rec:
+        return None, f"no PMC figure for {kernel} in profiles/{TRAFFIC_FILE}"
+    h = hashlib.sha256()
+    for name in rec.get("source_files", []):
+        try:
+            with open(os.path.join(here, "video_vae_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            return None, f"{name} not found"
+    if rec.get("source_sha256") != h.hexdigest():
+        return None, f"PMC passes predate the current {'/'.join(rec.get('source_files', []))}: re-run tools/pmc_bench_sum.py"
+    return rec.get("hbm_bytes_per_launch"), None
+
+
+def source_sha256(files):
+    import hashlib
+    h = hashlib.sha256()
+    for name in files:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "video_vae_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def parse():
@@ -74,8 +102,8 @@ def parse():
     ap.add_argument("--with-input-pipeline", action="store_true",
                     help="feed every timed step from the host input pipeline (video_vae_amd/data.py: worker processes -> pinned uint8 "
                          "-> H2D on a side stream) instead of a batch resident in HBM; the line reports the same metric")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames per clip of the bounded CPU sample")
-    ap.add_argument("--cpu-clips", type=int, default=4, help="clips of the bounded CPU sample (4 x 16 frames = one GPU batch)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames per clip of the bounded CPU sample")
+    ap.add_argument("--cpu-clips", type=int, default=1, help="clips of the bounded CPU sample")
     return ap.parse_args()
 
 
@@ -99,24 +127,74 @@ def build_model(args, dev, dtype):
     return m.to(dev), cfg
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
-    """The oracle's UNet + loss fwd+bwd on the host cores, fp32, on a bounded sample (1 clip x --cpu-frames frames)."""
-    from oracle import unet as OU
-    threads = min(16, os.cpu_count() or 1)          # the box's CPU share for one GPU is 16 cores
+    """the CPU oracle (a port of the reference's math: PyTorch CPU, fp32, oneDNN) on ALL host cores of the box, on
+    a bounded sample of the same workload: 3 warm-up + 5 timed steps, median.  ``value`` is the same metric as the GPU line --
+    frames/s of the whole train step (full-depth VideoVAE forward + recon/KL loss + backward + clip + Adam) -- on a clip cut
+    down in batch and frames so that the leg stays within ~30 s; the Conv3d UNet alone is timed beside it."""
+    import statistics
+    from oracle import loss as OLoss, model as OM, optim as OOpt, unet as OU
+    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
-    t, s, nb = args.cpu_frames, args.size, args.cpu_clips
-    p = OU.init_unet(12, 16, 3, 3, seed=5, zero_final=False)
-    for v in p.values():
-        v.requires_grad_(True)
+    s, t, nb = args.size, args.cpu_frames, args.cpu_clips
     g = torch.Generator().manual_seed(0)
+
+    def timed(fn, warm=3, reps=5):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    # ---- whole train step, production depth
+    cfg = OM.VAEConfig(**dict(PROD, height=s, width=s))
+    p = OM.init_video_vae(cfg, seed=2, zero_final=False)
+    adam = OOpt.Adam(p)
+    video = torch.rand((nb, t, s, s, 3), generator=g)
+    mask = torch.ones(nb, t)
+    emask = OLoss.expand_mask(mask.bool(), cfg.hw)
+    noise = {"gumbel_u": torch.rand((nb, t, 1), generator=g), "reparam_eps": torch.randn((nb, t, cfg.hw, cfg.latent_dim), generator=g)}
+    state = {"p": p}
+
+    def vae_step():
+        pr = {k: v.detach().requires_grad_(True) for k, v in state["p"].items()}
+        loss, _aux = OLoss.loss_fn_plain(OM.video_vae(pr, cfg, video, emask, noise), video, mask)
+        loss.backward()
+        clipped, _gn = OOpt.clip_by_global_norm({k: v.grad for k, v in pr.items()}, 1.0)
+        state["p"] = adam.update({k: v.detach() for k, v in pr.items()}, clipped, 2e-5)
+    t_vae = timed(vae_step)
+    del p, adam, state
+    # ---- the Conv3d UNet alone (the north-star kernels' CPU counterpart)
+    pu = OU.init_unet(12, 16, 3, 3, seed=5, zero_final=False)
+    for v in pu.values():
+        v.requires_grad_(True)
     x = torch.randn((nb, t, s, s, 12), generator=g) * 0.5
-    t0 = time.perf_counter()
-    y = OU.unet(p, x)
-    y.square().mean().backward()
-    dt_s = time.perf_counter() - t0
-    return {"value": nb * t / dt_s, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle UNet (Conv3d stack of the decoder) fwd+bwd, fp32, {nb} clips x {t} frames x {s}x{s}x12 features, "
-                      f"1 step, {dt_s:.1f} s on {threads} threads (transformer trunk not included)"}
+
+    def unet_step():
+        for v in pu.values():
+            v.grad = None
+        OU.unet(pu, x).square().mean().backward()
+    t_unet = timed(unet_step)
+    return {"value": nb * t / t_vae, "unit": "frames/s", "cores": threads, "cpu_model": cpu_model_name(), "kind": "port",
+            "protocol": "3 warm-up + 5 timed steps, median; torch.set_num_threads(os.cpu_count())",
+            "sample": f"oracle full-depth VideoVAE train step (fwd + recon/KL loss + bwd + clip + Adam), fp32, {nb} clip(s) x {t} frames x "
+                      f"{s}x{s}x3, median {t_vae:.2f} s/step on {threads} threads",
+            "unet_only": {"value": nb * t / t_unet, "unit": "frames/s",
+                          "sample": f"oracle UNet fwd+bwd, fp32, {nb} clip(s) x {t} frames x {s}x{s}x12 features, median {t_unet:.2f} s/step"}}
 
 
 def self_launch(n):
@@ -309,7 +387,7 @@ def main():
                 mf = bound == "mfma"
                 return {"bound": bound, "achieved": tfs if mf else gbs, "peak": MFMA_PEAK_TFS if mf else HBM_PEAK_GBS,
                         "unit": "TFLOP/s" if mf else "GB/s", "frac": (tfs / MFMA_PEAK_TFS) if mf else (gbs / HBM_PEAK_GBS),
-                        "traffic": measured_traffic(kname), "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
+                        "traffic": measured_traffic(kname)[0], "traffic_note": measured_traffic(kname)[1], "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
                         "launches_per_step": top["n"] / nsteps_timed, "alg_bytes_per_launch": b_l, "alg_flops_per_launch": f_l,
                         "alg_GBps": gbs, "alg_TFLOPps": tfs, "frac_mfma": tfs / MFMA_PEAK_TFS,
                         "kernel_ms_per_step": top["ms"] / nsteps_timed, "timed_in": timed_in}

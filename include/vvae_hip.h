@@ -57,6 +57,10 @@ int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int kw, int ld
 size_t vvae_conv3d_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int which);
 int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, int Cin, int Cout, int kt, int kh, int kw,
                           int dgrad, void* stream);
+/* n <= 64 packings in one launch (every conv layer of the UNet, forward + input-gradient forms: the weights change once per
+   optimizer step); host arrays of device pointers / ints, kt = 3, kw = kh in {3, 7}. */
+int vvae_conv3d_pack_grouped_bf16(const float* const* w, void* const* ws, const size_t* ws_bytes, const int* Cin, const int* Cout,
+                                  const int* kh, const int* dgrad, int n, void* stream);
 int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
                          int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
                          int prepacked, void* ws, size_t ws_bytes, void* stream);
@@ -246,6 +250,10 @@ int vvae_fold_rows_grouped(const void* const* part, float* const* d0, float* con
 /* n <= 64 contiguous fp32 ranges copied in one launch (gradients landing in the optimizer's flat buffer; replaces the
    per-parameter copies of optax's tree_map update path, reference train/rl_nonadversarial.py:233-236) */
 int vvae_copy_grouped(const float* const* src, float* const* dst, const long* count, int n, void* stream);
+
+/* Test hook: y[i] = x[i ^ o] within each group of 64 floats (o in {1,2,4,8,16,32}, n % 64 == 0), yd likewise in fp64 (scaled by
+   1.000000001): the VALU-only lane exchange (DPP + v_permlane16/32_swap) every wave-level reduction of this library uses. */
+int vvae_selftest_xor_lane(const float* x, float* y, double* yd, int n, int o, void* stream);
 
 #ifdef __cplusplus
 }

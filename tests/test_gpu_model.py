@@ -352,6 +352,21 @@ def _ddp_gpu_worker(rank, world, port, out):
             res[f"eager_loss{i}"] = float(loss)
         torch.cuda.synchronize()
         res["p_eager"] = vopt.p.cpu()
+        # ---- (c) multi-rank resume: rank 0 holds a trained state (moments, count), rank 1 a fresh one; after broadcast_state and
+        #      one real update (HIP clip+Adam on the all-reduced gradient) the replicas must be bit-identical
+        torch.manual_seed(0)
+        tiny = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.float32, **TINY).to(dev)
+        topt = optim.Optimizer(tiny, optim.warmup_cosine_decay_schedule(0.0, 1e-3, 10, 100, 1e-4), bucket_bytes=64 << 10)
+        v32 = torch.rand((2, 8, 32, 32, 3), generator=torch.Generator().manual_seed(9 + rank)).to(dev)
+        if rank == 0:
+            for _ in range(3):                                     # "the run that was checkpointed": count = 3, non-zero moments
+                L.train_step(tiny, topt, v32, mask, L.HPARAMS, 16, V.Rngs(7))
+        tred = ddp.GradReducer(topt)
+        tred.broadcast_state(0)
+        res["resume_count"] = topt.count
+        L.train_step(tiny, topt, v32, mask, L.HPARAMS, 16, V.Rngs(11 + rank))
+        torch.cuda.synchronize()
+        res["resume_p"], res["resume_m"], res["resume_v"], res["resume_count1"] = topt.p.cpu(), topt.m.cpu(), topt.v.cpu(), topt.count
         torch.save(res, os.path.join(out, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -372,17 +387,21 @@ def test_data_parallel_world2_sharing_one_gpu(dev, tmp_path):
         bad = [(n, int((r0["stack_got"][o:o + k] != r1["stack_got"][o:o + k]).sum()), k, o) for n, o, k in r0["layout"]
                if not torch.equal(r0["stack_got"][o:o + k], r1["stack_got"][o:o + k])]
         raise AssertionError(f"ranks disagree after the all-reduce: {bad[:6]}")
-    # Two processes time-slicing ONE GPU are not bitwise reproducible run to run (a few bf16 ulps in a few LayerNorm rows per
-    # ~1000 launches, amplified by 17 layers to ~1 % of the gradient scale; never seen with one process per GPU), so the sum is
-    # checked to 5 %: the failure this guards against -- a bucket reduced before its parked weight gradients were written --
-    # leaves each rank with its LOCAL gradient (error ~100 %) and breaks the bitwise rank-to-rank equality above.
-    assert_close_scaled(r0["stack_got"], r0["stack_want"], rel=5e-2, what="all-reduced flat gradient vs sum of shard gradients")
+    # The all-reduced gradient is the sum of the two shard gradients to fp32 rounding (round 1 had to open this check to 5 %: with a
+    # second process on the GPU, compiler-formed packed fp32 instructions dropped a subtraction in a few LayerNorm rows per ~1000
+    # launches -- tools/nondet_probe.py; the library is built without them now and the check is tight again)
+    assert_close_scaled(r0["stack_got"], r0["stack_want"], rel=1e-6, what="all-reduced flat gradient vs sum of shard gradients")
     for k in ("p_graph", "p_eager"):
         if not torch.equal(r0[k], r1[k]):
             bad = [(n, int((r0[k][o:o + c] != r1[k][o:o + c]).sum()), c) for n, o, c in r0["vlayout"] if not torch.equal(r0[k][o:o + c], r1[k][o:o + c])]
             raise AssertionError(f"replicas diverged ({k}): {len(bad)} of {len(r0['vlayout'])} parameters, {bad[:10]}")
         assert torch.isfinite(r0[k]).all()
     assert not torch.equal(r0["p_eager"], r0["p_graph"])
+    # resume: count and moments travelled with the parameters (reference claude_distributed/distributed_train.py:321-341)
+    assert r0["resume_count"] == 3 and r1["resume_count"] == 3 and r0["resume_count1"] == 4 and r1["resume_count1"] == 4
+    for k in ("resume_p", "resume_m", "resume_v"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert float(r0["resume_m"].abs().max()) > 0
     for i in range(2):
         assert r0[f"eager_loss{i}"] != r1[f"eager_loss{i}"]          # different shards
         for r in (r0, r1):
@@ -431,3 +450,46 @@ def test_graphed_train_step_rl_flavour_captures(dev):
         loss, aux = gstep()
         assert torch.isfinite(loss) and torch.isfinite(aux["rl_loss"])
     assert torch.isfinite(opt.p).all() and not torch.equal(opt.p, p0)
+
+
+def test_sigterm_checkpoints_and_exits(dev, tmp_path):
+    """Pre-emption path of the training driver (reference claude_distributed/distributed_train.py:58-67,489-494): SIGTERM flips a
+    flag, the loop stops at the next step, rank 0 writes `checkpoint_sigterm_<epoch>` and the process exits 0; the checkpoint loads
+    back into a fresh model + optimizer with a non-zero update count."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import time
+    import video_vae_amd as V
+    from video_vae_amd import optim, rl_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONUNBUFFERED="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "video_vae_amd.train", "--small", "--steps", "100000", "--size", "32", "--max_frames", "8",
+           "--save_dir", str(tmp_path)]
+    proc = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        seen, t0 = [], time.time()
+        while time.time() - t0 < 300:                              # wait for the first logged step, then pre-empt
+            line = proc.stdout.readline()
+            if not line:
+                break
+            seen.append(line)
+            if line.startswith("Epoch 0, Step 10"):
+                break
+        assert any(l.startswith("Epoch 0, Step") for l in seen), "".join(seen)[-2000:]
+        proc.send_signal(signal.SIGTERM)
+        out, _ = proc.communicate(timeout=120)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    assert proc.returncode == 0, out[-2000:]
+    ck = tmp_path / "checkpoint_sigterm_0"
+    assert (ck / "checkpoint.pt").exists(), (os.listdir(tmp_path), out[-1000:])
+    cfg = dict(height=32, width=32, channels=3, patch_size=16, encoder_depth=1, decoder_depth=1, mlp_dim=256, num_heads=4,
+               qkv_features=128, max_temporal_len=64, spatial_compression_rate=8, unembedding_upsample_rate=4)
+    m = rl_model.VideoVAE(rngs=V.Rngs(5), **cfg).to(dev)
+    opt = optim.Optimizer(m, 1e-3)
+    V.load_checkpoint(m, opt, str(ck))
+    assert opt.count >= 10 and float(opt.m.abs().max()) > 0 and torch.isfinite(opt.p).all()

@@ -981,3 +981,20 @@ def test_conv_block_gn_statistics_from_conv_epilogue(dev, ci, co, shape):
     for k, (a, b) in enumerate(zip(*res)):
         assert_close_scaled(a, b, rel=2e-2 if k < 2 else 1e-3, what=f"tensor {k}")
     assert float((res[0][0] != res[1][0]).float().mean()) < 0.02          # the statistics differ in fp32 summation order only
+
+
+@pytest.mark.parametrize("o", [1, 2, 4, 8, 16, 32])
+def test_xor_lane_exchange_selftest(dev, o):
+    """The VALU-only lane exchange (DPP / v_permlane16_swap / v_permlane32_swap) under every wave-level reduction of the library:
+    y[i] == x[i ^ o] inside each group of 64 lanes, bit for bit, for fp32 and for fp64 values."""
+    import ctypes
+    from video_vae_amd._lib import lib, check
+    n = 64 * 7
+    x = torch.arange(n, dtype=torch.float32, device=dev) * 1.25 + 3.0
+    y = torch.empty_like(x)
+    yd = torch.empty(n, dtype=torch.float64, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    check(lib().vvae_selftest_xor_lane(p(x), p(y), p(yd), n, o, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "selftest")
+    idx = torch.arange(n, device=dev) ^ o
+    assert torch.equal(y, x[idx])
+    assert torch.equal(yd, x[idx].double() * 1.000000001)

@@ -345,3 +345,19 @@ def test_grouped_weight_gradient_plan_keeps_products_whole():
     assert all(ops._WgradQueue._plannable(g) for g in launches)
     assert all(ops._WgradQueue._tiles(g) <= ops.GROUP_TILES for g in launches)
     assert len(launches) <= 7
+
+
+def test_library_has_no_packed_fp32_valu_instructions():
+    """Build hygiene that a correctness finding hangs on: with another process sharing the GPU, compiler-formed
+    packed fp32 VALU ops (v_pk_add_f32 with an op_sel broadcast, in layernorm_fwd_kernel) dropped their subtraction in lanes 48-63
+    of one register once per ~50-100 launches.  The library is built with -fno-slp-vectorize -fno-vectorize; this test disassembles
+    the gfx950 code objects embedded in the .so and checks that none of those instructions (and no LDS-crossbar shuffle) is left."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_scan
+    if not os.path.exists(isa_scan.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    res, lines = isa_scan.count([r"v_pk_[a-z0-9]+_f32", r"ds_bpermute_b32", r"ds_swizzle_b32", r"v_mfma_\w+"])
+    assert lines > 100000, "disassembly looks empty"
+    assert res[r"v_mfma_\w+"] > 1000                      # the scan does see the kernels
+    assert res[r"v_pk_[a-z0-9]+_f32"] == 0, res
+    assert res[r"ds_bpermute_b32"] == 0 and res[r"ds_swizzle_b32"] == 0, res

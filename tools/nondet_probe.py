@@ -143,6 +143,12 @@ def worker(rank, args, out_dir):
                             "max_err_bad_vs_fp32": float((y.float() - want).abs().max()),
                             "bad_rows_mod8": sorted(set((rows % 8).tolist())), "bad_vals": y[bad][:8].float().tolist(),
                             "ref_vals": y0[bad][:8].float().tolist()}
+            r0 = int(rows[0])
+            bc = bad[r0].nonzero().flatten()
+            detail[name]["row0"] = {"row": r0, "cols": bc.tolist(), "diff": [round(float(t), 4) for t in d[r0][bc]],
+                                    "ref": [round(float(t), 4) for t in y0[r0][bc].float()],
+                                    "x": [round(float(t), 4) for t in x0[r0][bc]],
+                                    "row_mean_x": float(x0[r0].mean()), "row_std_x": float(x0[r0].std(unbiased=False))}
     report["detail"] = detail
     with open(os.path.join(out_dir, f"nondet_p{args.procs}_late{args.ln_late}_r{rank}.json"), "w") as f:
         json.dump(report, f)

@@ -43,11 +43,7 @@ template <int LPR> __device__ __forceinline__ float lpr_sum(float v) {
     return v;
 }
 // sum over the lanes that hold the SAME channels (every LPR-th lane of the wave)
-template <int LPR> __device__ __forceinline__ float frames_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+template <int LPR> __device__ __forceinline__ float frames_sum(float v) { return butterfly_sum<32, LPR>(v); }   // VALU only (common.hpp)
 
 template <typename T_, int D, int LPR>
 __device__ __forceinline__ void load_row(const T_* __restrict__ row, int p, float (&r)[D / LPR]) {

@@ -28,7 +28,7 @@ struct SAttnDims { int A, S, H; float eps; };
 // chunk swizzle of an LDS image with 128-byte rows (see header comment)
 __device__ __forceinline__ int gsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
 
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float xor32(float v) { return xor_lane<32>(v); }          // v_permlane32_swap: VALU only (common.hpp)
 
 // Fragment-layout row: lane (j = lane & 31, kh = lane >> 5) holds x[ks][e] = channel 16 ks + 8 kh + e of row j.
 // q/k-norm (bias-free LayerNorm, y = round(xhat * scale)) followed by RoPE, in place; same rounding points as attn_rows.hpp.
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
                 t += dpp_xor2(t);
                 t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x141, 0xf, 0xf, true));      // row_half_mirror
                 t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x140, 0xf, 0xf, true));      // row_mirror
-                t += __shfl_xor(t, 16, 64);
+                t += xor_lane<16>(t);
                 if (j == 0) red[(wave * 2 + which) * SD + 32 * dt + 8 * (r >> 2) + 4 * kh + (r & 3)] += t;
             }
     };

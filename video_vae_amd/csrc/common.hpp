@@ -95,17 +95,50 @@ template <typename T> struct VecWidth;                       // widest vector = 
 template <> struct VecWidth<float> { static constexpr int value = 4; };
 template <> struct VecWidth<bf16_t> { static constexpr int value = 8; };
 
+// ---- cross-lane exchange on the VALU only (DPP + v_permlane16/32_swap), never through the LDS crossbar ---------------
+// xor_lane<O>(v): the value lane (id ^ O) holds, O in {1, 2, 4, 8, 16, 32} -- what __shfl_xor(v, O, 64) returns.
+// Why not __shfl_xor: hipcc lowers it to ds_bpermute_b32, an LDS-pipeline instruction (LGKM counter, ~50+ cycles of latency per
+// butterfly stage, and it competes for the LDS port with the kernels that stage tiles there).  DPP moves and the permlane swaps are
+// ordinary vector instructions: one or two issue slots per stage, no wait, bitwise the same data movement.
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int O> __device__ __forceinline__ unsigned xor_lane_u32(unsigned v) {
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8 || O == 16 || O == 32, "one address bit at a time");
+    if constexpr (O == 1) return dpp_u32<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (O == 2) return dpp_u32<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else if constexpr (O == 4) return dpp_u32<0x1B>(dpp_u32<0x141>(v));  // row_half_mirror (i -> 7-i), then quad_perm [3,2,1,0]: i -> i^4
+    else if constexpr (O == 8) return dpp_u32<0x128>(v);                 // row_ror:8 (16-lane rows: (i + 8) % 16 = i ^ 8)
+    else if constexpr (O == 16) {
+        // v_permlane16_swap vdst, src: rows 1, 3 of vdst trade places with rows 0, 2 of src.  With both operands = v:
+        // r[0] = rows {0,0,2,2} of v, r[1] = rows {1,1,3,3}: an odd row's partner is in r[0], an even row's in r[1].
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        // v_permlane32_swap: lanes 32-63 of vdst trade places with lanes 0-31 of src: r[0] = {lo, lo}, r[1] = {hi, hi}
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+template <int O> __device__ __forceinline__ float xor_lane(float v) { return __uint_as_float(xor_lane_u32<O>(__float_as_uint(v))); }
+template <int O> __device__ __forceinline__ double xor_lane(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = xor_lane_u32<O>((unsigned)u), hi = xor_lane_u32<O>((unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// Butterfly all-reduce over the lane-address bits HI, HI/2, ..., LO (powers of two): every lane ends with the sum over the lanes
+// that differ from it only in those bits, bitwise identical in all of them (each step adds the same two numbers on both sides).
+template <int HI, int LO, typename F> __device__ __forceinline__ F butterfly_sum(F v) {
+    static_assert(HI >= LO && LO >= 1, "bit range");
+    v += xor_lane<HI>(v);
+    if constexpr (HI > LO) return butterfly_sum<HI / 2, LO>(v);
+    else return v;
+}
+// the threads of a block must be laid out so that lane = threadIdx.x % 64 (every launch in this library is 1-D)
+
 // ---- wave (64-lane) reductions -------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return butterfly_sum<32, 1>(v); }
+__device__ __forceinline__ double wave_sum(double v) { return butterfly_sum<32, 1>(v); }
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (ten VALU instructions per element in the GroupNorm+SiLU kernels)
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

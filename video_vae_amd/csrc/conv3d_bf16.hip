@@ -43,34 +43,61 @@ struct BfDims { int N, T, H, W, CK, CO, tiles_h, tiles_w; };
 // dgrad=0: value = w[dt][dy][dx][ci][co]                (K channels = Cin,  produced = Cout)
 // dgrad=1: value = w[KT-1-dt][KH-1-dy][KW-1-dx][co][ci] (K channels = Cout, produced = Cin; "co" indexes Cin here)
 template <int CKB, int KT, int KH, int KW>
+__device__ __forceinline__ void pack_fragment(const float* __restrict__ w, uint4* __restrict__ wp, int Cin, int Cout, int dgrad, long i)
+{
+    constexpr int KSTEPS = (KT * KW * CKB + 31) / 32;
+    const int CO = dgrad ? Cin : Cout;
+    const int co_tiles = CO / 16;
+    const int l = (int)(i & 63); long q = i >> 6;
+    const int ct = (int)(q % co_tiles); q /= co_tiles;
+    const int j = (int)(q % KSTEPS); q /= KSTEPS;
+    const int dy = (int)(q % KH); const int chunk = (int)(q / KH);
+    const int co = ct * 16 + (l & 15);
+    uint32_t pk[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 32 * j + 8 * (l >> 4) + e;
+        const int slot = k / CKB, ci = chunk * CKB + k % CKB;
+        float v = 0.f;
+        if (slot < KT * KW) {
+            const int dt = slot / KW, dx = slot % KW;
+            if (!dgrad) v = w[((((long)dt * KH + dy) * KW + dx) * Cin + ci) * Cout + co];
+            else v = w[((((long)(KT - 1 - dt) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)) * Cin + co) * Cout + ci];
+        }
+        const uint32_t b = f2bf(v);
+        if (e & 1) pk[e >> 1] |= b << 16; else pk[e >> 1] = b;
+    }
+    wp[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+template <int CKB, int KT, int KH, int KW>
 __global__ void pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int Cin, int Cout, int dgrad)
 {
     constexpr int KSTEPS = (KT * KW * CKB + 31) / 32;
     const int CK = dgrad ? Cout : Cin, CO = dgrad ? Cin : Cout;
-    const int co_tiles = CO / 16, chunks = CK / CKB;
-    const long total = (long)chunks * KH * KSTEPS * co_tiles * 64;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int l = (int)(i & 63); long q = i >> 6;
-        const int ct = (int)(q % co_tiles); q /= co_tiles;
-        const int j = (int)(q % KSTEPS); q /= KSTEPS;
-        const int dy = (int)(q % KH); const int chunk = (int)(q / KH);
-        const int co = ct * 16 + (l & 15);
-        uint32_t pk[4];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 32 * j + 8 * (l >> 4) + e;
-            const int slot = k / CKB, ci = chunk * CKB + k % CKB;
-            float v = 0.f;
-            if (slot < KT * KW) {
-                const int dt = slot / KW, dx = slot % KW;
-                if (!dgrad) v = w[((((long)dt * KH + dy) * KW + dx) * Cin + ci) * Cout + co];
-                else v = w[((((long)(KT - 1 - dt) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)) * Cin + co) * Cout + ci];
-            }
-            const uint32_t b = f2bf(v);
-            if (e & 1) pk[e >> 1] |= b << 16; else pk[e >> 1] = b;
-        }
-        wp[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-    }
+    const long total = (long)(CK / CKB) * KH * KSTEPS * (CO / 16) * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        pack_fragment<CKB, KT, KH, KW>(w, wp, Cin, Cout, dgrad, i);
+}
+
+// Grouped form: every conv layer of a network (forward and flipped input-gradient packings) in ONE launch -- weights change once
+// per optimizer step, and 28 five-microsecond launches per step were pure launch latency.  Blocks [block_start_e,
+// block_start_{e+1}) belong to entry e, 256 packed 16-byte fragments-lanes each.  variant: 0 = 3x7x7 / 16-channel chunks,
+// 1 = 3x3x3 / 16, 2 = 3x3x3 / 32.
+constexpr int PACK_MAX = 64;
+struct PackEntry { const float* w; uint4* wp; long total; int Cin, Cout, variant, dgrad, block_start; };
+struct PackArgs { PackEntry e[PACK_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackArgs g)
+{
+    int ei = 0;
+    for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].block_start ? i : ei;
+    const PackEntry& E = g.e[ei];
+    const long i = ((long)((int)blockIdx.x - E.block_start)) * 256 + threadIdx.x;
+    if (i >= E.total) return;
+    if (E.variant == 0) pack_fragment<16, 3, 7, 7>(E.w, E.wp, E.Cin, E.Cout, E.dgrad, i);
+    else if (E.variant == 1) pack_fragment<16, 3, 3, 3>(E.w, E.wp, E.Cin, E.Cout, E.dgrad, i);
+    else pack_fragment<32, 3, 3, 3>(E.w, E.wp, E.Cin, E.Cout, E.dgrad, i);
 }
 
 // Stage a KT x HR x WR halo of 16-byte channel parts into LDS, zero-filled outside the volume.  Every thread owns one
@@ -304,6 +331,31 @@ extern "C" int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, 
     if (kh == 7) return launch_pack<16, 3, 7, 7>(w, (uint4*)ws, Cin, Cout, dgrad, s);
     if (chunk_of(CK) == 16) return launch_pack<16, 3, 3, 3>(w, (uint4*)ws, Cin, Cout, dgrad, s);
     return launch_pack<32, 3, 3, 3>(w, (uint4*)ws, Cin, Cout, dgrad, s);
+}
+
+// n <= 64 packings in one launch: entry i packs w[i] (kt = 3, kh[i] = kw[i] in {3, 7}, Cin[i] -> Cout[i]) for the forward
+// (dgrad[i] = 0) or the input-gradient (1) kernel into ws[i] (>= vvae_conv3d_bf16_ws_bytes(.., which = dgrad[i]) bytes, 16-byte
+// aligned).  Host arrays of device pointers / ints.  A caller packs once per optimizer step and passes prepacked = 1 afterwards.
+extern "C" int vvae_conv3d_pack_grouped_bf16(const float* const* w, void* const* ws, const size_t* ws_bytes, const int* Cin, const int* Cout,
+                                             const int* kh, const int* dgrad, int n, void* stream)
+{
+    if (!w || !ws || !ws_bytes || !Cin || !Cout || !kh || !dgrad || n <= 0 || n > PACK_MAX) return VVAE_ERR_BAD_ARG;
+    PackArgs g;
+    g.n = n;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || !ws[i] || ((uintptr_t)ws[i] % 16) || (kh[i] != 3 && kh[i] != 7)) return VVAE_ERR_BAD_ARG;
+        if (!vvae_conv3d_bf16_supported(Cin[i], Cout[i], 3, kh[i], kh[i], 8, 8, dgrad[i] ? 1 : 0, 0)) return VVAE_ERR_BAD_ARG;
+        const int CK = dgrad[i] ? Cout[i] : Cin[i], CO = dgrad[i] ? Cin[i] : Cout[i];
+        const size_t need = packed_bytes(CK, CO, 3, kh[i], kh[i]);
+        if (ws_bytes[i] < need) return VVAE_ERR_WORKSPACE;
+        const int variant = kh[i] == 7 ? 0 : (chunk_of(CK) == 16 ? 1 : 2);
+        g.e[i] = PackEntry{w[i], (uint4*)ws[i], (long)(need / 16), Cin[i], Cout[i], variant, dgrad[i] ? 1 : 0, (int)blocks};
+        blocks += ceil_div((long)(need / 16), 256L);
+    }
+    hipLaunchKernelGGL(pack_weights_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    VVAE_LAUNCH_CHECK();
+    return 0;
 }
 
 // dgrad = 0: y = conv(x, w) + bias.   dgrad = 1: "x" is dy (Cout channels), "y" is dx (Cin channels), bias ignored.
@@ -658,8 +710,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a = gs[i][e], b = gss[i][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                a = butterfly_sum<8, 1>(a); b = butterfly_sum<8, 1>(b);          // the 16 voxel lanes of this channel quad (DPP only)
                 if (r == 0) {
                     const int ch = (wn * NT_W + i) * 16 + 4 * g + e;
                     red[(wm * CO + ch) * 2 + 0] = a;

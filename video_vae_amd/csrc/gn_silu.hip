@@ -27,7 +27,14 @@ __device__ __forceinline__ void column_reduce(float& a, float& b, int cvecs, int
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (cvecs <= 64 && (cvecs & (cvecs - 1)) == 0) {
-        for (int o = 32; o >= cvecs; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        // the lanes of a wave that hold the same channel vector (lane % cvecs): VALU-only exchanges (common.hpp), cvecs is
+        // uniform over the grid, so the ladder below is one scalar branch chain
+        a += xor_lane<32>(a); b += xor_lane<32>(b);
+        if (cvecs <= 16) { a += xor_lane<16>(a); b += xor_lane<16>(b); }
+        if (cvecs <= 8) { a += xor_lane<8>(a); b += xor_lane<8>(b); }
+        if (cvecs <= 4) { a += xor_lane<4>(a); b += xor_lane<4>(b); }
+        if (cvecs <= 2) { a += xor_lane<2>(a); b += xor_lane<2>(b); }
+        if (cvecs <= 1) { a += xor_lane<1>(a); b += xor_lane<1>(b); }
         __syncthreads();                      // previous use of red is finished
         if (lane < cvecs) { red[wave * 64 + lane][0] = a; red[wave * 64 + lane][1] = b; }
         __syncthreads();

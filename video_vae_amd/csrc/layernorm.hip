@@ -16,11 +16,7 @@ struct LnDims { long rows; int C; int inner; long outer_pitch; long inner_pitch;
 
 __device__ __forceinline__ long row_off(const LnDims& d, long r) { return (r / d.inner) * d.outer_pitch + (r % d.inner) * d.inner_pitch; }
 
-template <int LPR> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+template <int LPR> __device__ __forceinline__ float group_sum(float v) { return butterfly_sum<LPR / 2, 1>(v); }   // VALU-only (common.hpp)
 
 // raw 16-byte vector -> fp32 lanes (the backward kernel keeps x and dy RAW between its two passes: 8 instead of 16 live
 // registers per bf16 vector, which is what lets four waves share a SIMD)
@@ -230,8 +226,7 @@ __global__ __launch_bounds__(64 * LN_BW) void layernorm_bwd_kernel(const T_* __r
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 float t = pass ? ab[k][e] : ag[k][e];
-#pragma unroll
-                for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+                if constexpr (LPR < 64) t = butterfly_sum<32, LPR>(t);       // the row slots of a wave (lanes with equal ll)
                 if (lane < LPR) red[wave][lane][k * V + e] = t;
             }
         __syncthreads();

@@ -525,3 +525,32 @@ extern "C" int vvae_copy_grouped(const float* const* src, float* const* dst, con
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
+template <int O> __global__ void xor_lane_selftest_kernel(const float* __restrict__ x, float* __restrict__ y, double* __restrict__ yd)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    y[i] = xor_lane<O>(x[i]);
+    yd[i] = xor_lane<O>((double)x[i] * 1.000000001);
+}
+}  // namespace
+
+// Test hook: y[i] = x[i ^ o] within each group of 64 floats (n a multiple of 64), yd[i] = (double)x[i ^ o] * 1.000000001: the
+// VALU-only lane exchange every reduction of this library is built on (common.hpp: xor_lane), checked against index arithmetic.
+extern "C" int vvae_selftest_xor_lane(const float* x, float* y, double* yd, int n, int o, void* stream)
+{
+    if (!x || !y || !yd || n <= 0 || n % 64) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(n / 64), block(64);
+    switch (o) {
+        case 1: hipLaunchKernelGGL(xor_lane_selftest_kernel<1>, grid, block, 0, s, x, y, yd); break;
+        case 2: hipLaunchKernelGGL(xor_lane_selftest_kernel<2>, grid, block, 0, s, x, y, yd); break;
+        case 4: hipLaunchKernelGGL(xor_lane_selftest_kernel<4>, grid, block, 0, s, x, y, yd); break;
+        case 8: hipLaunchKernelGGL(xor_lane_selftest_kernel<8>, grid, block, 0, s, x, y, yd); break;
+        case 16: hipLaunchKernelGGL(xor_lane_selftest_kernel<16>, grid, block, 0, s, x, y, yd); break;
+        case 32: hipLaunchKernelGGL(xor_lane_selftest_kernel<32>, grid, block, 0, s, x, y, yd); break;
+        default: return VVAE_ERR_BAD_ARG;
+    }
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

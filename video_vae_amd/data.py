@@ -229,6 +229,7 @@ class DevicePrefetcher:
     def __init__(self, batches, device, dtype=torch.float32, depth=2):
         self.device, self.dtype = device, dtype
         self.stream = torch.cuda.Stream(device=device)
+        self.div255 = torch.full((), 255.0, dtype=torch.float32, device=device)
         self.q = queue.Queue(maxsize=depth)
         self.slots, self.slot = [None] * (depth + 1), 0
         self.err = None
@@ -245,7 +246,9 @@ class DevicePrefetcher:
             dv = video.to(self.device, non_blocking=True)
             dm = mask.to(self.device, non_blocking=True).float()
             if dv.dtype == torch.uint8:
-                dv = (dv.float() / 255.0).to(self.dtype)           # the reference's astype(float32) / 255.0, done after the copy
+                # the reference's astype(float32) / 255.0, done after the copy.  The divisor is a device TENSOR on purpose: with a
+                # Python scalar the framework multiplies by the rounded reciprocal, which is 1 ulp off a true division for some k
+                dv = torch.div(dv.float(), self.div255).to(self.dtype)
             else:
                 dv = dv.to(self.dtype)
             ev = torch.cuda.Event()

@@ -32,6 +32,16 @@ def expand_mask(mask, hw):
     return rearrange(mask, "b hw 1 1 time -> (b hw) 1 1 time")
 
 
+def kl_from_model(model, mean, logvar, mask_bt):
+    """Per-sample KL term (rl_nonadversarial.py:146-147).  A train-mode forward already produced it in the same pass that
+    reparameterised (ops.reparameterise_kl) and left it on the model, keyed by the very tensors it returned; anything else
+    (eval mode, a foreign model) takes the stand-alone kernel."""
+    cached = getattr(model, "_kl", None)
+    if cached is not None and cached[0] is mean and cached[1] is logvar and cached[2].shape[0] == mask_bt.shape[0]:
+        return cached[2]
+    return ops.kl_per_sample(mean, logvar, mask_bt)
+
+
 def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn=None, vgg_params=None, train=True):
     reconstruction, _comp, selection, selection_mask, logvar, mean = model(video, mask, rngs, train=train)
     output_mask = original_mask.to(torch.float32).repeat_interleave(2, dim=0)
@@ -50,7 +60,7 @@ def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn
     selection_loss = per_sample_mean(torch.square(
         magnify_negatives(density_compression_difference, hparams["magnify_negatives_rate"])))
 
-    kl_loss = ops.kl_per_sample(mean, logvar, output_mask)
+    kl_loss = kl_from_model(model, mean, logvar, output_mask)
 
     per_sample_loss = (per_sample_error + hparams["gamma3"] * perceptual_loss + hparams["gamma1"] * selection_loss
                        + hparams["gamma2"] * kl_loss + hparams["gamma4"] * per_sample_MAE)
@@ -90,7 +100,7 @@ def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
     kept_frame_density = selection_sum / sequence_lengths
     diff = kept_frame_density - (1 / hparams["max_compression_rate"])
     selection_loss = torch.square(magnify_negatives(diff, hparams["magnify_negatives_rate"])).mean()
-    kl_loss = ops.kl_per_sample(mean, logvar, om).mean()
+    kl_loss = kl_from_model(model, mean, logvar, om).mean()
     loss = MSE + hparams["gamma1"] * selection_loss + hparams["gamma2"] * kl_loss
     return loss, {"MSE": MSE, "selection_loss": selection_loss, "kl_loss": kl_loss, "reconstruction": reconstruction,
                   "kept_frame_density": kept_frame_density.mean()}

@@ -10,6 +10,12 @@ from .rngs import Rngs
 from .unet import UNet
 
 
+def frame_mask(mask, b, t):
+    """(b, t) float view of the temporal mask the drivers pass: (b*hw,1,1,t) as train_step expands it (rl_nonadversarial.py:190-192)
+    or (b,1,1,t) (claude_distributed/layers.py:213-214); every patch of a sample carries the same row."""
+    return mask.reshape(b, -1, t)[:, 0].to(torch.float32)
+
+
 class Encoder(nn.Module):
     """Reference train/model.py:14-60 -> (mean, log_variance, selection (b,t,1,1) in {0,1})."""
 
@@ -104,9 +110,13 @@ class VideoVAE(nn.Module):
 
     def forward(self, x, mask, rngs, train=True):
         mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
+        self._kl = None
         if train:
             noise = rngs.draw("reparam_eps", "normal", log_variance.shape, log_variance.device)
-            sampled_latent = ops.reparameterise(mean, log_variance, noise)
+            # z and the per-sample KL term in ONE pass over (mean, log_variance): the loss picks the KL up from here
+            # (loss.kl_from_model) instead of streaming the two tensors a second time
+            sampled_latent, kl = ops.reparameterise_kl(mean, log_variance, noise, frame_mask(mask, mean.shape[0], mean.shape[1]))
+            self._kl = (mean, log_variance, kl)
         else:
             sampled_latent = mean
         compressed_representation = self.fill_token * (1 - selection) + sampled_latent * selection

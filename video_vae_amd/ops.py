@@ -152,8 +152,9 @@ def force_generic_conv(on):
     lib().vvae_conv3d_force_generic(1 if on else 0)
 
 
-def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad):
-    """Shared by fwd (dgrad=0) and dgrad (dgrad=1): bf16 fast path with a separate pack launch, else the dispatcher."""
+def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None):
+    """Shared by fwd (dgrad=0) and dgrad (dgrad=1): bf16 fast path (weights packed here, or already packed for the whole step by
+    conv3d_prepack: ``packed``), else the dispatcher."""
     n, t, h, w, cin, cout, kt, kh, kw = dims
     dt = _dt(x)
     ldo = out.stride(-2)
@@ -165,10 +166,13 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad):
     name = "dgrad" if dgrad else "fwd"
     tag = f"conv3d_{name} {ck}->{co} k{kt}{kh}{kw} @{h}x{w}"
     if _bf16_fast(cin, cout, kt, kh, kw, ldx, ldo, 1 if dgrad else 0, dt):
-        wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, 1 if dgrad else 0)
-        ws, wsb = _ws(wsb, x.device)
-        check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, 1 if dgrad else 0, _stream()),
-              "vvae_conv3d_pack_bf16")
+        if packed is not None:
+            ws, wsb = packed, packed.numel()
+        else:
+            wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, 1 if dgrad else 0)
+            ws, wsb = _ws(wsb, x.device)
+            check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, 1 if dgrad else 0, _stream()),
+                  "vvae_conv3d_pack_bf16")
         check(_launch(tag, alg, flops, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
                       lambda: lib().vvae_conv3d_fwd_bf16(_p(x), ldx, None, _p(bias), _p(out), ldo, n, t, h, w, cin, cout, kt, kh,
                                                          kw, 1 if dgrad else 0, 1, _p(ws), wsb, _stream())),
@@ -184,24 +188,74 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad):
 
 
 # --------------------------------------------------------------------------------------------- Conv3d
-def conv3d_fwd_raw(x, kernel, bias, out=None):
+def conv3d_fwd_raw(x, kernel, bias, out=None, packed=None):
     x, ldx = rows(x)
     n, t, h, w, cin = x.shape
     kt, kh, kw, cin2, cout = kernel.shape
     assert cin == cin2, (cin, cin2)
     if out is None:
         out = torch.empty((n, t, h, w, cout), dtype=x.dtype, device=x.device)
-    return _conv_fwd_like(x, ldx, kernel, bias, out, (n, t, h, w, cin, cout, kt, kh, kw), 0)
+    return _conv_fwd_like(x, ldx, kernel, bias, out, (n, t, h, w, cin, cout, kt, kh, kw), 0, packed)
 
 
-def conv3d_dgrad_raw(dy, kernel, out=None):
+def conv3d_dgrad_raw(dy, kernel, out=None, packed=None):
     dy, lddy = rows(dy)
     n, t, h, w, cout = dy.shape
     kt, kh, kw, cin, cout2 = kernel.shape
     assert cout == cout2
     if out is None:
         out = torch.empty((n, t, h, w, cin), dtype=dy.dtype, device=dy.device)
-    return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1)
+    return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1, packed)
+
+
+class ConvPack:
+    """Packed bf16 weight fragments of one conv layer for one optimizer step: ``fwd`` and ``dgrad`` are uint8 views of one buffer."""
+    __slots__ = ("fwd", "dgrad")
+
+    def __init__(self, fwd, dgrad):
+        self.fwd, self.dgrad = fwd, dgrad
+
+
+def conv3d_prepack(kernels):
+    """Pack the weights of every conv layer of a network -- forward and flipped input-gradient forms -- in ONE launch
+    (vvae_conv3d_pack_grouped_bf16).  ``kernels``: fp32 GPU tensors (3, kh, kw, Cin, Cout); -> list of ConvPack (None for a layer
+    the bf16 matrix-core kernels do not take).  Weights change once per optimizer step; packing per call was 28 launches a step."""
+    specs, sizes = [], []
+    for k in kernels:
+        kt, kh, kw, cin, cout = k.shape
+        ok = (k.is_cuda and k.dtype == torch.float32 and kt == 3 and kh == kw and kh in (3, 7) and not _FORCE_GENERIC[0]
+              and lib().vvae_conv3d_bf16_supported(cin, cout, kt, kh, kw, 8, 8, 0, 0) == 1
+              and lib().vvae_conv3d_bf16_supported(cin, cout, kt, kh, kw, 8, 8, 1, 0) == 1)
+        specs.append(ok)
+        if ok:
+            for which in (0, 1):
+                sizes.append((lib().vvae_conv3d_bf16_ws_bytes(1, 1, 1, 1, cin, cout, kt, kh, kw, which) + 255) // 256 * 256)
+    if not sizes:
+        return [None] * len(kernels)
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=kernels[0].device)
+    packs, off, ent = [], 0, []
+    it = iter(sizes)
+    for k, ok in zip(kernels, specs):
+        if not ok:
+            packs.append(None)
+            continue
+        views = []
+        for which in (0, 1):
+            nb = next(it)
+            v = buf[off:off + nb]
+            off += nb
+            views.append(v)
+            ent.append((k.contiguous(), v, which))
+        packs.append(ConvPack(views[0], views[1]))
+    for i0 in range(0, len(ent), 64):
+        e = ent[i0:i0 + 64]
+        n = len(e)
+        VP, IA, SA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_size_t * n
+        check(lib().vvae_conv3d_pack_grouped_bf16(VP(*[k.data_ptr() for k, _, _ in e]), VP(*[v.data_ptr() for _, v, _ in e]),
+                                                  SA(*[v.numel() for _, v, _ in e]), IA(*[k.shape[3] for k, _, _ in e]),
+                                                  IA(*[k.shape[4] for k, _, _ in e]), IA(*[k.shape[1] for k, _, _ in e]),
+                                                  IA(*[w for _, _, w in e]), n, _stream()), "vvae_conv3d_pack_grouped_bf16")
+    return packs
 
 
 def conv3d_wgrad_raw(x, dy, kshape, want_bias=True, dw_out=None, db_out=None):
@@ -232,50 +286,55 @@ def conv3d_gn_blocks(x, kernel, groups):
     return lib().vvae_conv3d_gn_blocks(n, t, h, w, cin, cout, kt, kh, kw, x.stride(-2), cout, groups)
 
 
-def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk):
+def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk, packed=None):
     """conv3d_fwd_raw + the per-(sample, workgroup, group) sums of the rounded outputs: -> (y, part (n, nblk, groups, 2) fp32)."""
     x, ldx = rows(x)
     n, t, h, w, cin = x.shape
     kt, kh, kw, _, cout = kernel.shape
     out = torch.empty((n, t, h, w, cout), dtype=x.dtype, device=x.device)
     part = torch.empty((n, nblk, groups, 2), dtype=torch.float32, device=x.device)
-    wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, 0)
-    ws, wsb = _ws(wsb, x.device)
+    if packed is not None:
+        ws, wsb = packed, packed.numel()
+    else:
+        wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, 0)
+        ws, wsb = _ws(wsb, x.device)
     vox = n * t * h * w
     tag = f"conv3d_fwd {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
     check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
                   lambda: lib().vvae_conv3d_fwd_bf16_gn(_p(x), ldx, _p(kernel), _p(bias), _p(out), cout, n, t, h, w, cin, cout, kt, kh,
-                                                        kw, 0, _p(ws), wsb, _p(part), groups, _stream())), "vvae_conv3d_fwd_bf16_gn")
+                                                        kw, 1 if packed is not None else 0, _p(ws), wsb, _p(part), groups, _stream())),
+          "vvae_conv3d_fwd_bf16_gn")
     return out, part
 
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias, gn_groups=0, gn_blocks=0):
+    def forward(ctx, x, kernel, bias, gn_groups=0, gn_blocks=0, pack=None):
         k32 = _f32(kernel)
         b32 = _f32(bias) if bias is not None else None
         ctx.save_for_backward(x, k32)
         ctx.has_bias = bias is not None
         ctx.kdtype = kernel.dtype
         ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the gradient may be written directly
+        ctx.pack = pack                                  # this step's packed weights (conv3d_prepack), or None: pack per call
         if gn_blocks:
-            y, part = conv3d_fwd_gn_raw(x, k32, b32, gn_groups, gn_blocks)
+            y, part = conv3d_fwd_gn_raw(x, k32, b32, gn_groups, gn_blocks, pack.fwd if pack is not None else None)
             ctx.mark_non_differentiable(part)
             ctx.with_part = True
             return y, part
         ctx.with_part = False
-        return conv3d_fwd_raw(x, k32, b32)
+        return conv3d_fwd_raw(x, k32, b32, packed=pack.fwd if pack is not None else None)
 
     @staticmethod
     def backward(ctx, dy, dpart=None):
         dx, dw, db = _Conv3d._backward(ctx, dy)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
     @staticmethod
     def _backward(ctx, dy):
         x, k32 = ctx.saved_tensors
         dy = dy.to(x.dtype)
-        dx = conv3d_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
+        dx = conv3d_dgrad_raw(dy, k32, packed=ctx.pack.dgrad if ctx.pack is not None else None) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             q = WGRAD_QUEUE[0]
@@ -297,19 +356,19 @@ class _Conv3d(torch.autograd.Function):
         return dx, dw, db
 
 
-def conv3d(x, kernel, bias=None):
-    """NDHWC Conv3d, SAME, stride 1 (nnx.Conv; reference train/unet.py:13-21)."""
-    return _Conv3d.apply(x, kernel, bias, 0, 0)
+def conv3d(x, kernel, bias=None, pack=None):
+    """NDHWC Conv3d, SAME, stride 1 (nnx.Conv; reference train/unet.py:13-21).  ``pack``: from conv3d_prepack."""
+    return _Conv3d.apply(x, kernel, bias, 0, 0, pack)
 
 
-def conv3d_with_gn_stats(x, kernel, bias, groups):
+def conv3d_with_gn_stats(x, kernel, bias, groups, pack=None):
     """-> (conv3d(x), stats) where stats is None or (partial sums, rows per sample) for group_norm_silu(..., stats=...): on
     the rolling bf16 kernel the conv's epilogue also sums its rounded outputs per GroupNorm group, so the norm behind it
     (reference train/unet.py:13-23) skips its own statistics pass over the tensor."""
     nblk = conv3d_gn_blocks(x, kernel, groups) if bias is not None else 0
     if not nblk:
-        return _Conv3d.apply(x, kernel, bias, 0, 0), None
-    y, part = _Conv3d.apply(x, kernel, bias, groups, nblk)
+        return _Conv3d.apply(x, kernel, bias, 0, 0, pack), None
+    y, part = _Conv3d.apply(x, kernel, bias, groups, nblk, pack)
     return y, (part, nblk)
 
 

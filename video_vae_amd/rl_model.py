@@ -4,7 +4,7 @@ from einops import rearrange
 from torch import nn
 
 from . import ops
-from .model import Encoder as _Encoder, Decoder  # Decoder is identical in both flavours (rl_model.py:62-97)
+from .model import Encoder as _Encoder, Decoder, frame_mask  # Decoder is identical in both flavours (rl_model.py:62-97)
 
 __all__ = ["Encoder", "Decoder", "VideoVAE"]
 
@@ -37,15 +37,19 @@ class VideoVAE(nn.Module):
 
     def forward(self, x, mask, rngs, train=True):
         mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
+        self._kl = None
+        kl = None
         if train:
             noise = rngs.draw("reparam_eps", "normal", log_variance.shape, log_variance.device)
-            sampled_latent = ops.reparameterise(mean, log_variance, noise)
+            sampled_latent, kl = ops.reparameterise_kl(mean, log_variance, noise, frame_mask(mask, mean.shape[0], mean.shape[1]))
         else:
             sampled_latent = mean
         selection = rearrange(selection, "b t 1 -> b t 1 1").repeat_interleave(2, dim=0)
         sampled_latent = sampled_latent.repeat_interleave(2, dim=0)
         mean = mean.repeat_interleave(2, dim=0)
         log_variance = log_variance.repeat_interleave(2, dim=0)
+        if kl is not None:                                  # both members of a pair share mean / log-variance / mask: same KL term
+            self._kl = (mean, log_variance, kl.repeat_interleave(2, dim=0))
         mask = mask.repeat_interleave(2, dim=0)
         u = rngs.draw("bernoulli_u", "uniform", selection.shape, selection.device)
         selection_mask = (u < selection).to(sampled_latent.dtype)

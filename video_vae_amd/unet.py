@@ -62,11 +62,12 @@ class ConvBlock3D(nn.Module):
         self.conv = Conv(in_channels, out_channels, (temporal_kernel, kernel_size, kernel_size), rngs, dtype, param_dtype)
         self.norm = GroupNorm(min(8, out_channels), out_channels, param_dtype)
 
-    def forward(self, x, kernel=None, out=None):
+    def forward(self, x, kernel=None, out=None, pack=None):
         # ``kernel``: optional stand-in for self.conv.kernel (UNet passes a zero-padded view for 16-channel alignment)
         # ``out``: channel slice of a wider buffer for the block's output (the skip half of a decoder's concat buffer)
+        # ``pack``: this step's packed weights of the conv (ops.conv3d_prepack), or None
         x, stats = ops.conv3d_with_gn_stats(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias,
-                                            self.norm.num_groups)
+                                            self.norm.num_groups, pack)
         return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out, stats)
 
 
@@ -78,8 +79,8 @@ class DownBlock3D(nn.Module):
         self.conv1 = ConvBlock3D(in_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
         self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
 
-    def forward(self, x, kernel1=None, skip_out=None):
-        x = self.conv2(self.conv1(x, kernel1), out=skip_out)
+    def forward(self, x, kernel1=None, skip_out=None, packs=(None, None)):
+        x = self.conv2(self.conv1(x, kernel1, pack=packs[0]), out=skip_out, pack=packs[1])
         return ops.max_pool_fork(x)
 
 
@@ -92,7 +93,7 @@ class UpBlock3D(nn.Module):
         self.conv1 = ConvBlock3D(out_channels * 2, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
         self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
 
-    def forward(self, x, skip, joint=None):
+    def forward(self, x, skip, joint=None, packs=(None, None)):
         """joint: the (.., 2C) buffer whose upper channel half ``skip`` already is; the up-conv writes the lower half and the
         concat of the reference (unet.py:79, a 268 MB copy at the 256^2 level) disappears."""
         if joint is not None:
@@ -100,7 +101,7 @@ class UpBlock3D(nn.Module):
             x = ops.join_channels(self.upsample(x, out=joint[..., :c]), skip, joint)
         else:
             x = torch.cat([self.upsample(x), skip], dim=-1)
-        return self.conv2(self.conv1(x))
+        return self.conv2(self.conv1(x, pack=packs[0]), pack=packs[1])
 
 
 class UNet(nn.Module):
@@ -136,6 +137,7 @@ class UNet(nn.Module):
         c = self.patch_mixer.kernel.shape[-2]
         pad = (-c) % 16 if (x.is_cuda and self.dtype == torch.bfloat16 and len(self.encoders) > 0) else 0
         k1 = None
+        km, bm = self.patch_mixer.kernel, self.patch_mixer.bias
         if pad:
             # bf16 MFMA kernels want channel counts in multiples of 16: run the mixer and the first encoder conv on
             # zero-padded channels (zero weights in the pad rows/columns => identical results, grads sliced by autograd).
@@ -144,10 +146,20 @@ class UNet(nn.Module):
                 x = F.pad(x, (0, pad))
             elif x.shape[-1] != c + pad:
                 raise ValueError(f"UNet expects {c} (or {c + pad} zero-padded) input channels, got {x.shape[-1]}")
-            x = ops.conv3d(x, F.pad(self.patch_mixer.kernel, (0, pad, 0, pad)), F.pad(self.patch_mixer.bias, (0, pad)))
+            km, bm = F.pad(km, (0, pad, 0, pad)), F.pad(bm, (0, pad))
             k1 = F.pad(self.encoders[0].conv1.conv.kernel, (0, 0, 0, pad))
-        else:
-            x = self.patch_mixer(x)
+        # every conv layer's weights are packed for the matrix-core kernels once per step, in one launch (they were 28 launches)
+        packs = None
+        if x.is_cuda and self.dtype == torch.bfloat16:
+            ks = [km]
+            for i, enc in enumerate(self.encoders):
+                ks += [k1 if (i == 0 and k1 is not None) else enc.conv1.conv.kernel, enc.conv2.conv.kernel]
+            ks += [self.bottleneck1.conv.kernel, self.bottleneck2.conv.kernel]
+            for dec in self.decoders:
+                ks += [dec.conv1.conv.kernel, dec.conv2.conv.kernel]
+            packs = ops.conv3d_prepack([k.detach() for k in ks])
+        pk = (lambda j: packs[j]) if packs is not None else (lambda j: None)
+        x = ops.conv3d(x.to(self.patch_mixer.dtype), km, bm, pack=pk(0))
         skips, joints = [], []
         for i, enc in enumerate(self.encoders):
             c = enc.conv2.norm.scale.shape[0]
@@ -156,10 +168,11 @@ class UNet(nn.Module):
                 # the decoder at this level will read concat([up, skip]): allocate that buffer now and let the encoder's
                 # last kernel write the skip straight into its upper channel half
                 joint = torch.empty((*x.shape[:-1], 2 * c), dtype=self.dtype, device=x.device)
-            x, skip = enc(x, k1 if i == 0 else None, None if joint is None else joint[..., c:])
+            x, skip = enc(x, k1 if i == 0 else None, None if joint is None else joint[..., c:], packs=(pk(1 + 2 * i), pk(2 + 2 * i)))
             skips.append(skip)
             joints.append(joint)
-        x = self.bottleneck2(self.bottleneck1(x))
-        for dec, skip, joint in zip(self.decoders, reversed(skips), reversed(joints)):
-            x = dec(x, skip, joint)
+        nb = 1 + 2 * len(self.encoders)
+        x = self.bottleneck2(self.bottleneck1(x, pack=pk(nb)), pack=pk(nb + 1))
+        for j, (dec, skip, joint) in enumerate(zip(self.decoders, reversed(skips), reversed(joints))):
+            x = dec(x, skip, joint, packs=(pk(nb + 2 + 2 * j), pk(nb + 3 + 2 * j)))
         return self.final_conv(x)
