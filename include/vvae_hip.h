@@ -144,7 +144,8 @@ int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, 
  * inner = 1: sequences contiguous (A,T,C).  inner = hw: tensors are (b,t,hw,C), sequence a = b*hw+i strides over frames
  * (no transpose copies around the temporal half of FactoredAttention). */
 int vvae_temporal_attn_fast_supported(int T, int D, int ld, int ldo, int dtype);
-int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D);
+int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D, int dtype);
+int vvae_temporal_attn_mfma_enable(int on);   /* test hook: 0 = keep bf16 / T = 16 / head_dim 64 on the VALU kernels (default 1: matrix cores) */
 int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, int ldo, float* lse, const float* q_scale,
                                 const float* k_scale, const float* cos_table, const float* sin_table, const uint8_t* mask,
                                 int mask_div, int inner, int A, int T, int heads, int D, float eps, int dtype, void* stream);
@@ -218,10 +219,6 @@ int vvae_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, 
  * are host arrays of device pointers / ints. */
 int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C,
                               float* const* db, const int* M, const int* N, int n, int K, void* stream);
-/* 1 if the products (in this order) can be dealt to the 8 XCDs as WHOLE products (tiles that share an operand panel then walk K
- * side by side behind one L2; a product cut by an XCD boundary fetches the shared panels twice): the grouping policy of the caller
- * closes a group when adding a product would make this 0.  vvae_gemm_tn_grouped_bf16 itself accepts any list. */
-int vvae_gemm_tn_grouped_plan(const int* M, const int* N, int n);
 int vvae_gemm_tn_use_big_tiles(int on);   /* test hook: 0 = 128x128 kernel for every shape */
 
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam) at train/rl_nonadversarial.py:248-251. ---- */

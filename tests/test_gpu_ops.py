@@ -998,3 +998,53 @@ def test_xor_lane_exchange_selftest(dev, o):
     idx = torch.arange(n, device=dev) ^ o
     assert torch.equal(y, x[idx])
     assert torch.equal(yd, x[idx].double() * 1.000000001)
+
+
+@pytest.mark.parametrize("a,heads,inner,masked", [(6, 8, 1, True), (5, 3, 1, False), (8, 8, 4, True), (12, 2, 6, False)])
+def test_temporal_attention_matrix_core_kernels(dev, a, heads, inner, masked):
+    """bf16, T = 16, head_dim 64 (the production temporal shape) runs on the matrix-core kernels (attn_temporal_mfma.hip): against
+    the oracle, and against the VALU kernels it replaces (test hook), contiguous and strided (FactoredAttention's (b, t, hw, c))
+    sequence layouts, item counts that do not fill the last workgroup, shared mask rows."""
+    ops = _ops()
+    from video_vae_amd._lib import lib
+    t, d, dtype = 16, 64, torch.bfloat16
+    bsz = a // inner
+    shape = (a, t, 3 * heads * d) if inner == 1 else (bsz, t, inner, 3 * heads * d)
+    qkv = rnd(shape, 19).to(dtype).float()
+    qs = 1 + 0.2 * rnd((d,), 20); ks = 1 + 0.2 * rnd((d,), 21)
+    go = rnd(shape[:-1] + (heads * d,), 22).to(dtype).float()
+    nm = a // 2 if inner > 1 else a                                   # strided case: two sequences share a mask row (mask_div = 2)
+    mask = None
+    if masked:
+        lens = torch.tensor([max(1, t - (i * 5) % t) for i in range(nm)])
+        mask = (torch.arange(t)[None, :] < lens[:, None])
+    cos, sin = OL.rope_tables(d, 64)
+    # oracle on (a, t, c) sequences
+    seq = (lambda z: z) if inner == 1 else (lambda z: z.permute(0, 2, 1, 3).reshape(a, t, -1))
+    unseq = (lambda z: z) if inner == 1 else (lambda z: z.reshape(bsz, inner, t, -1).permute(0, 2, 1, 3))
+    xo = qkv.clone().requires_grad_(True); qso = qs.clone().requires_grad_(True); kso = ks.clone().requires_grad_(True)
+    mo = None
+    if masked:
+        mo = mask.repeat_interleave(a // nm, dim=0).reshape(a, 1, 1, t)
+    yo = unseq(_attn_ref(seq(xo), qso, kso, mo, heads, 64, dtype))
+    yo.backward(go)
+    m8 = mask.to(torch.uint8).to(dev) if masked else None
+
+    def run(mfma):
+        lib().vvae_temporal_attn_mfma_enable(1 if mfma else 0)
+        try:
+            xg = qkv.to(dev, dtype).requires_grad_(True); qsg = qs.to(dev).requires_grad_(True); ksg = ks.to(dev).requires_grad_(True)
+            yg = ops.temporal_attention_core(xg, qsg, ksg, cos.to(dev), sin.to(dev), m8, a // nm, heads, inner=inner)
+            yg.backward(go.to(dev, dtype))
+            return yg.detach(), xg.grad, qsg.grad, ksg.grad
+        finally:
+            lib().vvae_temporal_attn_mfma_enable(1)
+    new, old = run(True), run(False)
+    for got in (new, old):
+        assert_close(got[0], yo, rtol=3e-2, atol=3e-2, what="out")
+        assert_close_scaled(got[1], xo.grad, rel=5e-2, what="dqkv")
+        assert_close_scaled(got[2], qso.grad, rel=5e-2, what="dq_scale")
+        assert_close_scaled(got[3], kso.grad, rel=5e-2, what="dk_scale")
+    # the two implementations agree with each other much more closely than either is required to agree with the oracle
+    assert_close(new[0], old[0], rtol=2e-2, atol=2e-2, what="out, matrix-core vs VALU")
+    assert_close_scaled(new[1], old[1], rel=3e-2, what="dqkv, matrix-core vs VALU")

@@ -309,44 +309,6 @@ def test_bench_self_launch_relays_rank0_line(tmp_path):
     assert bad.returncode != 0 and "rank failed" in bad.stderr
 
 
-def test_grouped_weight_gradient_plan_keeps_products_whole():
-    """The grouped dense weight-gradient launch deals WHOLE products to the 8 XCDs (tiles that share an operand panel then walk K
-    behind one L2).  Host logic only: the planner accepts the production sequence in launches of 8 half-layers and refuses lists
-    that cannot be cut that way (the kernel then falls back to an even split)."""
-    from video_vae_amd._lib import lib
-    from video_vae_amd import ops
-    l = lib()
-
-    def plan(items):
-        n = len(items)
-        IA = ctypes.c_int * n
-        return l.vvae_gemm_tn_grouped_plan(IA(*[m for m, _ in items]), IA(*[k for _, k in items]), n)
-    half = [(1536, 768), (768, 1536), (512, 768), (768, 1536)]           # mlp2, mlp1, out-proj, qkv: 18 + 18 + 6 + 18 tiles
-    assert plan(half * 8) == 1                                             # 480 tiles = 8 shares of 60
-    assert plan(half * 8 + [(512, 768)]) == 0                              # 486 tiles: two rounds, but a 9th share of whole products
-    assert plan([(2560, 2560)]) == 0                                       # one product of 100 tiles cannot stay whole
-    assert plan([(768, 768)]) == 1
-    assert plan([(300, 256)]) == 0                                         # not a multiple of the tile
-    # the queue policy built on it: every launch is a plannable prefix, nothing is lost
-    launches = []
-    saved = ops.flush_wgrad
-    ops.flush_wgrad = lambda items, opt, tiles, k: launches.append(list(items))
-    try:
-        q = ops._WgradQueue(None)
-        keep = []
-        for m, n in [(768, 3072), (768, 768)] + half * 42 + [(768, 768)]:
-            kern = object()
-            keep.append(kern)
-            q.append((torch.empty((0, m)), torch.empty((0, n)), kern, None))
-        q.flush()
-    finally:
-        ops.flush_wgrad = saved
-    assert sum(len(g) for g in launches) == 2 + 4 * 42 + 1
-    assert all(ops._WgradQueue._plannable(g) for g in launches)
-    assert all(ops._WgradQueue._tiles(g) <= ops.GROUP_TILES for g in launches)
-    assert len(launches) <= 7
-
-
 def test_library_has_no_packed_fp32_valu_instructions():
     """Build hygiene that a correctness finding hangs on: with another process sharing the GPU, compiler-formed
     packed fp32 VALU ops (v_pk_add_f32 with an op_sel broadcast, in layernorm_fwd_kernel) dropped their subtraction in lanes 48-63

@@ -13,6 +13,15 @@
 //   * q/k-norm scale gradients are written as per-workgroup partials (summed by the caller): deterministic.
 #include "attn_rows.hpp"
 
+// matrix-core form for bf16, head_dim 64, T = 16 (attn_temporal_mfma.hip)
+int tmfma_supported(int T, int D, int ld, int ldo, int dtype);
+int tmfma_bwd_rows(long items);
+int tmfma_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const float* qs, const float* ks, const float* cosT, const float* sinT,
+              const uint8_t* mask, int mask_div, int inner, int A, int heads, float eps, hipStream_t s);
+int tmfma_bwd(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse, void* dqkv, int lddq,
+              const float* qs, const float* ks, const float* cosT, const float* sinT, const uint8_t* mask, int mask_div, int inner,
+              float* part, int A, int heads, float eps, hipStream_t s);
+
 namespace {
 
 struct FAttnDims { int A, T, heads, mask_div; float eps; long items; int inner; };
@@ -334,10 +343,12 @@ bool fast_ok(int T, int D, int ld, int ldo, int dtype)
 // 1 if the lane-per-frame kernels take this shape (else callers use the generic vvae_temporal_attn_fwd/_bwd).
 extern "C" int vvae_temporal_attn_fast_supported(int T, int D, int ld, int ldo, int dtype) { return fast_ok(T, D, ld, ldo, dtype) ? 1 : 0; }
 
-// Workgroups (= rows of the dscale partial buffer, each 2*D floats: [dq_scale | dk_scale]) for this shape.
-extern "C" int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D)
+// Rows of the dscale partial buffer (each 2*D floats: [dq_scale | dk_scale]) vvae_temporal_attn_bwd_fast writes for this shape:
+// one per workgroup of the VALU kernels, one per persistent wave of the matrix-core kernels (bf16, D = 64, T = 16).
+extern "C" int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D, int dtype)
 {
     if (T < 1 || T > 64 || D < 1) return 0;
+    if (tmfma_supported(T, D, 8, 8, dtype)) return tmfma_bwd_rows((long)A * heads);
     return ceil_div((long)A * heads, 64 / (T * pick_lpr(T, D)));
 }
 
@@ -352,6 +363,8 @@ extern "C" int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, i
         return VVAE_ERR_BAD_ARG;
     FAttnDims d{A, T, heads, mask_div, eps, (long)A * heads, inner};
     hipStream_t s = (hipStream_t)stream;
+    if (tmfma_supported(T, D, ld, ldo, dtype) && (!mask || ((uintptr_t)mask % 4) == 0))
+        return tmfma_fwd(qkv, ld, out, ldo, lse, q_scale, k_scale, cos_table, sin_table, mask, mask_div, inner, A, heads, eps, s);
     FATTN_DISPATCH(launch_fwd, qkv, ld, out, ldo, lse, q_scale, k_scale, cos_table, sin_table, mask, d, s);
 }
 
@@ -368,5 +381,8 @@ extern "C" int vvae_temporal_attn_bwd_fast(const void* qkv, int ld, const void* 
         ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16)) return VVAE_ERR_BAD_ARG;
     FAttnDims d{A, T, heads, mask_div, eps, (long)A * heads, inner};
     hipStream_t s = (hipStream_t)stream;
+    if (tmfma_supported(T, D, ld, ldo, dtype) && tmfma_supported(T, D, lddq, lddo, dtype) && (!mask || ((uintptr_t)mask % 4) == 0))
+        return tmfma_bwd(qkv, ld, out, ldo, dout, lddo, lse, dqkv, lddq, q_scale, k_scale, cos_table, sin_table, mask, mask_div, inner,
+                         dscale_part, A, heads, eps, s);
     FATTN_DISPATCH(launch_bwd, qkv, ld, out, ldo, dout, lddo, lse, dqkv, lddq, q_scale, k_scale, cos_table, sin_table, mask, dscale_part, d, s);
 }

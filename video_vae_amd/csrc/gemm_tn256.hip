@@ -195,21 +195,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(const bf16_t* __rest
 // once, straight into its parameter's slot of the optimizer's flat gradient buffer.
 struct GroupProb { const bf16_t* A; const bf16_t* B; float* C; float* db; int M, N, lda, ldb, tiles_m, tiles_n, tile_start; };
 constexpr int GROUP_MAX = 64;
-// xcd_start: the logical tiles [xcd_start[x], xcd_start[x + 1]) run on the workgroups with blockIdx % 8 == x (one XCD under the
-// round-robin placement the dispatcher is observed to use: a speed assumption only, any placement gives the same result).
-struct GroupArgs { GroupProb p[GROUP_MAX]; int nprob, K; int xcd_start[9]; };        // ~3.6 KB of kernel arguments
+struct GroupArgs { GroupProb p[GROUP_MAX]; int nprob, K; };        // 3 KB of kernel arguments
 
 // Which tiles share an L2.  An operand panel (256 channels x all K tokens = 8 MB at K = 16 384) is far larger than an XCD's 4 MB L2,
-// so two tiles share a panel's fetches only while they walk K side by side on the same XCD.  Tiles take equal time, so an XCD runs
-// its share in rounds of 32 (one per CU).  A product whose tiles are cut by a share or round boundary fetches the panels both parts
-// touch twice: round 1's even split cut ~2 of every 3.5 products at a cost of 5-6 of their 9 panels (1.56x the algorithmic bytes
-// by the counters).  So: (a) every XCD gets WHOLE products (plan_shares), (b) inside a product the shorter tile dimension runs
-// fastest, so the one cut a share still has (its round boundary) re-fetches min(tiles_m, tiles_n) panels (+1), not max.
+// so two tiles share a panel's fetches only while they walk K side by side on the same XCD.  Consecutive logical tiles go to one
+// XCD (64 of a 512-tile launch, run in two rounds of 32); a product cut by an XCD or round boundary fetches the panels both parts
+// touch twice.  Inside a product the SHORTER tile dimension runs fastest, so such a cut re-fetches min(tiles_m, tiles_n) (+1)
+// panels instead of max(...) (round 1 ran tm-major: 5-6 of a 3 x 6 product's 9 panels per cut, 1.56x the algorithmic bytes).
+// Tried and dropped: dealing WHOLE products to the XCDs (shares of 18 + 18 + 6 + 18 = 60 tiles): 1.8 % faster per round, but the
+// two rounds then carry 480 tiles instead of 512 -- a net 4 % loss, plus a 171-tile remainder launch per step.
 __global__ __launch_bounds__(512, 1) void gemm_tn256_grouped_kernel(GroupArgs g)
 {
-    const int xcd = blockIdx.x & 7;
-    const int L = g.xcd_start[xcd] + (int)(blockIdx.x >> 3);
-    if (L >= g.xcd_start[xcd + 1]) return;                                       // this XCD's share is shorter than the longest
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     int pi = 0;
     for (int i = 1; i < g.nprob; ++i) pi = L >= g.p[i].tile_start ? i : pi;      // uniform scan (tile_start ascending)
     const GroupProb& P = g.p[pi];
@@ -218,51 +216,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_grouped_kernel(GroupArgs g)
     if (P.tiles_m <= P.tiles_n) { tn = tile / P.tiles_m; tm = tile - tn * P.tiles_m; }
     else { tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n; }
     tn256_tile(P.A, P.B, P.lda, P.ldb, tm * BM, tn * BN, 0, g.K / KS, P.C, P.N, (P.db && tm == 0) ? P.db : nullptr);
-}
-
-// Cut the tile list (ntiles[i] tiles per product, in order) into 8 XCD shares of whole, consecutive products.  A share may hold
-// at most `cap` tiles = what an XCD's 32 CUs run in the number of rounds the launch needs anyway; among the cuts that respect it the
-// one with the smallest largest share is taken (fill-to-B greedy, B found by bisection: the classic linear partition).  Returns 1
-// and fills start[0..8] if such a cut exists, else 0 (the caller then splits the tile list evenly, products cut where they fall).
-static int fill_shares(const int* ntiles, int n, int bound, int* start)
-{
-    int x = 0, used = 0, at = 0;
-    if (start) start[0] = 0;
-    for (int i = 0; i < n; ++i) {
-        const int t = ntiles[i];
-        if (t > bound) return 9;
-        if (used + t > bound) {
-            if (++x >= 8) return 9;
-            if (start) start[x] = at;
-            used = 0;
-        }
-        used += t;
-        at += t;
-    }
-    if (start) for (int k = x + 1; k <= 8; ++k) start[k] = at;
-    return x + 1;
-}
-
-int plan_shares(const int* ntiles, int n, int* start)
-{
-    int total = 0, biggest = 0;
-    for (int i = 0; i < n; ++i) { total += ntiles[i]; biggest = ntiles[i] > biggest ? ntiles[i] : biggest; }
-    if (total <= 0) return 0;
-    const int rounds = (total + 255) / 256, cap = 32 * rounds;
-    if (fill_shares(ntiles, n, cap, nullptr) > 8) return 0;
-    int lo = biggest > (total + 7) / 8 ? biggest : (total + 7) / 8, hi = cap;        // smallest bound that still needs <= 8 shares
-    while (lo < hi) {
-        const int mid = (lo + hi) / 2;
-        if (fill_shares(ntiles, n, mid, nullptr) <= 8) hi = mid; else lo = mid + 1;
-    }
-    fill_shares(ntiles, n, lo, start);
-    return 1;
-}
-
-void even_shares(int total, int* start)
-{
-    const int q8 = total >> 3, r8 = total & 7;
-    for (int x = 0; x <= 8; ++x) start[x] = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
 }
 
 // splits so that tiles x splits ~ one workgroup per CU, each with at least 8 k-steps
@@ -301,7 +254,7 @@ int launch(const void* A, int lda, const void* B, int ldb, float* slab, float* s
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_grouped(const GroupArgs& g, int max_share, hipStream_t s)
+int launch_grouped(const GroupArgs& g, int total_tiles, hipStream_t s)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -309,7 +262,7 @@ int launch_grouped(const GroupArgs& g, int max_share, hipStream_t s)
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3(8 * max_share), dim3(512), LDS_BYTES, s, g);
+    hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3(total_tiles), dim3(512), LDS_BYTES, s, g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -326,30 +279,13 @@ extern "C" int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, c
     if (!A || !lda || !B || !ldb || !C || !db || !M || !N || n <= 0 || n > tn256::GROUP_MAX || K <= 0 || K % tn256::KS) return VVAE_ERR_BAD_ARG;
     tn256::GroupArgs g;
     g.nprob = n; g.K = K;
-    int tiles = 0, nt[tn256::GROUP_MAX];
+    int tiles = 0;
     for (int i = 0; i < n; ++i) {
         if (!A[i] || !B[i] || !C[i] || !tn256::supported(M[i], N[i], K, lda[i], ldb[i]) || ((uintptr_t)A[i] % 16) || ((uintptr_t)B[i] % 16) ||
             ((uintptr_t)C[i] % 16)) return VVAE_ERR_BAD_ARG;
         g.p[i] = tn256::GroupProb{(const bf16_t*)A[i], (const bf16_t*)B[i], C[i], db[i], M[i], N[i], lda[i], ldb[i], M[i] / tn256::BM,
                                   N[i] / tn256::BN, tiles};
-        nt[i] = (M[i] / tn256::BM) * (N[i] / tn256::BN);
-        tiles += nt[i];
+        tiles += (M[i] / tn256::BM) * (N[i] / tn256::BN);
     }
-    if (!tn256::plan_shares(nt, n, g.xcd_start)) tn256::even_shares(tiles, g.xcd_start);
-    int max_share = 0;
-    for (int x = 0; x < 8; ++x) max_share = g.xcd_start[x + 1] - g.xcd_start[x] > max_share ? g.xcd_start[x + 1] - g.xcd_start[x] : max_share;
-    return tn256::launch_grouped(g, max_share, (hipStream_t)stream);
-}
-
-// 1 if the products (M_i x N_i, in this order) can be dealt to the 8 XCDs as whole products within the rounds the launch needs
-// anyway (see plan_shares): the caller's grouping policy closes a group when adding a product would make this 0.
-extern "C" int vvae_gemm_tn_grouped_plan(const int* M, const int* N, int n)
-{
-    if (!M || !N || n <= 0 || n > tn256::GROUP_MAX) return 0;
-    int nt[tn256::GROUP_MAX], start[9];
-    for (int i = 0; i < n; ++i) {
-        if (M[i] <= 0 || N[i] <= 0 || M[i] % tn256::BM || N[i] % tn256::BN) return 0;
-        nt[i] = (M[i] / tn256::BM) * (N[i] / tn256::BN);
-    }
-    return tn256::plan_shares(nt, n, start);
+    return tn256::launch_grouped(g, tiles, (hipStream_t)stream);
 }

@@ -701,7 +701,7 @@ class _TemporalAttn(torch.autograd.Function):
         dt = _dt(qkv)
         dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
         if fast:
-            nblk = lib().vvae_temporal_attn_fast_blocks(a, t, heads, d)
+            nblk = lib().vvae_temporal_attn_fast_blocks(a, t, heads, d, dt)
             part = torch.empty((nblk, 2 * d), dtype=torch.float32, device=qkv.device)
             nbytes = a * t * heads * d * 8 * qkv.element_size()
             check(_launch(f"temporal_attn_bwd T{t} D{d}", nbytes, 10 * a * heads * t * t * d, "tattn_bwd_fast",
@@ -1249,42 +1249,15 @@ class _WgradQueue:
         x2, dy2, kernel, bias = item
         self.claim(kernel)
         t = (x2.shape[1] // 256) * (dy2.shape[1] // 256)
-        if self.items and x2.shape[0] != self.k:
+        if self.items and (x2.shape[0] != self.k or len(self.items) == GROUP_MAX or self.tiles + t > GROUP_TILES):
             self.flush()
-        elif self.items and (len(self.items) == GROUP_MAX or self.tiles + t > GROUP_TILES):
-            self.flush(final=False)
         self.items.append(item); self.tiles += t; self.k = x2.shape[0]
 
-    @staticmethod
-    def _tiles(items):
-        return sum((x2.shape[1] // 256) * (dy2.shape[1] // 256) for x2, dy2, _, _ in items)
-
-    @staticmethod
-    def _plannable(items):
-        """Can these products be dealt to the 8 XCDs as whole products (vvae_gemm_tn_grouped_plan)?"""
-        n = len(items)
-        IA = ctypes.c_int * n
-        return lib().vvae_gemm_tn_grouped_plan(IA(*[x2.shape[1] for x2, _, _, _ in items]), IA(*[dy2.shape[1] for _, dy2, _, _ in items]), n) == 1
-
-    def flush(self, final=True):
-        """Launch the parked products.  A launch takes the longest prefix of the queue that the kernel can deal to the XCDs as whole
-        products (tiles sharing an operand panel then run behind one L2: see gemm_tn256.hip); what is cut off stays parked for
-        the next launch unless this is the final flush."""
-        while self.items:
-            items, k = self.items, self.k
-            n = len(items)
-            if self._tiles(items) >= GROUP_MIN_TILES:
-                for m in range(n, max(n - 8, 0), -1):
-                    if self._tiles(items[:m]) < GROUP_MIN_TILES:
-                        break
-                    if self._plannable(items[:m]):
-                        n = m
-                        break
-            head, self.items = items[:n], items[n:]
-            self.tiles = self._tiles(self.items)
-            flush_wgrad(head, self.opt, self._tiles(head), k)
-            if not final:
-                break
+    def flush(self):
+        items, tiles, k = self.items, self.tiles, self.k
+        self.items, self.tiles = [], 0
+        if items:
+            flush_wgrad(items, self.opt, tiles, k)
 
 
 def wgrad_deferrable(x2, dy2, kernel, bias):
