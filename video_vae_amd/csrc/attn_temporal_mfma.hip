@@ -16,8 +16,9 @@
 //   * probabilities are normalised in fp32 and rounded to bf16 BEFORE the PV product, exactly where the reference casts them
 //     (jax.nn.dot_product_attention: softmax in fp32, probs cast to the value dtype);
 //   * backward recomputes both orientations of the score tile (S^T for dQ, S for dK / dV: two extra 16 x 16 x 64 products instead
-//     of any transpose through LDS), 20 MFMAs per (sequence, head) in all; waves are persistent over items so the q/k-norm scale
-//     gradients leave as one partial row per wave (<= 8192 rows), folded by the caller in fixed order: deterministic.
+//     of any transpose through LDS), 20 MFMAs per (sequence, head) in all; the q/k-norm scale gradients of a workgroup's four items
+//     are summed over frames with DPP row adds and over the waves through LDS and leave as ONE partial row per workgroup, folded by
+//     the caller in fixed order: deterministic.
 #include "common.hpp"
 
 namespace tmfma {
@@ -259,13 +260,13 @@ __device__ __forceinline__ void store_cols(bf16_t* __restrict__ row, int p, cons
     }
 }
 
-// part: fp32 (4 * gridDim.x, 2 * D): one row per wave, [dq_scale | dk_scale], written once at the end (zeros for idle waves).
-__global__ __launch_bounds__(256, 3) void tattn16_bwd_mfma(const bf16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ out, int ldo,
-                                                       const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ lse,
-                                                       bf16_t* __restrict__ dqkv, int lddq, const float* __restrict__ q_scale,
-                                                       const float* __restrict__ k_scale, const float* __restrict__ cosT,
-                                                       const float* __restrict__ sinT, const uint8_t* __restrict__ mask,
-                                                       float* __restrict__ part, Dims d)
+// part: fp32 (gridDim.x, 2 * D): one row per workgroup (4 items), [dq_scale | dk_scale].
+__global__ __launch_bounds__(256, 4) void tattn16_bwd_mfma(const bf16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ out, int ldo,
+                                                          const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int lddq, const float* __restrict__ q_scale,
+                                                          const float* __restrict__ k_scale, const float* __restrict__ cosT,
+                                                          const float* __restrict__ sinT, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ part, Dims d)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * (3 * IMG + 64)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -277,18 +278,15 @@ __global__ __launch_bounds__(256, 3) void tattn16_bwd_mfma(const bf16_t* __restr
     float* dlds = reinterpret_cast<float*>(base + 3 * IMG);       // delta[16]
     const int HD = d.heads * D;
     const float scale = 0.125f;
-    float accq[4][4], acck[4][4];                 // scale-gradient partials of this wave (column layout), summed over its items
+    float accq[4][4], acck[4][4];                 // this item's scale-gradient contributions (column layout)
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { accq[tl][r] = 0.f; acck[tl][r] = 0.f; }
 
-    const long nwaves = (long)gridDim.x * 4;
-    for (long item = (long)blockIdx.x * 4 + wave; item < d.items; item += nwaves) {
-        // the tables are re-read per item (L1 hits) instead of living in 64 registers across the loop: the pointers are laundered so
-        // that the compiler cannot hoist the loads (the kernel must stay under 128 VGPRs: 4 waves per SIMD)
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item < d.items) {                                          // wave-uniform: every lane of a working wave is active (tr reads)
         const float* ct = cosT; const float* st_ = sinT; const float* qsp = q_scale; const float* ksp = k_scale;
-        asm volatile("" : "+s"(ct), "+s"(st_), "+s"(qsp), "+s"(ksp));
         const int a = (int)(item / d.heads), h = (int)(item % d.heads);
         const long tok = token_of(d, a, t);
         const bf16_t* g = qkv + tok * ld + h * D;
@@ -413,20 +411,24 @@ __global__ __launch_bounds__(256, 3) void tattn16_bwd_mfma(const bf16_t* __restr
                 for (int r = 0; r < 4; ++r) acck[tl][r] += contrib[tl][r];
         }
     }
-    // scale gradients: sum over the 16 frames (lanes t of a group), one row per wave
-    float* prow = part + ((long)blockIdx.x * 4 + wave) * 2 * D;
+    // scale gradients: sum over the 16 frames (DPP row adds), then over the workgroup's four items through LDS: one row per workgroup
+    __syncthreads();                                               // every wave is done with its images
+    float* red = reinterpret_cast<float*>(smem);                   // [wave][2 * D]
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float a = butterfly_sum<8, 1>(accq[tl][r]), b = butterfly_sum<8, 1>(acck[tl][r]);
-            if (t == 0) { prow[16 * tl + 4 * p + r] = a; prow[D + 16 * tl + 4 * p + r] = b; }
+            if (t == 0) { red[wave * 2 * D + 16 * tl + 4 * p + r] = a; red[wave * 2 * D + D + 16 * tl + 4 * p + r] = b; }
         }
+    __syncthreads();
+    if (threadIdx.x < 2 * D)
+        part[(long)blockIdx.x * 2 * D + threadIdx.x] = (red[threadIdx.x] + red[2 * D + threadIdx.x]) + (red[4 * D + threadIdx.x] + red[6 * D + threadIdx.x]);
 }
 
 int g_enable = 1;
 
-inline int bwd_blocks(long items) { long b = (items + 3) / 4; if (b > 2048) b = 2048; return (int)(b < 1 ? 1 : b); }
+inline int bwd_blocks(long items) { return (int)((items + 3) / 4); }
 
 bool shape_ok(int T_, int D_, int ld, int ldo, int dtype) {
     return g_enable && dtype == VVAE_DT_BF16 && T_ == T && D_ == D && ld % 8 == 0 && ldo % 8 == 0;
@@ -443,7 +445,7 @@ extern "C" int vvae_temporal_attn_mfma_enable(int on)
 
 // internal entry points used by attn_temporal_fast.hip's dispatch (declared there)
 int tmfma_supported(int T, int D, int ld, int ldo, int dtype) { return tmfma::shape_ok(T, D, ld, ldo, dtype) ? 1 : 0; }
-int tmfma_bwd_rows(long items) { return 4 * tmfma::bwd_blocks(items); }
+int tmfma_bwd_rows(long items) { return tmfma::bwd_blocks(items); }
 
 int tmfma_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const float* qs, const float* ks, const float* cosT, const float* sinT,
               const uint8_t* mask, int mask_div, int inner, int A, int heads, float eps, hipStream_t s)

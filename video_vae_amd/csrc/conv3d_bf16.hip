@@ -933,8 +933,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         base = (long)(co / COB) * slab_floats + (long)taps * CIB * COB + co % COB;          // ci-sub 0
     }
     float s = 0.f;
-    if (base >= 0)
-        for (int b = bl; b < nblk; b += 8) s += slab[(long)b * nsub * slab_floats + base];
+    if (base >= 0) {
+        // the slabs sit in L2: this loop pays latency, so 8 loads are in flight per thread (same summation order)
+        const long stride = (long)nsub * slab_floats;
+        const float* p = slab + base;
+        int b = bl;
+        for (; b + 56 < nblk; b += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(b + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblk; b += 8) s += p[(long)b * stride];
+    }
     red[bl][el] = s;
     __syncthreads();
     if (bl == 0 && base >= 0) {
