@@ -21,7 +21,6 @@ tn.tuning_enable(True)
 tn.set_max_tuning_duration(30)
 tn.set_max_tuning_iterations(100)
 tn.set_filename(out, insert_device_ordinal=False)
-tn.write_file_on_exit(True)
 
 import video_vae_amd as V  # noqa: E402
 from video_vae_amd import loss as L, optim  # noqa: E402
@@ -41,5 +40,4 @@ for i in range(2):
     loss, _ = L.train_step(m, opt, video, mask, L.HPARAMS, 256, V.Rngs(3))
     torch.cuda.synchronize()
     print(f"step {i}: loss {float(loss):.4f}, {time.time() - t0:.1f} s", flush=True)
-tn.write_file(out)
-print(open(out).read())
+print('results so far:', len(tn.get_results()), 'entries; the file is written at exit', flush=True)
