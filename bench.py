@@ -104,6 +104,7 @@ def parse():
                          "-> H2D on a side stream) instead of a batch resident in HBM; the line reports the same metric")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames per clip of the bounded CPU sample")
     ap.add_argument("--cpu-clips", type=int, default=1, help="clips of the bounded CPU sample")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the CPU baseline leg may take (steps are cut to fit)")
     return ap.parse_args()
 
 
@@ -138,19 +139,54 @@ def cpu_model_name():
     return "unknown"
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask clipped by the cgroup CPU quota (a GPU box hands one GPU's share of
+    a large host to the job: os.cpu_count() reports the whole host there and oversubscribes the share many times over)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # cgroup v1
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    env = os.environ.get("VVAE_CPU_THREADS")
+    return max(1, int(env)) if env else n
+
+
 def cpu_baseline(args):
-    """the CPU oracle (a port of the reference's math: PyTorch CPU, fp32, oneDNN) on ALL host cores of the box, on
-    a bounded sample of the same workload: 3 warm-up + 5 timed steps, median.  ``value`` is the same metric as the GPU line --
-    frames/s of the whole train step (full-depth VideoVAE forward + recon/KL loss + backward + clip + Adam) -- on a clip cut
-    down in batch and frames so that the leg stays within ~30 s; the Conv3d UNet alone is timed beside it."""
+    """the CPU oracle (a port of the reference's math: PyTorch CPU, fp32, oneDNN) on all host cores this job may
+    use, on a bounded sample of the same workload: 3 warm-up + 5 timed steps, median.  ``value`` is the same metric as the GPU
+    line -- frames/s of the whole train step (full-depth VideoVAE forward + recon/KL loss + backward + clip + Adam) -- on a clip
+    cut down in batch and frames; the Conv3d UNet alone is timed beside it.  The leg is bounded in TIME as well: when the first
+    step shows that 3 + 5 steps would not fit ``--cpu-budget`` seconds, fewer are run and the protocol field says how many."""
     import statistics
     from oracle import loss as OLoss, model as OM, optim as OOpt, unet as OU
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     s, t, nb = args.size, args.cpu_frames, args.cpu_clips
     g = torch.Generator().manual_seed(0)
 
-    def timed(fn, warm=3, reps=5):
+    def timed(fn, budget):
+        t0 = time.perf_counter()
+        fn()
+        first = time.perf_counter() - t0                     # warm-up 1 (also pays one-time allocations)
+        warm, reps = 2, 5
+        if first * (warm + reps) > budget:
+            warm = 0 if first * 4 > budget else 1
+            reps = max(1, min(5, int(budget / max(first, 1e-3)) - warm))
         for _ in range(warm):
             fn()
         ts = []
@@ -158,7 +194,7 @@ def cpu_baseline(args):
             t0 = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t0)
-        return statistics.median(ts)
+        return statistics.median(ts), f"{warm + 1} warm-up + {reps} timed"
 
     # ---- whole train step, production depth
     cfg = OM.VAEConfig(**dict(PROD, height=s, width=s))
@@ -176,7 +212,7 @@ def cpu_baseline(args):
         loss.backward()
         clipped, _gn = OOpt.clip_by_global_norm({k: v.grad for k, v in pr.items()}, 1.0)
         state["p"] = adam.update({k: v.detach() for k, v in pr.items()}, clipped, 2e-5)
-    t_vae = timed(vae_step)
+    t_vae, proto_vae = timed(vae_step, 0.75 * args.cpu_budget)
     del p, adam, state
     # ---- the Conv3d UNet alone (the north-star kernels' CPU counterpart)
     pu = OU.init_unet(12, 16, 3, 3, seed=5, zero_final=False)
@@ -188,12 +224,13 @@ def cpu_baseline(args):
         for v in pu.values():
             v.grad = None
         OU.unet(pu, x).square().mean().backward()
-    t_unet = timed(unet_step)
+    t_unet, proto_unet = timed(unet_step, 0.25 * args.cpu_budget)
     return {"value": nb * t / t_vae, "unit": "frames/s", "cores": threads, "cpu_model": cpu_model_name(), "kind": "port",
-            "protocol": "3 warm-up + 5 timed steps, median; torch.set_num_threads(os.cpu_count())",
+            "host_logical_cpus": os.cpu_count(),
+            "protocol": f"{proto_vae} steps, median; torch.set_num_threads({threads}) = affinity mask clipped by the cgroup CPU quota",
             "sample": f"oracle full-depth VideoVAE train step (fwd + recon/KL loss + bwd + clip + Adam), fp32, {nb} clip(s) x {t} frames x "
                       f"{s}x{s}x3, median {t_vae:.2f} s/step on {threads} threads",
-            "unet_only": {"value": nb * t / t_unet, "unit": "frames/s",
+            "unet_only": {"value": nb * t / t_unet, "unit": "frames/s", "protocol": f"{proto_unet} steps, median",
                           "sample": f"oracle UNet fwd+bwd, fp32, {nb} clip(s) x {t} frames x {s}x{s}x12 features, median {t_unet:.2f} s/step"}}
 
 
@@ -208,7 +245,7 @@ def self_launch(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this pool
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for out in proc.stdout:                                     # ranks' stderr passes straight through
@@ -284,7 +321,7 @@ def main():
             from video_vae_amd import data as D
             clip_dir = tempfile.mkdtemp(prefix=f"vvae_bench_clips_r{rank}_")
             D.write_synthetic_clips(clip_dir, max(48, 4 * B), T + 4, S + 32, S + 32, seed=rank)
-            workers = max(2, min(8, (os.cpu_count() or 8) // max(1, world)))
+            workers = max(2, min(8, host_cores() // max(1, world)))
             host = D.create_batched_dataloader(clip_dir, batch_size=B, max_frames=T, resize=(S, S), crop_size=S, shuffle=True, seed=0,
                                                num_workers=workers, prefetch_size=4 * workers, drop_remainder=True, rank=rank,
                                                num_epochs=None, as_uint8=True)

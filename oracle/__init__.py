@@ -19,4 +19,4 @@ guarded by a self-consistency test in ``tests/test_oracle.py``.
 Every function cites the reference file:line it follows
 (paths relative to the reference checkout).
 """
-from . import nn, unet, layers, model, loss, optim  # noqa: F401
+from . import nn, unet, layers, model, loss, optim, perceptual  # noqa: F401

@@ -1,0 +1,102 @@
+"""The reference's video discriminator (train/classifier.py): oracle self-checks on the CPU, HIP path vs oracle on the GPU."""
+import pytest
+import torch
+
+from oracle import classifier as OC
+from util import assert_close, assert_close_scaled, grad_floor, rnd
+
+
+def test_spectral_norm_step_against_svd():
+    """One power-iteration step moves u towards the top right-singular vector; iterated to convergence sigma is the spectral norm
+    (Miyato et al. 2018, the algorithm classifier.py:31-52 cites) and kernel / sigma has spectral norm 1."""
+    k = rnd((3, 3, 3, 8, 16), 0)
+    u = rnd((1, 16), 1)
+    for _ in range(200):
+        ksn, u = OC.spectral_norm_kernel(k, u)
+    smax = torch.linalg.matrix_norm(k.reshape(-1, 16), ord=2)
+    assert_close(torch.linalg.matrix_norm(ksn.reshape(-1, 16), ord=2), torch.tensor(1.0), rtol=1e-4, atol=1e-4)
+    assert_close((k / ksn).flatten()[0], smax, rtol=1e-4, atol=1e-5)
+    # update_stats=False leaves u alone and still normalises with a v recomputed from it (classifier.py:47-49)
+    ksn2, u2 = OC.spectral_norm_kernel(k, u, update_stats=False)
+    assert torch.equal(u2, u)
+    assert_close(ksn2, ksn, rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_classifier_shapes_and_state():
+    """classifier.py:181-215 (the module's own smoke test): (b, t, h, w, c) -> (b, 1) for any clip length; u advances per call."""
+    p, st = OC.init_classifier(3, base_features=4, num_levels=2, seed=0)
+    assert set(st) == {k[:-6] + "u" for k in p if k.endswith("conv.kernel")}
+    for t in (2, 5):
+        out, st2 = OC.classifier(p, st, torch.rand(2, t, 16, 16, 3))
+        assert out.shape == (2, 1) and torch.isfinite(out).all()
+    assert all(not torch.equal(st2[k], st[k]) for k in st)
+    assert all(abs(float(torch.linalg.norm(v)) - 1) < 1e-5 for v in st2.values())
+
+
+def test_product_classifier_parameter_tree_matches_oracle():
+    import video_vae_amd as V
+    from video_vae_amd.classifier import Classifier
+    p, st = OC.init_classifier(3, base_features=4, num_levels=2, seed=0)
+    m = Classifier(3, base_features=4, num_levels=2, rngs=V.Rngs(0), dtype=torch.float32)
+    names = {k.replace(".conv.layer.", ".conv."): tuple(v.shape) for k, v in m.named_parameters()}
+    assert names == {k: tuple(v.shape) for k, v in p.items()}
+    assert {k: tuple(v.shape) for k, v in m.named_buffers()} == {k: tuple(v.shape) for k, v in st.items()}
+
+
+def _load(m, p, st, dev):
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            v.copy_(p[k.replace(".conv.layer.", ".conv.")])
+        for k, v in m.named_buffers():
+            v.copy_(st[k])
+    return m.to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_classifier_vs_oracle(dev, dtype):
+    """Logits, every parameter gradient (through sigma and the power iteration) and the updated u vs the oracle at (2, 4, 32, 32, 3),
+    base 16, two levels; a second call continues from the stored u."""
+    import video_vae_amd as V
+    from video_vae_amd.classifier import Classifier
+    p, st = OC.init_classifier(3, base_features=16, num_levels=2, seed=3)
+    for k in p:
+        if k.endswith("bias") or k.endswith("scale"):
+            p[k] = p[k] + 0.1 * rnd(p[k].shape, len(k))
+    x = torch.rand(2, 4, 32, 32, 3, generator=torch.Generator().manual_seed(1))
+    w = torch.tensor([[1.0], [-2.0]])
+
+    def oracle(dt):
+        pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        out, st1 = OC.classifier(pr, st, x, dtype=dt)
+        (out * w).sum().backward()
+        out2, st2 = OC.classifier(pr, st1, x, dtype=dt)
+        return out.detach(), {k: v.grad for k, v in pr.items()}, st1, out2.detach()
+
+    ref, gref, st1, ref2 = oracle(torch.float32)
+    m = _load(Classifier(3, base_features=16, num_levels=2, rngs=V.Rngs(0), dtype=dtype), p, st, dev)
+    out = m(x.to(dev))
+    assert out.shape == (2, 1)
+    (out.float() * w.to(dev)).sum().backward()
+    got_g = {k.replace(".conv.layer.", ".conv."): v.grad for k, v in m.named_parameters()}
+    for k, v in m.named_buffers():
+        assert_close(v, st1[k], rtol=1e-4, atol=1e-5, what=k)
+    out2 = m(x.to(dev))
+    if dtype == torch.float32:
+        assert_close(out, ref, rtol=1e-3, atol=1e-4, what="logits")
+        assert_close(out2, ref2, rtol=1e-3, atol=1e-4, what="logits, second call")
+        for k in gref:
+            assert_close_scaled(got_g[k], gref[k], rel=2e-3, what=k, floor=grad_floor(k, gref))
+    else:
+        from test_gpu_parity_r2 import check_bf16
+        emu, gemu, _, _ = oracle(torch.bfloat16)
+        report = []
+        check_bf16("logits", out, emu, ref, report)
+        for k in gref:
+            scale = float(gref[k[:-4] + "kernel"].abs().max()) if k.endswith("conv.bias") else None
+            check_bf16(k, got_g[k], gemu[k], gref[k], report, floor_scale=scale)
+        print(report)
+    # eval-style call: update_stats=False keeps u
+    before = {k: v.clone() for k, v in m.named_buffers()}
+    m(x.to(dev), update_stats=False)
+    assert all(torch.equal(v, before[k]) for k, v in m.named_buffers())

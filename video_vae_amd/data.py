@@ -22,6 +22,7 @@ files (.mp4 ...) are read through OpenCV when ``cv2`` is importable (it is not i
 reported as unreadable, i.e. the reference's zero-clip fallback).
 """
 import os
+import sys
 import queue
 import threading
 
@@ -134,7 +135,7 @@ class VideoDataSource:
 
     def __init__(self, base_dir):
         self.video_paths = list_video_files(base_dir)
-        print(f"Found {len(self.video_paths)} videos")
+        print(f"Found {len(self.video_paths)} videos", file=sys.stderr)      # the reference prints this (train/dataloader.py:268); stderr keeps stdout for results
 
     def __len__(self):
         return len(self.video_paths)

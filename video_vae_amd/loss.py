@@ -3,8 +3,8 @@
 ``loss_fn``        : train/rl_nonadversarial.py:100-186 (pair-doubled rl_model outputs, REINFORCE term).
 ``loss_fn_plain``  : train/legacy/training_loop_adversarial.py:90-124 (model.py outputs: MSE + selection + KL).
 The heavy reductions (masked MSE/MAE over the clip, KL over the latent) are fused HIP kernels; the per-sample
-scalar algebra stays in torch.  The VGG16 perceptual term needs remote weights and is out of scope: callers pass
-``perceptual_loss_fn=None`` (zeros), as the reference's CPU test does (claude_distributed/test_training_loop.py:71).
+scalar algebra stays in torch.  The VGG16 perceptual term is video_vae_amd/perceptual.py (``get_adversarial_perceptual_loss_fn``);
+``perceptual_loss_fn=None`` gives zeros, as the reference's CPU test does (claude_distributed/test_training_loop.py:71).
 """
 import torch
 from einops import rearrange, reduce, repeat
@@ -50,6 +50,8 @@ def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn
     per_sample_error, per_sample_MAE = ops.masked_mse_mae(video, reconstruction, output_mask, video_div=2)
     if perceptual_loss_fn is None:
         perceptual_loss = torch.zeros_like(per_sample_error)
+    elif getattr(perceptual_loss_fn, "takes_target_div", False):
+        perceptual_loss = perceptual_loss_fn(vgg_params, reconstruction, video, target_div=2)      # features of each clip once
     else:
         perceptual_loss = perceptual_loss_fn(vgg_params, reconstruction, video.repeat_interleave(2, dim=0))
 
