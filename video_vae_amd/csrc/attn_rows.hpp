@@ -147,4 +147,45 @@ __device__ __forceinline__ void rope_ln_bwd_row(float (&g)[D / LPR], float (&xh)
     }
 }
 
+// The two row transforms with scale / cos / sin already in registers (load_tab order: element i = channel ch(i, p)): a kernel
+// that issues every global load of a tile up front, before the first dependent instruction, uses these.
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void ln_rope_row_reg(float (&x)[D / LPR], float eps, const float (&sc)[D / LPR], const float (&cs)[D / LPR],
+                                                const float (&sn)[D / LPR]) {
+    using S = Slice<T_, D, LPR>;
+    xhat_row<S::DL, LPR, D>(x, eps);
+#pragma unroll
+    for (int i = 0; i < S::DL; ++i) x[i] = round_to<T_>(x[i] * sc[i]);
+#pragma unroll
+    for (int i = 0; i < S::HL; ++i) {
+        const float lo = x[i], hi = x[i + S::HL];
+        x[i] = round_to<T_>(round_to<T_>(lo * cs[i]) + round_to<T_>(-hi * sn[i]));
+        x[i + S::HL] = round_to<T_>(round_to<T_>(hi * cs[i + S::HL]) + round_to<T_>(lo * sn[i + S::HL]));
+    }
+}
+template <typename T_, int D, int LPR>
+__device__ __forceinline__ void rope_ln_bwd_row_reg(float (&g)[D / LPR], float (&xh)[D / LPR], float rstd, const float (&sc)[D / LPR],
+                                                    const float (&cs)[D / LPR], const float (&sn)[D / LPR]) {
+    using S = Slice<T_, D, LPR>;
+#pragma unroll
+    for (int i = 0; i < S::HL; ++i) {
+        const float lo = g[i], hi = g[i + S::HL];
+        g[i] = lo * cs[i] + hi * sn[i + S::HL];
+        g[i + S::HL] = hi * cs[i + S::HL] - lo * sn[i];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < S::DL; ++i) {
+        const float dxh = g[i] * sc[i];
+        s1 += dxh; s2 += dxh * xh[i];
+    }
+    s1 = lpr_sum<LPR>(s1) / D; s2 = lpr_sum<LPR>(s2) / D;
+#pragma unroll
+    for (int i = 0; i < S::DL; ++i) {
+        const float dy = g[i], x = xh[i];
+        g[i] = rstd * (dy * sc[i] - s1 - x * s2);
+        xh[i] = dy * x;
+    }
+}
+
 }  // namespace

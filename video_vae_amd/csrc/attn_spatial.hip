@@ -10,10 +10,20 @@
 //   * V^T fragments come from the row-major V image through ds_read_b64_tr_b16; K' fragments are plain ds_read_b128.  One XOR
 //     swizzle of the 16-byte chunk index, g(row) = ((row>>1)&1)<<2 | ((row>>3)&1)<<1 | ((row>>2)&1), is conflict-free for BOTH
 //     read shapes on 128-byte rows (the backward kernel reads every image both ways).
-//   * the Q fragment layout keeps a query row in two lanes (l, l^32), each with d = 16 ks + 8 kh + e: the rotate-half partner
-//     d + 32 is the same lane's ks + 2, so LayerNorm + RoPE run on the fragment registers (one cross-lane add for the statistics).
+//   * global memory is only touched in ROW layout (4 lanes per token row, 64 contiguous bytes per lane quad, attn_rows.hpp): the raw
+//     rows, the RoPE tables and the scale slices a phase needs are all requested before its first dependent instruction; MFMA
+//     fragments and accumulator tiles (lane = token, registers = channels: 8-byte pieces of 64 different rows per instruction if
+//     sent to memory as they are -- measured at a third of the kernel's time) cross over through a per-wave 2 KB scratch image.
+//   * the tile loops are software-pipelined by hand: the next tile's row fragments and this tile's transposed fragments are requested
+//     before the exponentials start; exp2 is the bare v_exp_f32 (arguments are <= 0).
 // Forward saves the base-2 log-sum-exp per query for the backward pass.
+// Where the time goes (tools/sattn_probe.py, A = 64, S = 256, 8 heads): every workgroup of the launch is resident at once, so the
+// phases run chip-wide in lock step -- staging and the tile epilogues at HBM rate, the tile loops with HBM idle.
 #include "attn_rows.hpp"
+
+#ifndef SATTN_PROBE          // tools/sattn_probe.py builds timing-only variants with phases cut out (results are garbage there)
+#define SATTN_PROBE 0
+#endif
 
 namespace {
 
@@ -29,36 +39,6 @@ struct SAttnDims { int A, S, H; float eps; };
 __device__ __forceinline__ int gsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
 
 __device__ __forceinline__ float xor32(float v) { return xor_lane<32>(v); }          // v_permlane32_swap: VALU only (common.hpp)
-
-// Fragment-layout row: lane (j = lane & 31, kh = lane >> 5) holds x[ks][e] = channel 16 ks + 8 kh + e of row j.
-// q/k-norm (bias-free LayerNorm, y = round(xhat * scale)) followed by RoPE, in place; same rounding points as attn_rows.hpp.
-__device__ __forceinline__ void ln_rope_frag(float (&x)[4][8], int kh, const float* __restrict__ scale, float eps,
-                                             const float* __restrict__ cosr, const float* __restrict__ sinr)
-{
-    float s = 0.f, ss = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s += x[ks][e]; ss += x[ks][e] * x[ks][e]; }
-    s += xor32(s); ss += xor32(ss);
-    const float mean = s / SD;
-    float var = ss / SD - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    const float rstd = rsqrtf(var + eps);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[ks][e] = round_to<bf16_t>((x[ks][e] - mean) * rstd * scale[16 * ks + 8 * kh + e]);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int cl = 16 * ks + 8 * kh + e, ch = cl + 32;
-            const float lo = x[ks][e], hi = x[ks + 2][e];
-            x[ks][e] = round_to<bf16_t>(round_to<bf16_t>(lo * cosr[cl]) + round_to<bf16_t>(-hi * sinr[cl]));
-            x[ks + 2][e] = round_to<bf16_t>(round_to<bf16_t>(hi * cosr[ch]) + round_to<bf16_t>(lo * sinr[ch]));
-        }
-}
 
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8])
 {
@@ -80,9 +60,6 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigne
 
 // byte offset of (row, 16-byte chunk c) in a swizzled image
 __device__ __forceinline__ int img_off(int row, int c) { return row * SROW + ((c ^ gsw(row)) << 4); }
-// byte offset of the 8 bytes a transposed read takes at (row, 16-channel block cb (0..3), 4-channel group p)
-__device__ __forceinline__ int img_off_tr(int row, int cb, int p) { return row * SROW + ((((2 * cb + (p >> 1)) ^ gsw(row))) << 4) + (p & 1) * 8; }
-
 // Lane-constant parts of the fragment addresses (the swizzle term of a row depends on row bits 1..3 only, which a 32-row block
 // offset never touches): a row fragment is img + blk * 32 * SROW + row[ks]; a transposed fragment of the 16-row group u of
 // block blk and channel tile dt is the pair img + (blk * 32 + 16 u) * SROW + tr[dt][0 | 1] (token rows +0..3 and +8..11).
@@ -108,37 +85,138 @@ struct FragAddr {
     }
 };
 
-// Stage rows [0, S) of one head into a swizzled LDS image: K path applies k_norm + RoPE, V path copies.  256 threads, 4 lanes per
-// row (attn_rows.hpp slices: lane p owns channels [8p, 8p+8) and [32+8p, 32+8p+8) = chunks p and 4+p).
-template <bool NORM>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, long tok0, int ld, unsigned char* img, int S,
-                                           const float* __restrict__ scale, float eps, const float* __restrict__ cosT,
-                                           const float* __restrict__ sinT)
-{
-    const int p = threadIdx.x & 3;
-    for (int row = threadIdx.x >> 2; row < S; row += (int)(blockDim.x >> 2)) {
-        float x[16];
-        load_row<bf16_t, SD, 4>(src + (tok0 + row) * ld, p, x);
-        if (NORM) ln_rope_row<bf16_t, SD, 4>(x, p, scale, eps, cosT + (long)row * SD, sinT + (long)row * SD);
-        float lo[8], hi[8];
+// Staging of one head's rows into swizzled LDS images, 4 lanes per row (attn_rows.hpp slices: lane p owns channels [8p, 8p+8) and
+// [32+8p, 32+8p+8) = 16-byte chunks p and 4+p).  In two steps so that EVERY global load of the workgroup's staging phase is in
+// flight before the first dependent instruction: RawRows::fetch (the loads), then one of the put_* (unpack / norm + RoPE / LDS store).
+template <int NT, int S_>
+struct RawRows {
+    static constexpr int RPP = NT / 4;                       // rows per pass
+    static constexpr int PASSES = (S_ + RPP - 1) / RPP;
+    uint4 v[PASSES][2];
+    __device__ __forceinline__ void fetch(const bf16_t* __restrict__ src, long tok0, int ld) {
+        const int p = threadIdx.x & 3;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { lo[e] = x[e]; hi[e] = x[8 + e]; }
-        VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(img + img_off(row, p)), lo);
-        VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(img + img_off(row, 4 + p)), hi);
+        for (int i = 0; i < PASSES; ++i) {
+            const int row = (threadIdx.x >> 2) + i * RPP;
+            if (S_ % RPP == 0 || row < S_) {
+                const bf16_t* r = src + (tok0 + row) * ld;
+                v[i][0] = *reinterpret_cast<const uint4*>(r + 8 * p);
+                v[i][1] = *reinterpret_cast<const uint4*>(r + 32 + 8 * p);
+            } else {
+                v[i][0] = make_uint4(0u, 0u, 0u, 0u);
+                v[i][1] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
     }
+    static __device__ __forceinline__ void unpack(const uint4 (&u)[2], float (&x)[16]) {
+        const uint32_t w[8] = {u[0].x, u[0].y, u[0].z, u[0].w, u[1].x, u[1].y, u[1].z, u[1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { x[2 * i] = __uint_as_float(w[i] << 16); x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    // plain copy (V, dO)
+    __device__ __forceinline__ void put_raw(unsigned char* img) const {
+        const int p = threadIdx.x & 3;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int row = (threadIdx.x >> 2) + i * RPP;
+            if (S_ % RPP == 0 || row < S_) {
+                *reinterpret_cast<uint4*>(img + img_off(row, p)) = v[i][0];
+                *reinterpret_cast<uint4*>(img + img_off(row, 4 + p)) = v[i][1];
+            }
+        }
+    }
+    // q/k-norm + RoPE (position = row index) with the tables already in registers
+    template <class Tabs>
+    __device__ __forceinline__ void put_norm(unsigned char* img, const float (&sc)[16], float eps, const Tabs& t) const {
+        const int p = threadIdx.x & 3;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int row = (threadIdx.x >> 2) + i * RPP;
+            if (S_ % RPP == 0 || row < S_) {
+                float x[16];
+                unpack(v[i], x);
+                ln_rope_row_reg<bf16_t, SD, 4>(x, eps, sc, t.cs[i], t.sn[i]);
+                float lo[8], hi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { lo[e] = x[e]; hi[e] = x[8 + e]; }
+                VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(img + img_off(row, p)), lo);
+                VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(img + img_off(row, 4 + p)), hi);
+            }
+        }
+    }
+};
+// the RoPE table slices of the rows a thread stages (Q' and K' rows of one position share them)
+template <int NT, int S_>
+struct RowTabs {
+    static constexpr int RPP = NT / 4, PASSES = (S_ + RPP - 1) / RPP;
+    float cs[PASSES][16], sn[PASSES][16];
+    __device__ __forceinline__ void fetch(const float* __restrict__ cosT, const float* __restrict__ sinT) {
+        const int p = threadIdx.x & 3;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            int row = (threadIdx.x >> 2) + i * RPP;
+            if (S_ % RPP != 0 && row >= S_) row = 0;
+            load_tab<bf16_t, SD, 4>(cosT + (long)row * SD, p, cs[i]);
+            load_tab<bf16_t, SD, 4>(sinT + (long)row * SD, p, sn[i]);
+        }
+    }
+};
+
+// ---- accumulator layout <-> row layout through a per-wave 16-row scratch image (2 KB, same swizzle as the big images) ----------
+// acc layout: lane (j = lane & 31, kh = lane >> 5) holds channels 32 dt + 8 rg + 4 kh + e (e < 4) of row j of a 32-row tile (what a
+// 32x32 MFMA leaves with rows = channels): written or read straight to memory that is 8-byte pieces of 64 different rows per
+// instruction -- one cache line each.  row layout (attn_rows.hpp, 4 lanes per row): lane (row = lane >> 2, p = lane & 3) holds
+// channels [8p, 8p+8) and [32+8p, 32+8p+8): 16 rows x 64 contiguous bytes per instruction.  A tile goes through the scratch image
+// one 16-row half at a time; writer and reader are the same wave (LDS operations of a wave complete in order: wave_lds_fence).
+constexpr int SCR_BYTES = 16 * SROW;
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
 }
 
-// Q fragments of the 32-query block starting at token tok0 + q0: raw row -> q_norm -> RoPE -> bf16 operand registers
-__device__ __forceinline__ void load_q_frags(const bf16_t* __restrict__ qrow, int kh, int pos, const float* __restrict__ q_scale, float eps,
-                                             const float* __restrict__ cosT, const float* __restrict__ sinT, bf16x8 (&qf)[4])
+// the lanes that own rows [16 hf, 16 hf + 16) of the tile write their 8-byte pieces (values rounded to bf16)
+__device__ __forceinline__ void acc_half_put(unsigned char* scr, int j, int kh, int hf, const float (&g)[2][16])
 {
-    float x[4][8];
+    if ((j >> 4) == hf) {
+        const int row = j & 15, gs = gsw(row);
+        unsigned char* r = scr + row * SROW + kh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) VecIO<bf16_t, 8>::load(qrow + 16 * ks + 8 * kh, x[ks]);
-    ln_rope_frag(x, kh, q_scale, eps, cosT + (long)pos * SD, sinT + (long)pos * SD);
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = pack8(x[ks]);
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 o;
+                o.x = (uint32_t)f2bf(g[dt][4 * rg]) | ((uint32_t)f2bf(g[dt][4 * rg + 1]) << 16);
+                o.y = (uint32_t)f2bf(g[dt][4 * rg + 2]) | ((uint32_t)f2bf(g[dt][4 * rg + 3]) << 16);
+                *reinterpret_cast<uint2*>(r + (((4 * dt + rg) ^ gs) << 4)) = o;
+            }
+    }
 }
+// row-layout write / read of the scratch image: lane (row = lane >> 2, p = lane & 3), chunks p and 4 + p
+__device__ __forceinline__ void rows_put(unsigned char* scr, int lane, const float (&x)[16])
+{
+    const int row = lane >> 2, p = lane & 3;
+    float lo[8], hi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lo[e] = x[e]; hi[e] = x[8 + e]; }
+    VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(scr + img_off(row, p)), lo);
+    VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(scr + img_off(row, 4 + p)), hi);
+}
+__device__ __forceinline__ void rows_get(const unsigned char* scr, int lane, float (&x)[16])
+{
+    const int row = lane >> 2, p = lane & 3;
+    float lo[8], hi[8];
+    VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(scr + img_off(row, p)), lo);
+    VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(scr + img_off(row, 4 + p)), hi);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x[e] = lo[e]; x[8 + e] = hi[e]; }
+}
+
+// exp2 of a non-positive argument: the bare v_exp_f32 (results below 2^-126 flush to zero; exp2f() wraps the instruction in a
+// range-scaling sequence of five more VALU operations per element for denormal results that a probability rounded to bf16 never needs)
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int NKB>          // key blocks of 32: S = 32 * NKB
 __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ out, int ldo,
@@ -151,23 +229,57 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
     unsigned char* Ks = smem;
     unsigned char* Vs = smem + S * SROW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* scr = smem + 2 * S * SROW + wave * SCR_BYTES;     // this wave's scratch image
     const int a = blockIdx.x / d.H, h = blockIdx.x - a * d.H;
     const int HD = d.H * SD;
     const long tok0 = (long)a * S;
     const bf16_t* base = qkv + h * SD;
 
-    stage_rows<true>(base + HD, tok0, ld, Ks, S, k_scale, d.eps, cosT, sinT);
-    stage_rows<false>(base + 2 * HD, tok0, ld, Vs, S, nullptr, 0.f, nullptr, nullptr);
+    if (!(SATTN_PROBE & 1)) {
+        RawRows<256, S> rk, rv;
+        RowTabs<256, S> tabs;
+        float sck[16];
+        rk.fetch(base + HD, tok0, ld);                             // the rows with VALU work first: V streams in behind the k-norm
+        tabs.fetch(cosT, sinT);
+        load_tab<bf16_t, SD, 4>(k_scale, threadIdx.x & 3, sck);
+        rv.fetch(base + 2 * HD, tok0, ld);
+        rk.put_norm(Ks, sck, d.eps, tabs);
+        rv.put_raw(Vs);
+    }
     __syncthreads();
 
     const int j = lane & 31, kh = lane >> 5;
     const FragAddr fa(lane);
     const float c2 = rsqrtf((float)SD) * 1.44269504088896341f;          // softmax scale in the exp2 domain
 
-    for (int qb = wave; qb < NKB; qb += 4) {
+    for (int qb = wave; qb < NKB && !(SATTN_PROBE & 2); qb += 4) {
         const int qrow = qb * 32 + j;
+        // Q' fragments: raw rows in row layout (coalesced; every load of both halves issued first) -> q_norm -> RoPE -> scratch image
+        // -> operand registers
         bf16x8 qf[4];
-        load_q_frags(base + (tok0 + qrow) * ld, kh, qrow, q_scale, d.eps, cosT, sinT, qf);
+        {
+            float x[2][16], cs[2][16], sn[2][16], sc[16];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const long rr = qb * 32 + 16 * hf + (lane >> 2);
+                load_row<bf16_t, SD, 4>(base + (tok0 + rr) * ld, lane & 3, x[hf]);
+                load_tab<bf16_t, SD, 4>(cosT + rr * SD, lane & 3, cs[hf]);
+                load_tab<bf16_t, SD, 4>(sinT + rr * SD, lane & 3, sn[hf]);
+            }
+            load_tab<bf16_t, SD, 4>(q_scale, lane & 3, sc);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                ln_rope_row_reg<bf16_t, SD, 4>(x[hf], d.eps, sc, cs[hf], sn[hf]);
+                wave_lds_fence();                                   // earlier reads of the scratch image are done
+                rows_put(scr, lane, x[hf]);
+                wave_lds_fence();
+                if ((j >> 4) == hf) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        qf[ks] = *reinterpret_cast<const bf16x8*>(scr + (j & 15) * SROW + (((2 * ks + kh) ^ gsw(j & 15)) << 4));
+                }
+            }
+        }
 
         // Online softmax over groups of <= 4 key tiles (64 score registers live at a time).
         // S^T tile: s[g][r] = score(key 32 kb + 8 (r/4) + 4 kh + r%4, query j).  O^T[d][query] = sum over keys V[key][d] P[query][key];
@@ -198,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
             }
             mg = fmaxf(mg, xor32(mg));
             if (kb0 > 0) {                                          // rescale what the earlier groups accumulated
-                const float alpha = exp2f((m - mg) * c2);
+                const float alpha = exp2_fast((m - mg) * c2);
                 l *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
@@ -213,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
                     for (int u = 0; u < 2; ++u) {
                         float pv[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { pv[e] = exp2f((s[g][8 * u + e] - m) * c2); l += pv[e]; }
+                        for (int e = 0; e < 8; ++e) { pv[e] = exp2_fast((s[g][8 * u + e] - m) * c2); l += pv[e]; }
                         const bf16x8 pf = pack8(pv);                 // the reference multiplies V by probabilities in the value dtype
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt)
@@ -224,89 +336,25 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
         }
         l += xor32(l);
         const float inv = 1.f / l;
-        bf16_t* orow = out + (tok0 + qrow) * ldo + h * SD;
+        float og[2][16];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                float v4[4];
+            for (int e = 0; e < 16; ++e) og[dt][e] = o[dt][e] * inv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = o[dt][rg * 4 + e] * inv;
-                VecIO<bf16_t, 4>::store(orow + 32 * dt + 8 * rg + 4 * kh, v4);
-            }
+        for (int hf = 0; hf < 2; ++hf) {                            // O rows leave through the scratch image: whole 64-byte row segments
+            wave_lds_fence();
+            acc_half_put(scr, j, kh, hf, og);
+            wave_lds_fence();
+            float x[16];
+            rows_get(scr, lane, x);
+            store_row<bf16_t, SD, 4>(out + (tok0 + qb * 32 + 16 * hf + (lane >> 2)) * ldo + h * SD, lane & 3, x);
+        }
         if (kh == 0) lse2[((long)a * d.H + h) * S + qrow] = m * c2 + log2f(l);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ backward
-// Accumulator-layout row: lane (j = lane & 31, kh = lane >> 5) holds g[dt][r] = channel 32 dt + 8 (r/4) + 4 kh + r%4 of row j
-// (what a 32x32 MFMA leaves when rows = channels, columns = tokens).  The rotate-half partner (dt = 0 <-> 1, same r) is in the
-// same lane.  g: gradient w.r.t. the rotated row -> gradient w.r.t. the raw row; xh: raw row -> this row's contribution
-// dy_ln * xhat to the q/k-norm scale gradient (same algebra and rounding points as rope_ln_bwd_row in attn_rows.hpp).
-__device__ __forceinline__ void rope_ln_bwd_acc(float (&g)[2][16], float (&xh)[2][16], int kh, const float* __restrict__ scale, float eps,
-                                                const float* __restrict__ cosr, const float* __restrict__ sinr)
-{
-    float s = 0.f, ss = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s += xh[dt][r]; ss += xh[dt][r] * xh[dt][r]; }
-    s += xor32(s); ss += xor32(ss);
-    const float mean = s / SD;
-    float var = ss / SD - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    const float rstd = rsqrtf(var + eps);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cl = 8 * (r >> 2) + 4 * kh + (r & 3), ch = cl + 32;
-        const float lo = g[0][r], hi = g[1][r];
-        g[0][r] = lo * cosr[cl] + hi * sinr[ch];
-        g[1][r] = hi * cosr[ch] - lo * sinr[cl];
-        xh[0][r] = (xh[0][r] - mean) * rstd;
-        xh[1][r] = (xh[1][r] - mean) * rstd;
-        const float d0 = g[0][r] * scale[cl], d1 = g[1][r] * scale[ch];
-        s1 += d0 + d1; s2 += d0 * xh[0][r] + d1 * xh[1][r];
-    }
-    s1 += xor32(s1); s2 += xor32(s2);
-    s1 /= SD; s2 /= SD;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cl = 8 * (r >> 2) + 4 * kh + (r & 3), ch = cl + 32;
-        const float dy0 = g[0][r], dy1 = g[1][r], x0 = xh[0][r], x1 = xh[1][r];
-        g[0][r] = rstd * (dy0 * scale[cl] - s1 - x0 * s2);
-        g[1][r] = rstd * (dy1 * scale[ch] - s1 - x1 * s2);
-        xh[0][r] = dy0 * x0;
-        xh[1][r] = dy1 * x1;
-    }
-}
-
-// accumulator-layout row <-> global memory (8-byte pieces: 4 consecutive channels)
-__device__ __forceinline__ void load_acc_row(const bf16_t* __restrict__ row, int kh, float (&x)[2][16])
-{
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            float v4[4];
-            VecIO<bf16_t, 4>::load(row + 32 * dt + 8 * rg + 4 * kh, v4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[dt][rg * 4 + e] = v4[e];
-        }
-}
-__device__ __forceinline__ void store_acc_row(bf16_t* __restrict__ row, int kh, const float (&x)[2][16])
-{
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            float v4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v4[e] = x[dt][rg * 4 + e];
-            VecIO<bf16_t, 4>::store(row + 32 * dt + 8 * rg + 4 * kh, v4);
-        }
-}
-
 // part: (A*H, 2, 64) fp32 = per-(sequence, head) partial of [dq_scale | dk_scale] (summed by the caller).
 // One workgroup of 8 waves per (sequence, head); Q' = rope(q_norm(Q)), K' = rope(k_norm(K)), V and dO are staged ONCE as swizzled LDS
 // images (128 KB at S = 256) and every operand of the seven products is a row or a transposed fragment of one of them.
@@ -330,6 +378,7 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
     float* delS = lseS + S;
     float* red = delS + S;                            // [8 waves][2][64] scale-gradient partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* scr = reinterpret_cast<unsigned char*>(red + 16 * SD) + wave * SCR_BYTES;      // this wave's scratch image
     const int a = blockIdx.x / d.H, h = blockIdx.x - a * d.H;
     const int HD = d.H * SD;
     const long tok0 = (long)a * S;
@@ -341,49 +390,101 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
     const float c2 = sm_scale * 1.44269504088896341f;
 
     // ---- staging: Q' and K' (norm + RoPE), V, dO, delta = rowsum(dO * O), lse
-    stage_rows<true>(base, tok0, ld, Qs, S, q_scale, d.eps, cosT, sinT);
-    stage_rows<true>(base + HD, tok0, ld, Ks, S, k_scale, d.eps, cosT, sinT);
-    stage_rows<false>(base + 2 * HD, tok0, ld, Vs, S, nullptr, 0.f, nullptr, nullptr);
-    {                                                 // dO image + delta in one pass over dO
-        const int p = threadIdx.x & 3;
-        for (int row = threadIdx.x >> 2; row < S; row += 128) {
+    if (!(SATTN_PROBE & 1)) {
+        typedef RawRows<512, S> RR;
+        RR rv, rg, ro, rq, rk;
+        RowTabs<512, S> tabs;
+        float scq[16], sck[16];
+        rq.fetch(base, tok0, ld);                                  // the rows with VALU work (q/k-norm + RoPE) first: the rest streams
+        rk.fetch(base + HD, tok0, ld);                             // in behind them
+        tabs.fetch(cosT, sinT);
+        load_tab<bf16_t, SD, 4>(q_scale, threadIdx.x & 3, scq);
+        load_tab<bf16_t, SD, 4>(k_scale, threadIdx.x & 3, sck);
+        rv.fetch(base + 2 * HD, tok0, ld);
+        rg.fetch(gbase, tok0, lddo);
+        ro.fetch(out + h * SD, tok0, ldo);
+        float lse_r[RR::PASSES];
+#pragma unroll
+        for (int i = 0; i < RR::PASSES; ++i) {
+            const int row = (threadIdx.x >> 2) + i * RR::RPP;
+            lse_r[i] = row < S ? lse2[((long)a * d.H + h) * S + row] : 0.f;
+        }
+        rq.put_norm(Qs, scq, d.eps, tabs);
+        rk.put_norm(Ks, sck, d.eps, tabs);
+        rv.put_raw(Vs);
+        rg.put_raw(Gs);
+#pragma unroll
+        for (int i = 0; i < RR::PASSES; ++i) {                // delta = rowsum(dO * O)
+            const int row = (threadIdx.x >> 2) + i * RR::RPP;
             float go[16], oo[16];
-            load_row<bf16_t, SD, 4>(gbase + (tok0 + row) * lddo, p, go);
-            load_row<bf16_t, SD, 4>(out + (tok0 + row) * ldo + h * SD, p, oo);
-            float dl = 0.f, lo[8], hi[8];
+            RR::unpack(rg.v[i], go);
+            RR::unpack(ro.v[i], oo);
+            float dl = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dl += go[i] * oo[i];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { lo[e] = go[e]; hi[e] = go[8 + e]; }
-            VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(Gs + img_off(row, p)), lo);
-            VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(Gs + img_off(row, 4 + p)), hi);
+            for (int e = 0; e < 16; ++e) dl += go[e] * oo[e];
             dl = lpr_sum<4>(dl);
-            if (p == 0) { delS[row] = dl; lseS[row] = lse2[((long)a * d.H + h) * S + row]; }
+            if ((threadIdx.x & 3) == 0 && row < S) { delS[row] = dl; lseS[row] = lse_r[i]; }
         }
     }
-    // scale-gradient contributions (accumulator layout: 32 channels per lane) are summed over the 32 rows a half-wave holds with
-    // DPP butterflies (xor 1, 2, then the half-row and row mirrors; one cross-row shuffle) at the end of each tile and added to
-    // this wave's slots in LDS: nothing of it stays live across the tile loops
-    auto add_scale_grad = [&](const float (&ds)[2][16], int which) {
+    // A finished 32-row gradient tile (accumulator layout, fp32) leaves through the scratch image in two 16-row halves, in row layout:
+    // whole 64-byte row segments per lane quad on the way out, and the raw rows / RoPE tables the q/k-norm backward needs come in
+    // the same way.  The tile is rounded to bf16 on the way (the reference's attention hands bf16 gradients to its RoPE backward).
+    auto put_v_tile = [&](const float (&g)[2][16], int row0) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float t = ds[dt][r];
-                t += dpp_xor1(t);
-                t += dpp_xor2(t);
-                t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x141, 0xf, 0xf, true));      // row_half_mirror
-                t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x140, 0xf, 0xf, true));      // row_mirror
-                t += xor_lane<16>(t);
-                if (j == 0) red[(wave * 2 + which) * SD + 32 * dt + 8 * (r >> 2) + 4 * kh + (r & 3)] += t;
-            }
+        for (int hf = 0; hf < 2; ++hf) {
+            wave_lds_fence();
+            acc_half_put(scr, j, kh, hf, g);
+            wave_lds_fence();
+            float x[16];
+            rows_get(scr, lane, x);
+            store_row<bf16_t, SD, 4>(dqkv + (tok0 + row0 + 16 * hf + (lane >> 2)) * lddq + 2 * HD + h * SD, lane & 3, x);
+        }
     };
+    // which: 0 = q section, 1 = k section.  Also leaves this wave's scale-gradient partial in its slot of red[].
+    // q / k tiles (which: 0 = q section, 1 = k section) in two steps, so that the loads fly while something else runs:
+    // qk_loads issues every global load of the tile -- the raw rows (for xhat) and the RoPE tables of both halves, the scale slice;
+    // qk_finish transposes, runs RoPE / q-k-norm backward, stores, and leaves this wave's scale-gradient partial in its slot of red[].
+    struct RowCtx { float xr[2][16], cs[2][16], sn[2][16], sc[16]; };
+    auto qk_loads = [&](RowCtx& c, int row0, int which, const float* __restrict__ scale) {
+        const int p = lane & 3;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const long rr = row0 + 16 * hf + (lane >> 2);
+            load_row<bf16_t, SD, 4>(base + which * HD + (tok0 + rr) * ld, p, c.xr[hf]);
+            load_tab<bf16_t, SD, 4>(cosT + rr * SD, p, c.cs[hf]);
+            load_tab<bf16_t, SD, 4>(sinT + rr * SD, p, c.sn[hf]);
+        }
+        load_tab<bf16_t, SD, 4>(scale, p, c.sc);
+    };
+    auto qk_finish = [&](RowCtx& c, const float (&g)[2][16], int row0, int which) {
+        const int p = lane & 3;
+        float ds[16];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int rr = row0 + 16 * hf + (lane >> 2);
+            wave_lds_fence();
+            acc_half_put(scr, j, kh, hf, g);
+            wave_lds_fence();
+            float gx[16];
+            rows_get(scr, lane, gx);
+            const float rstd = xhat_row<16, 4, SD>(c.xr[hf], d.eps);
+            rope_ln_bwd_row_reg<bf16_t, SD, 4>(gx, c.xr[hf], rstd, c.sc, c.cs[hf], c.sn[hf]);
+            store_row<bf16_t, SD, 4>(dqkv + (tok0 + rr) * lddq + which * HD + h * SD, p, gx);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ds[i] = hf ? ds[i] + c.xr[hf][i] : c.xr[hf][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float t = frames_sum<4>(ds[i]);                   // over the 16 lanes that hold the same channels
+            if (lane < 4) red[(wave * 2 + which) * SD + Slice<bf16_t, SD, 4>::ch(i, p)] = t;
+        }
+    };
+    static_assert(NKB <= 8, "one key tile and one query tile per wave: the red[] slots are written once");
     for (int i = threadIdx.x; i < 16 * SD; i += 512) red[i] = 0.f;
     __syncthreads();
 
     // ---- phase A: dV, dK for the wave's key tiles
-    for (int kt = wave; kt < NKB; kt += 8) {
-        const int key = kt * 32 + j;
+    for (int kt = wave; kt < NKB && !(SATTN_PROBE & 2); kt += 8) {
         bf16x8 kc[4], vc[4];                          // the tile's own K' / V rows: column operands, constant over the query loop
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { kc[ks] = fa.rowfrag(Ks, kt, ks); vc[ks] = fa.rowfrag(Vs, kt, ks); }
@@ -392,6 +493,11 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { dv[dt][e] = 0.f; dk[dt][e] = 0.f; }
+        // Software pipeline: the row fragments of query block qb + 1 and the transposed fragments / lse / delta of block qb are
+        // requested before the exponentials of block qb start, so LDS latency runs under VALU work instead of in front of the MFMAs.
+        bf16x8 qr[4], gr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qr[ks] = fa.rowfrag(Qs, 0, ks); gr[ks] = fa.rowfrag(Gs, 0, ks); }
 #pragma unroll 1
         for (int qb = 0; qb < NKB; ++qb) {
             f32x16 s, dp;
@@ -399,8 +505,24 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Qs, qb, ks), kc[ks], s, 0, 0, 0);        // [query][key]
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Gs, qb, ks), vc[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ks], kc[ks], s, 0, 0, 0);        // [query][key]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gr[ks], vc[ks], dp, 0, 0, 0);
+            }
+            bf16x8 gt[2][2], qt[2][2];
+            float4 l4[4], d4[4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) { gt[u][dt] = fa.trfrag(Gs, qb, u, dt); qt[u][dt] = fa.trfrag(Qs, qb, u, dt); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                l4[i] = *reinterpret_cast<const float4*>(lseS + qb * 32 + 8 * i + 4 * kh);
+                d4[i] = *reinterpret_cast<const float4*>(delS + qb * 32 + 8 * i + 4 * kh);
+            }
+            {
+                const int nb = qb + 1 < NKB ? qb + 1 : qb;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { qr[ks] = fa.rowfrag(Qs, nb, ks); gr[ks] = fa.rowfrag(Gs, nb, ks); }
             }
             // register r <-> query 32 qb + 8 (r/4) + 4 kh + r%4; the two register halves are the two k16 steps of the next products
 #pragma unroll
@@ -408,12 +530,11 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
                 float p8[8], s8[8];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const float4 l4 = *reinterpret_cast<const float4*>(lseS + qb * 32 + 8 * (2 * u + hh) + 4 * kh);
-                    const float4 d4 = *reinterpret_cast<const float4*>(delS + qb * 32 + 8 * (2 * u + hh) + 4 * kh);
-                    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const float4 lv = l4[2 * u + hh], dv4 = d4[2 * u + hh];
+                    const float lq[4] = {lv.x, lv.y, lv.z, lv.w}, dq4[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float pe = exp2f(s[8 * u + 4 * hh + e] * c2 - lq[e]);
+                        const float pe = exp2_fast(s[8 * u + 4 * hh + e] * c2 - lq[e]);
                         p8[4 * hh + e] = pe;
                         s8[4 * hh + e] = pe * (dp[8 * u + 4 * hh + e] - dq4[e]);
                     }
@@ -421,30 +542,29 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
                 const bf16x8 pf = pack8(p8), sf = pack8(s8);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(Gs, qb, u, dt), pf, dv[dt], 0, 0, 0);   // dV^T[d][key] += dO^T[d][q] P[q][key]
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(Qs, qb, u, dt), sf, dk[dt], 0, 0, 0);   // dK^T[d][key] += Q'^T[d][q] dS[q][key]
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt[u][dt], pf, dv[dt], 0, 0, 0);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[u][dt], sf, dk[dt], 0, 0, 0);   // dK^T[d][key] += Q'^T[d][q] dS[q][key]
                 }
             }
         }
         // lane <-> key, registers <-> channels: dv leaves as it is; dk goes back through RoPE and k_norm
-        float g[2][16], xh[2][16];
+        RowCtx c;
+        qk_loads(c, kt * 32, 1, k_scale);                           // in flight while dV goes out
+        float g[2][16];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[dt][r] = dv[dt][r];
-        store_acc_row(dqkv + (tok0 + key) * lddq + 2 * HD + h * SD, kh, g);
+        put_v_tile(g, kt * 32);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[dt][r] = dk[dt][r] * sm_scale;
-        load_acc_row(base + HD + (tok0 + key) * ld, kh, xh);
-        rope_ln_bwd_acc(g, xh, kh, k_scale, d.eps, cosT + (long)key * SD, sinT + (long)key * SD);
-        store_acc_row(dqkv + (tok0 + key) * lddq + HD + h * SD, kh, g);
-        add_scale_grad(xh, 1);
+        qk_finish(c, g, kt * 32, 1);
     }
 
     // ---- phase B: dQ for the wave's query tiles
-    for (int qt = wave; qt < NKB; qt += 8) {
+    for (int qt = wave; qt < NKB && !(SATTN_PROBE & 4); qt += 8) {
         const int qrow = qt * 32 + j;
         bf16x8 qc[4], gc[4];
 #pragma unroll
@@ -455,6 +575,9 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+        bf16x8 kr[4], vr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kr[ks] = fa.rowfrag(Ks, 0, ks); vr[ks] = fa.rowfrag(Vs, 0, ks); }
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 s, dp;
@@ -462,29 +585,38 @@ __global__ __launch_bounds__(512) void sattn_bwd_kernel(const bf16_t* __restrict
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Ks, kb, ks), qc[ks], s, 0, 0, 0);        // [key][query]
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(Vs, kb, ks), gc[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[ks], qc[ks], s, 0, 0, 0);        // [key][query]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[ks], gc[ks], dp, 0, 0, 0);
+            }
+            bf16x8 kt2[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) kt2[u][dt] = fa.trfrag(Ks, kb, u, dt);
+            {
+                const int nb = kb + 1 < NKB ? kb + 1 : kb;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { kr[ks] = fa.rowfrag(Ks, nb, ks); vr[ks] = fa.rowfrag(Vs, nb, ks); }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 float s8[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s8[e] = exp2f(s[8 * u + e] * c2 - lq) * (dp[8 * u + e] - dl);
+                for (int e = 0; e < 8; ++e) s8[e] = exp2_fast(s[8 * u + e] * c2 - lq) * (dp[8 * u + e] - dl);
                 const bf16x8 sf = pack8(s8);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(Ks, kb, u, dt), sf, dq[dt], 0, 0, 0);   // dQ^T[d][query] += K'^T[d][key] dS^T[key][query]
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt2[u][dt], sf, dq[dt], 0, 0, 0);   // dQ^T[d][query] += K'^T[d][key] dS^T[key][query]
             }
         }
-        float g[2][16], xh[2][16];
+        float g[2][16];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[dt][r] = dq[dt][r] * sm_scale;
-        load_acc_row(base + (tok0 + qrow) * ld, kh, xh);
-        rope_ln_bwd_acc(g, xh, kh, q_scale, d.eps, cosT + (long)qrow * SD, sinT + (long)qrow * SD);
-        store_acc_row(dqkv + (tok0 + qrow) * lddq + h * SD, kh, g);
-        add_scale_grad(xh, 0);
+        RowCtx c;
+        qk_loads(c, qt * 32, 0, q_scale);
+        qk_finish(c, g, qt * 32, 0);
     }
 
     __syncthreads();
@@ -503,7 +635,7 @@ template <int NKB>
 int launch_sattn_bwd(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse2, void* dqkv, int lddq,
                      const float* qs, const float* ks, const float* cosT, const float* sinT, float* part, SAttnDims d, hipStream_t s)
 {
-    constexpr int lds = 4 * 32 * NKB * SROW + 2 * 32 * NKB * 4 + 16 * SD * 4;
+    constexpr int lds = 4 * 32 * NKB * SROW + 2 * 32 * NKB * 4 + 16 * SD * 4 + 8 * SCR_BYTES;
     auto k = sattn_bwd_kernel<NKB>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -521,7 +653,7 @@ template <int NKB>
 int launch_sattn_fwd(const void* qkv, int ld, void* out, int ldo, float* lse2, const float* qs, const float* ks, const float* cosT,
                      const float* sinT, SAttnDims d, hipStream_t s)
 {
-    constexpr int lds = 2 * 32 * NKB * SROW;
+    constexpr int lds = 2 * 32 * NKB * SROW + 4 * SCR_BYTES;
     auto k = sattn_fwd_kernel<NKB>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
