@@ -94,7 +94,9 @@ def test_classifier_vs_oracle(dev, dtype):
         check_bf16("logits", out, emu, ref, report)
         for k in gref:
             scale = float(gref[k[:-4] + "kernel"].abs().max()) if k.endswith("conv.bias") else None
-            check_bf16(k, got_g[k], gemu[k], gref[k], report, floor_scale=scale)
+            # five GroupNorm stages behind a two-sample batch: the bf16-emulated oracle itself sits at 0.17 on the stem's norm scale,
+            # so the absolute sanity cap is wider here; the bar that matters is 3 x the emulation's own error
+            check_bf16(k, got_g[k], gemu[k], gref[k], report, floor_scale=scale, abs_cap=0.5)
         print(report)
     # eval-style call: update_stats=False keeps u
     before = {k: v.clone() for k, v in m.named_buffers()}
