@@ -75,6 +75,18 @@ size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int 
 int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
                            int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
                            void* ws, size_t ws_bytes, void* stream);
+/* The decoder's concat([up, skip], channels) + conv1 (reference train/unet.py:79-81) at 16 + 16 channels WITHOUT the joint tensor: the
+   conv reads its input channels from two dense tensors (x: the first c_split, x2: the rest), its input gradient writes two dense
+   tensors (y, y2) and its weight gradient stages X from both.  (A producer that fills a 32-byte channel half of 64-byte voxels
+   runs at a third of the HBM rate; see tools/convt_pitch_probe.py.)  which: 0 forward (y2 = NULL; gn_part optional, as in
+   vvae_conv3d_fwd_bf16_gn), 1 input gradient (x = dY, x2 = NULL).  ws: packed weights (vvae_conv3d_pack_bf16 / _grouped). */
+int vvae_conv3d_cat2_supported(int Cin, int Cout, int c_split, int kt, int kh, int kw);
+int vvae_conv3d_fwd_bf16_cat2(const void* x, int ldx, const void* x2, int ldx2, const float* bias, void* y, int ldy, void* y2, int ldy2,
+                              int c_split, int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int which,
+                              const void* ws, size_t ws_bytes, float* gn_part, int groups, void* stream);
+int vvae_conv3d_wgrad_bf16_cat2(const void* x, int ldx, const void* x2, int ldx2, int c_split, const void* dy, int lddy, float* dw,
+                                float* dbias, int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, void* ws,
+                                size_t ws_bytes, void* stream);
 /* out[c] = sum over V rows of x[v][c] (bias gradients) */
 int vvae_colsum(const void* x, int ld, long V, int C, float* out, int dtype, void* stream);
 

@@ -1048,3 +1048,74 @@ def test_temporal_attention_matrix_core_kernels(dev, a, heads, inner, masked):
     # the two implementations agree with each other much more closely than either is required to agree with the oracle
     assert_close(new[0], old[0], rtol=2e-2, atol=2e-2, what="out, matrix-core vs VALU")
     assert_close_scaled(new[1], old[1], rel=3e-2, what="dqkv, matrix-core vs VALU")
+
+
+@pytest.mark.parametrize("case", [(16, 16, 16, (2, 5, 20, 36)), (16, 16, 32, (1, 4, 16, 32)), (16, 16, 16, (1, 3, 9, 21))])
+def test_conv3d_over_two_tensors_equals_conv_of_concat(dev, case):
+    """concat([up, skip]) + conv1 of the decoder (reference train/unet.py:79-81) with the two operands left as two dense tensors:
+    forward (with the GroupNorm partials), both input gradients, the weight and bias gradients are BITWISE those of the same layer
+    run on the concatenated tensor (same kernels, same summation order -- only the addresses differ), and the concatenated run is
+    oracle-checked by test_conv3d_bf16_fast_path; through autograd the module path gives the same numbers again."""
+    from video_vae_amd import ops
+    ca, cb, co, (n, t, h, w) = case
+    xa = _bf16_exact((n, t, h, w, ca), 60, 1.0).to(dev, torch.bfloat16)
+    xb = _bf16_exact((n, t, h, w, cb), 61, 1.0).to(dev, torch.bfloat16)
+    k = _bf16_exact((3, 3, 3, ca + cb, co), 62, (27 * (ca + cb)) ** -0.5).to(dev)
+    b = rnd((co,), 63, 0.1).to(dev)
+    gy = _bf16_exact((n, t, h, w, co), 64, 1.0).to(dev, torch.bfloat16)
+    assert ops.conv3d_cat2_ok(xa, xb, k)
+    xc = torch.cat([xa, xb], dim=-1)
+    groups = min(8, co)
+    nblk = ops.conv3d_gn_blocks(xc, k, groups)
+    assert nblk > 0
+    y_ref, part_ref = ops.conv3d_fwd_gn_raw(xc, k, b, groups, nblk)
+    y, part = ops.conv3d_cat2_fwd_raw(xa, xb, k, b, groups, nblk)
+    assert torch.equal(y, y_ref) and torch.equal(part, part_ref)
+    assert torch.equal(ops.conv3d_cat2_fwd_raw(xa, xb, k, b), ops.conv3d_fwd_raw(xc, k, b))
+    dx_ref = ops.conv3d_dgrad_raw(gy, k)
+    dxa, dxb = ops.conv3d_cat2_dgrad_raw(gy, k, ca)
+    assert dxa.is_contiguous() and dxb.is_contiguous()
+    assert torch.equal(dxa, dx_ref[..., :ca]) and torch.equal(dxb, dx_ref[..., ca:])
+    dw_ref, db_ref = ops.conv3d_wgrad_raw(xc, gy, tuple(k.shape))
+    dw, db = ops.conv3d_cat2_wgrad_raw(xa, xb, gy, tuple(k.shape))
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    # pitched operands (channel slices of wider buffers) are taken as they are
+    wide = torch.zeros((n, t, h, w, ca + 8), dtype=torch.bfloat16, device=dev)
+    wide[..., :ca] = xa
+    assert torch.equal(ops.conv3d_cat2_fwd_raw(wide[..., :ca], xb, k, b), y_ref)
+    # autograd node
+    xar, xbr = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    kr, br = k.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yy, stats = ops.conv3d_cat2_with_gn_stats(xar, xbr, kr, br, groups)
+    assert stats is not None and torch.equal(yy, y_ref)
+    yy.backward(gy)
+    assert torch.equal(xar.grad, dxa) and torch.equal(xbr.grad, dxb) and torch.equal(kr.grad, dw_ref) and torch.equal(br.grad, db_ref)
+
+
+def test_unet_decoder_two_tensor_level_matches_joint_buffer_free_path(dev):
+    """The 16 + 16 channel decoder level of the bf16 UNet (two dense tensors into conv1) against the same network with that level
+    forced onto torch.cat: outputs and every parameter gradient agree bitwise."""
+    import video_vae_amd as V
+    from video_vae_amd import ops, unet as U
+    net = V.UNet(12, 16, 2, 3, rngs=V.Rngs(4), dtype=torch.bfloat16).to(dev)
+    with torch.no_grad():
+        net.final_conv.kernel.copy_(rnd(net.final_conv.kernel.shape, 7, 0.2))
+    x = torch.rand(1, 4, 32, 32, 12, generator=torch.Generator().manual_seed(3)).to(dev)
+    gy = rnd((1, 4, 32, 32, 3), 5).to(dev, torch.bfloat16)
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        y = net(x)
+        y.backward(gy)
+        return y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+    y1, g1 = run()
+    real = ops.conv3d_cat2_ok
+    ops.conv3d_cat2_ok = lambda *a: False
+    try:
+        y0, g0 = run()
+    finally:
+        ops.conv3d_cat2_ok = real
+    assert torch.equal(y1, y0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k

@@ -20,6 +20,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 template <int CKB_, int KT_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_>
 struct ConvCfg {
@@ -37,6 +38,13 @@ struct ConvCfg {
 };
 
 struct BfDims { int N, T, H, W, CK, CO, tiles_h, tiles_w; };
+
+// Optional second tensor on either side of a single-chunk layer (the decoder's concat([up, skip]) at 16 + 16 channels, reference
+// train/unet.py:79, without the joint buffer: a producer that writes a 32-byte channel half of 64-byte voxels runs at a third of the
+// HBM rate, tools/convt_pitch_probe.py).  Input channels >= xsplit come from x2 (channel c at x2[c - xsplit]); produced channels
+// >= ysplit go to y2.  x2 / y2 == nullptr: one tensor.  Splits are multiples of 8 (input) / 16 (output) channels.
+struct Split2 { const bf16_t* x2; int ldx2, xsplit; bf16_t* y2; int ldy2, ysplit; };
+constexpr Split2 NO_SPLIT{nullptr, 0, 0, nullptr, 0, 0};
 
 // Packed weight layout (uint4 = 8 bf16 per lane): [chunk][dy][kstep][co_tile][lane]
 //   lane l: co = co_tile*16 + (l & 15), k = 32*kstep + 8*(l >> 4) + e,  slot = k / CKB -> (dt, dx), ci = chunk*CKB + k % CKB
@@ -289,7 +297,7 @@ extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, in
 namespace {
 bool roll_enabled();
 int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s,
-                    float* gn_part = nullptr, int gn_groups = 0);
+                    float* gn_part = nullptr, int gn_groups = 0, Split2 sp = NO_SPLIT);
 int roll_gn_blocks_any(BfDims d, int kh, int groups);
 }
 
@@ -427,6 +435,42 @@ extern "C" int vvae_conv3d_fwd_bf16_gn(const void* x, int ldx, const float* w, c
     return launch_roll_any((const bf16_t*)x, ldx, (const uint4*)ws, bias, (bf16_t*)y, ldy, d, kh, (hipStream_t)stream, gn_part, groups);
 }
 
+// Single-chunk layers with a second tensor on one side (Split2 above): which = 0 forward over concat([x, x2], channels) -- x holds the
+// first c_split input channels, x2 the other Cin - c_split -- optionally with the GroupNorm partials of vvae_conv3d_fwd_bf16_gn
+// (gn_part != NULL); which = 1 input gradient (x = dY) whose Cin produced channels are split between y (first c_split) and y2.
+// ws: weights already packed (vvae_conv3d_pack_bf16 / _grouped).  Only layers the rolling kernel takes (vvae_conv3d_cat2_supported:
+// K channels and produced channels both 16 or 32, 3x3x3); anything else is VVAE_ERR_BAD_ARG.
+extern "C" int vvae_conv3d_cat2_supported(int Cin, int Cout, int c_split, int kt, int kh, int kw)
+{
+    if (kt != 3 || kh != 3 || kw != 3 || !roll_enabled()) return 0;
+    if (!(Cin == 16 || Cin == 32) || !(Cout == 16 || Cout == 32)) return 0;
+    return (c_split > 0 && c_split < Cin && c_split % 16 == 0) ? 1 : 0;
+}
+
+extern "C" int vvae_conv3d_fwd_bf16_cat2(const void* x, int ldx, const void* x2, int ldx2, const float* bias, void* y, int ldy, void* y2,
+                                         int ldy2, int c_split, int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                                         int which, const void* ws, size_t ws_bytes, float* gn_part, int groups, void* stream)
+{
+    if (!x || !y || !ws || N <= 0 || T <= 0 || H <= 0 || W <= 0 || (which != 0 && which != 1)) return VVAE_ERR_BAD_ARG;
+    if (!vvae_conv3d_cat2_supported(Cin, Cout, c_split, kt, kh, kw)) return VVAE_ERR_BAD_ARG;
+    const int CK = which ? Cout : Cin, CO = which ? Cin : Cout;
+    if (ws_bytes < packed_bytes(CK, CO, kt, kh, kw) || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
+    Split2 sp = NO_SPLIT;
+    if (which == 0) {
+        if (!x2 || y2 || ((uintptr_t)x % 16) || ((uintptr_t)x2 % 16) || ldx % 8 || ldx2 % 8 || ldx < c_split || ldx2 < Cin - c_split ||
+            ldy < Cout || ldy % 4 || ((uintptr_t)y % 8)) return VVAE_ERR_BAD_ARG;
+        if (gn_part && vvae_conv3d_gn_blocks(N, T, H, W, Cin, Cout, kt, kh, kw, 8, ldy, groups) <= 0) return VVAE_ERR_BAD_ARG;
+        sp.x2 = (const bf16_t*)x2; sp.ldx2 = ldx2; sp.xsplit = c_split;
+    } else {
+        if (!y2 || x2 || gn_part || ((uintptr_t)x % 16) || ldx % 8 || ldx < Cout || ((uintptr_t)y % 8) || ((uintptr_t)y2 % 8) || ldy % 4 ||
+            ldy2 % 4 || ldy < c_split || ldy2 < Cin - c_split) return VVAE_ERR_BAD_ARG;
+        sp.y2 = (bf16_t*)y2; sp.ldy2 = ldy2; sp.ysplit = c_split;
+    }
+    BfDims d{N, T, H, W, CK, CO, 0, 0};
+    return launch_roll_any((const bf16_t*)x, ldx, (const uint4*)ws, which ? nullptr : bias, (bf16_t*)y, ldy, d, kh, (hipStream_t)stream, gn_part,
+                           groups, sp);
+}
+
 namespace {
 // =============================================================================================== weight gradient
 // dW[dt][dy][dx][ci][co] = sum_v X[v + off(dt,dy,dx)][ci] * dY[v][co]          (and dbias[co] = sum_v dY[v][co])
@@ -552,12 +596,17 @@ struct RollCfg {
 template <class C, bool GN>
 __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wp,
                                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy,
-                                                                       BfDims d, int tchunk, float* __restrict__ gn_part, int gn_groups)
+                                                                       BfDims d, int tchunk, float* __restrict__ gn_part, int gn_groups,
+                                                                       Split2 sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CKB = C::CKB, KT = C::KT, KH = C::KH, KW = C::KW, MT_W = C::MT_W, NT_W = C::NT_W;
     constexpr int HR = C::HR, WR = C::WR, PITCH = C::PITCH, KSTEPS = C::KSTEPS, PLANE = C::PLANE, CO_T = C::CO_T;
     constexpr bool WREG = C::WMODE == W_REG;
+    if (sp.x2 && (int)(threadIdx.x % (WR * (CKB / 8))) % (CKB / 8) * 8 >= sp.xsplit) {     // this thread stages a 16-byte part of x2
+        x = sp.x2 - sp.xsplit;
+        ldx = sp.ldx2;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int r = lane & 15, g = lane >> 4;
@@ -611,11 +660,13 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
     sx.fetch(x, ldx, n, t_beg + 1, hx, wx, d.T, d.H, d.W, tid);
     const int wo = w0 + r;
     const int lin_w = (wm * MT_W) * WR + r;                                // this lane's voxel in the wave's first halo row
-    float gs[GN ? NT_W : 1][4], gss[GN ? NT_W : 1][4];
+    // GroupNorm partials per channel PAIR (a group is an even number of consecutive channels): v_dot2c_f32_bf16 adds the two
+    // rounded outputs of a packed word (against 1.0 | 1.0), or their squares, to an fp32 accumulator in one instruction
+    float gs[GN ? NT_W : 1][2], gss[GN ? NT_W : 1][2];
 #pragma unroll
     for (int i = 0; i < (GN ? NT_W : 1); ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { gs[i][e] = 0.f; gss[i][e] = 0.f; }
+        for (int e = 0; e < 2; ++e) { gs[i][e] = 0.f; gss[i][e] = 0.f; }
     for (int tt = t_beg; tt < t_end; ++tt) {
         sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
         __syncthreads();
@@ -688,12 +739,15 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
                 uint2 o;
                 o.x = (uint32_t)f2bf(acc[m][i][0] + bv[i][0]) | ((uint32_t)f2bf(acc[m][i][1] + bv[i][1]) << 16);
                 o.y = (uint32_t)f2bf(acc[m][i][2] + bv[i][2]) | ((uint32_t)f2bf(acc[m][i][3] + bv[i][3]) << 16);
-                *reinterpret_cast<uint2*>(y + v * ldy + (ct0 + i) * 16 + 4 * g) = o;
+                if (sp.y2 && (ct0 + i) * 16 >= sp.ysplit) *reinterpret_cast<uint2*>(sp.y2 + v * sp.ldy2 + (ct0 + i) * 16 - sp.ysplit + 4 * g) = o;
+                else *reinterpret_cast<uint2*>(y + v * ldy + (ct0 + i) * 16 + 4 * g) = o;
                 if (GN) {                                          // statistics of what GroupNorm will read: the rounded values
-                    const float q0 = __uint_as_float(o.x << 16), q1 = __uint_as_float(o.x & 0xffff0000u);
-                    const float q2 = __uint_as_float(o.y << 16), q3 = __uint_as_float(o.y & 0xffff0000u);
-                    gs[i][0] += q0; gs[i][1] += q1; gs[i][2] += q2; gs[i][3] += q3;
-                    gss[i][0] += q0 * q0; gss[i][1] += q1 * q1; gss[i][2] += q2 * q2; gss[i][3] += q3 * q3;
+                    const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+                    const bf16x2 p0 = __builtin_bit_cast(bf16x2, o.x), p1 = __builtin_bit_cast(bf16x2, o.y);
+                    gs[i][0] = __builtin_amdgcn_fdot2_f32_bf16(p0, ones, gs[i][0], false);
+                    gs[i][1] = __builtin_amdgcn_fdot2_f32_bf16(p1, ones, gs[i][1], false);
+                    gss[i][0] = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, gss[i][0], false);
+                    gss[i][1] = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, gss[i][1], false);
                 }
             }
         }
@@ -703,27 +757,27 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
         // channels of each group -- fixed order, no atomics
         static_assert(!GN || C::CO_T * 16 * C::WM * 2 * 4 <= 4 * C::PLANE, "fold scratch fits the ring");
         __syncthreads();                                           // every wave is done with the ring
-        float* red = reinterpret_cast<float*>(smem);               // [wm][channel][2]
-        const int CO = C::CO_BLK;
+        float* red = reinterpret_cast<float*>(smem);               // [wm][channel pair][2]
+        constexpr int CP = C::CO_BLK / 2;
 #pragma unroll
         for (int i = 0; i < NT_W; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 2; ++e) {
                 float a = gs[i][e], b = gss[i][e];
-                a = butterfly_sum<8, 1>(a); b = butterfly_sum<8, 1>(b);          // the 16 voxel lanes of this channel quad (DPP only)
+                a = butterfly_sum<8, 1>(a); b = butterfly_sum<8, 1>(b);          // the 16 voxel lanes of this channel pair (DPP only)
                 if (r == 0) {
-                    const int ch = (wn * NT_W + i) * 16 + 4 * g + e;
-                    red[(wm * CO + ch) * 2 + 0] = a;
-                    red[(wm * CO + ch) * 2 + 1] = b;
+                    const int cp = (wn * NT_W + i) * 8 + 2 * g + e;
+                    red[(wm * CP + cp) * 2 + 0] = a;
+                    red[(wm * CP + cp) * 2 + 1] = b;
                 }
             }
         __syncthreads();
         if (tid < gn_groups) {
-            const int cpg = CO / gn_groups;
+            const int ppg = CP / gn_groups;                        // pairs per group (roll_gn_blocks: channels per group is even)
             float a = 0.f, b = 0.f;
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c)
+            for (int c = tid * ppg; c < (tid + 1) * ppg; ++c)
 #pragma unroll
-                for (int w2 = 0; w2 < C::WM; ++w2) { a += red[(w2 * CO + c) * 2]; b += red[(w2 * CO + c) * 2 + 1]; }
+                for (int w2 = 0; w2 < C::WM; ++w2) { a += red[(w2 * CP + c) * 2]; b += red[(w2 * CP + c) * 2 + 1]; }
             const long nblk = (long)d.tiles_h * d.tiles_w * nch;
             const long blk = ((long)th * d.tiles_w + tw) * nch + tc;
             float* pp = gn_part + ((n * nblk + blk) * gn_groups + tid) * 2;
@@ -753,14 +807,14 @@ int roll_tchunk(BfDims& d)
 template <class C>
 int roll_gn_blocks(BfDims d, int groups)
 {
-    if (d.CO != C::CO_BLK || groups <= 0 || d.CO % groups || groups > C::NTHREADS) return 0;
+    if (d.CO != C::CO_BLK || groups <= 0 || d.CO % (2 * groups) || groups > C::NTHREADS) return 0;      // whole channel pairs per group
     const int tchunk = roll_tchunk<C>(d);
     return d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk);
 }
 
 template <class C, bool GN>
 int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s,
-                float* gn_part = nullptr, int gn_groups = 0)
+                float* gn_part, int gn_groups, Split2 sp)
 {
     const int tchunk = roll_tchunk<C>(d);
     dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk)), d.CO / C::CO_BLK);
@@ -771,7 +825,7 @@ int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk, gn_part, gn_groups);
+    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk, gn_part, gn_groups, sp);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -783,12 +837,15 @@ typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false> R16_32;      // TH 8, one ou
 typedef RollCfg<32, 3, 3, 2, 1, 8, 1, W_REG, false> R32_16;      // TH 16, 8 waves
 typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false> R32_32;      // TH 16, 8 waves, one output-channel tile per wave
 
-#define ROLL(C) do { if (gn_part) return launch_roll<C, true>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups); \
-                     return launch_roll<C, false>(x, ldx, wp, bias, y, ldy, d, s); } while (0)
+#define ROLL(C) do { if (gn_part) return launch_roll<C, true>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups, sp); \
+                     return launch_roll<C, false>(x, ldx, wp, bias, y, ldy, d, s, nullptr, 0, sp); } while (0)
 int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s,
-                    float* gn_part, int gn_groups)
+                    float* gn_part, int gn_groups, Split2 sp)
 {
-    if (kh == 7) { if (gn_part) return VVAE_ERR_BAD_ARG; return launch_roll<R377, false>(x, ldx, wp, bias, y, ldy, d, s); }
+    if (kh == 7) {
+        if (gn_part || sp.x2 || sp.y2) return VVAE_ERR_BAD_ARG;
+        return launch_roll<R377, false>(x, ldx, wp, bias, y, ldy, d, s, nullptr, 0, NO_SPLIT);
+    }
     if (d.CK == 16 && d.CO == 16) ROLL(R16_16);
     if (d.CK == 16 && d.CO == 32) ROLL(R16_32);
     if (d.CK == 32 && d.CO == 16) ROLL(R32_16);
@@ -810,7 +867,7 @@ int roll_gn_blocks_any(BfDims d, int kh, int groups)
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx,
                                                                                  const bf16_t* __restrict__ dy, int lddy,
-                                                                                 float* __restrict__ slab, WgDims d)
+                                                                                 float* __restrict__ slab, WgDims d, Split2 sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CIB = C::CIB, COB = C::COB, KH = C::KH, KW = C::KW, TH = C::TH, TW = C::TW, AGS = C::AGS;
@@ -844,6 +901,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
     PlaneStager<C::NTHREADS, TH, TW, COB / 8, PY> sy;
     const bf16_t* xsrc = x + ci0;
     const bf16_t* ysrc = dy + co0;
+    if (sp.x2 && ci0 + (int)(threadIdx.x % (WR * (CIB / 8))) % (CIB / 8) * 8 >= sp.xsplit) {   // this thread stages a 16-byte part of x2
+        xsrc = sp.x2 + ci0 - sp.xsplit;
+        ldx = sp.ldx2;
+    }
 
     // A workgroup walks whole time-columns: for a fixed (n, h-tile, w-tile) it marches t = 0..T-1, so every X plane is
     // fetched from memory once (not KT times) and lives in the LDS ring for the three steps that use it.
@@ -984,7 +1045,7 @@ size_t wg_ws_bytes(int N, int T, int H, int W, int CI, int CO)
 
 template <class C>
 int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float* dw, float* dbias, int N, int T, int H, int W,
-                     int CI, int CO, void* ws, size_t ws_bytes, hipStream_t s)
+                     int CI, int CO, void* ws, size_t ws_bytes, hipStream_t s, Split2 sp = NO_SPLIT)
 {
     WgDims d{N, T, H, W, CI, CO, ceil_div(H, C::TH), ceil_div(W, C::TW), 0, 0};
     const long ncols = (long)N * d.tiles_h * d.tiles_w;
@@ -1001,7 +1062,7 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d);
+    hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d, sp);
     VVAE_LAUNCH_CHECK();
     const int taps = C::KT * C::KH * C::KW;
     const long total = (long)taps * CI * CO + CO;
@@ -1045,6 +1106,25 @@ extern "C" int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, in
     if (i32 && o32) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     if (i32) return launch_wgrad_cfg<W333_32_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     return launch_wgrad_cfg<W333_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+}
+
+// vvae_conv3d_wgrad_bf16 for a layer whose input is concat([x, x2], channels) held as two tensors (x: the first c_split channels):
+// the X halo parts are staged from whichever tensor holds them.  3x3x3, c_split a multiple of 8; same workspace query.
+extern "C" int vvae_conv3d_wgrad_bf16_cat2(const void* x, int ldx, const void* x2, int ldx2, int c_split, const void* dy, int lddy, float* dw,
+                                           float* dbias, int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, void* ws,
+                                           size_t ws_bytes, void* stream)
+{
+    if (!x || !x2 || !dy || !dw || N <= 0 || T <= 0 || H <= 0 || W <= 0 || kh != 3 || !wgrad_shape_ok(Cin, Cout, kt, kh, kw)) return VVAE_ERR_BAD_ARG;
+    if (c_split <= 0 || c_split >= Cin || c_split % 8 || ldx < c_split || ldx2 < Cin - c_split || lddy < Cout || ldx % 8 || ldx2 % 8 || lddy % 8 ||
+        ((uintptr_t)x % 16) || ((uintptr_t)x2 % 16) || ((uintptr_t)dy % 16)) return VVAE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bf16_t* xp = (const bf16_t*)x;
+    const bf16_t* dyp = (const bf16_t*)dy;
+    const Split2 sp{(const bf16_t*)x2, ldx2, c_split, nullptr, 0, 0};
+    const bool i32 = Cin % 32 == 0, o32 = i32 && Cout % 32 == 0 && !g_wg_cob16;
+    if (i32 && o32) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
+    if (i32) return launch_wgrad_cfg<W333_32_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
+    return launch_wgrad_cfg<W333_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
 }
 
 // Tuning hook for the weight-gradient kernel: output channels per workgroup (16 / 32 where Cout allows) and persistent grid size.

@@ -356,6 +356,127 @@ class _Conv3d(torch.autograd.Function):
         return dx, dw, db
 
 
+# ---- conv over concat([xa, xb], channels) held as two dense tensors (the decoder's 16 + 16 channel level) ----
+def conv3d_cat2_ok(xa, xb, kernel):
+    """The rolling bf16 kernels take this layer with its input in two tensors (forward, input gradient and weight gradient)."""
+    if _FORCE_GENERIC[0] or not (xa.is_cuda and xa.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16 and xa.shape[:-1] == xb.shape[:-1]):
+        return False
+    kt, kh, kw, cin, cout = kernel.shape
+    return cin == xa.shape[-1] + xb.shape[-1] and lib().vvae_conv3d_cat2_supported(cin, cout, xa.shape[-1], kt, kh, kw) == 1
+
+
+def _cat2_pack(kernel, dgrad, dims, device):
+    n, t, h, w, cin, cout, kt, kh, kw = dims
+    wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, dgrad)
+    ws, wsb = _ws(wsb, device)
+    check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, dgrad, _stream()), "vvae_conv3d_pack_bf16")
+    return ws
+
+
+def conv3d_cat2_fwd_raw(xa, xb, kernel, bias, groups=0, nblk=0, packed=None):
+    """-> y, or (y, part) with the GroupNorm partials when nblk > 0 (conv3d_fwd_gn_raw)."""
+    xa, lda = rows(xa)
+    xb, ldb = rows(xb)
+    n, t, h, w, ca = xa.shape
+    kt, kh, kw, cin, cout = kernel.shape
+    dims = (n, t, h, w, cin, cout, kt, kh, kw)
+    ws = packed if packed is not None else _cat2_pack(kernel, 0, dims, xa.device)
+    out = torch.empty((n, t, h, w, cout), dtype=xa.dtype, device=xa.device)
+    part = torch.empty((n, nblk, groups, 2), dtype=torch.float32, device=xa.device) if nblk else None
+    vox = n * t * h * w
+    tag = f"conv3d_fwd {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
+    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+                  lambda: lib().vvae_conv3d_fwd_bf16_cat2(_p(xa), lda, _p(xb), ldb, _p(bias), _p(out), cout, None, 0, ca, n, t, h, w, cin, cout,
+                                                          kt, kh, kw, 0, _p(ws), ws.numel(), _p(part), groups, _stream())),
+          "vvae_conv3d_fwd_bf16_cat2")
+    return (out, part) if nblk else out
+
+
+def conv3d_cat2_dgrad_raw(dy, kernel, ca, packed=None):
+    """-> (dxa, dxb): the input gradient's first ``ca`` channels and the rest, each dense."""
+    dy, lddy = rows(dy)
+    n, t, h, w, cout = dy.shape
+    kt, kh, kw, cin, _ = kernel.shape
+    dims = (n, t, h, w, cin, cout, kt, kh, kw)
+    ws = packed if packed is not None else _cat2_pack(kernel, 1, dims, dy.device)
+    dxa = torch.empty((n, t, h, w, ca), dtype=dy.dtype, device=dy.device)
+    dxb = torch.empty((n, t, h, w, cin - ca), dtype=dy.dtype, device=dy.device)
+    vox = n * t * h * w
+    tag = f"conv3d_dgrad {cout}->{cin} k{kt}{kh}{kw} @{h}x{w}"
+    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+                  lambda: lib().vvae_conv3d_fwd_bf16_cat2(_p(dy), lddy, None, 0, None, _p(dxa), ca, _p(dxb), cin - ca, ca, n, t, h, w, cin, cout,
+                                                          kt, kh, kw, 1, _p(ws), ws.numel(), None, 0, _stream())),
+          "vvae_conv3d_fwd_bf16_cat2")
+    return dxa, dxb
+
+
+def conv3d_cat2_wgrad_raw(xa, xb, dy, kshape, want_bias=True, dw_out=None, db_out=None):
+    xa, lda = rows(xa)
+    xb, ldb = rows(xb)
+    dy, lddy = rows(dy)
+    n, t, h, w, ca = xa.shape
+    kt, kh, kw, cin, cout = kshape
+    dw = dw_out if dw_out is not None else torch.empty(kshape, dtype=torch.float32, device=xa.device)
+    db = (db_out if db_out is not None else torch.empty((cout,), dtype=torch.float32, device=xa.device)) if want_bias else None
+    wsb = lib().vvae_conv3d_wgrad_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw)
+    ws, wsb = _ws(wsb, xa.device)
+    vox = n * t * h * w
+    tag = f"conv3d_wgrad {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
+    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_wgrad",
+                  lambda: lib().vvae_conv3d_wgrad_bf16_cat2(_p(xa), lda, _p(xb), ldb, ca, _p(dy), lddy, _p(dw), _p(db), n, t, h, w, cin, cout, kt,
+                                                            kh, kw, _p(ws), wsb, _stream())), "vvae_conv3d_wgrad_bf16_cat2")
+    return dw, db
+
+
+class _Conv3dCat2(torch.autograd.Function):
+    """_Conv3d over concat([xa, xb], -1) without the concatenated tensor (reference train/unet.py:79-81)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, kernel, bias, gn_groups=0, gn_blocks=0, pack=None):
+        k32, b32 = _f32(kernel), _f32(bias)
+        ctx.save_for_backward(xa, xb, k32)
+        ctx.kdtype, ctx.kparam, ctx.bparam, ctx.pack = kernel.dtype, kernel, bias, pack
+        pk = pack.fwd if pack is not None else None
+        if gn_blocks:
+            y, part = conv3d_cat2_fwd_raw(xa, xb, k32, b32, gn_groups, gn_blocks, pk)
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return conv3d_cat2_fwd_raw(xa, xb, k32, b32, packed=pk)
+
+    @staticmethod
+    def backward(ctx, dy, dpart=None):
+        xa, xb, k32 = ctx.saved_tensors
+        dy = dy.to(xa.dtype)
+        dxa = dxb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dxa, dxb = conv3d_cat2_dgrad_raw(dy, k32, xa.shape[-1], ctx.pack.dgrad if ctx.pack is not None else None)
+        dw = db = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            q = WGRAD_QUEUE[0]
+            kp, bp = ctx.kparam, ctx.bparam
+            if (q is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and getattr(kp, "gview", None) is not None
+                    and getattr(bp, "gview", None) is not None and kp.dtype == torch.float32 and bp.dtype == torch.float32):
+                q.claim(kp)                                  # straight into the flat gradient buffer (see _Conv3d._backward)
+                conv3d_cat2_wgrad_raw(xa, xb, dy, tuple(k32.shape), True, kp.gview, bp.gview)
+                q.opt.mark_external(kp)
+                q.opt.mark_external(bp)
+            else:
+                dw, db = conv3d_cat2_wgrad_raw(xa, xb, dy, tuple(k32.shape), True)
+                dw = dw.to(ctx.kdtype)
+        return dxa, dxb, dw, db, None, None, None
+
+
+def conv3d_cat2_with_gn_stats(xa, xb, kernel, bias, groups, pack=None):
+    """conv3d_with_gn_stats over concat([xa, xb], -1) held as two tensors; the caller checked conv3d_cat2_ok."""
+    kt, kh, kw, cin, cout = kernel.shape
+    n, t, h, w, _ = xa.shape
+    nblk = 0 if _FORCE_GENERIC[0] or groups <= 0 else lib().vvae_conv3d_gn_blocks(n, t, h, w, cin, cout, kt, kh, kw, 8, cout, groups)
+    if not nblk:
+        return _Conv3dCat2.apply(xa, xb, kernel, bias, 0, 0, pack), None
+    y, part = _Conv3dCat2.apply(xa, xb, kernel, bias, groups, nblk, pack)
+    return y, (part, nblk)
+
+
 def conv3d(x, kernel, bias=None, pack=None):
     """NDHWC Conv3d, SAME, stride 1 (nnx.Conv; reference train/unet.py:13-21).  ``pack``: from conv3d_prepack."""
     return _Conv3d.apply(x, kernel, bias, 0, 0, pack)

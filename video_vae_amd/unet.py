@@ -62,12 +62,17 @@ class ConvBlock3D(nn.Module):
         self.conv = Conv(in_channels, out_channels, (temporal_kernel, kernel_size, kernel_size), rngs, dtype, param_dtype)
         self.norm = GroupNorm(min(8, out_channels), out_channels, param_dtype)
 
-    def forward(self, x, kernel=None, out=None, pack=None):
+    def forward(self, x, kernel=None, out=None, pack=None, x2=None):
         # ``kernel``: optional stand-in for self.conv.kernel (UNet passes a zero-padded view for 16-channel alignment)
         # ``out``: channel slice of a wider buffer for the block's output (the skip half of a decoder's concat buffer)
         # ``pack``: this step's packed weights of the conv (ops.conv3d_prepack), or None
-        x, stats = ops.conv3d_with_gn_stats(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias,
-                                            self.norm.num_groups, pack)
+        # ``x2``: the input is concat([x, x2], channels) held as two tensors (ops.conv3d_cat2_ok was checked by the caller)
+        if x2 is not None:
+            x, stats = ops.conv3d_cat2_with_gn_stats(x.to(self.conv.dtype), x2.to(self.conv.dtype), self.conv.kernel, self.conv.bias,
+                                                     self.norm.num_groups, pack)
+        else:
+            x, stats = ops.conv3d_with_gn_stats(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias,
+                                                self.norm.num_groups, pack)
         return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out, stats)
 
 
@@ -99,9 +104,13 @@ class UpBlock3D(nn.Module):
         if joint is not None:
             c = skip.shape[-1]
             x = ops.join_channels(self.upsample(x, out=joint[..., :c]), skip, joint)
-        else:
-            x = torch.cat([self.upsample(x), skip], dim=-1)
-        return self.conv2(self.conv1(x, pack=packs[0]), pack=packs[1])
+            return self.conv2(self.conv1(x, pack=packs[0]), pack=packs[1])
+        up = self.upsample(x)
+        if ops.conv3d_cat2_ok(up, skip, self.conv1.conv.kernel):
+            # 16 + 16 channels: two dense tensors instead of the halves of a joint buffer (a 32-byte half-voxel write runs at a third
+            # of the HBM rate); conv1 reads both, its input gradient writes both
+            return self.conv2(self.conv1(up, pack=packs[0], x2=skip), pack=packs[1])
+        return self.conv2(self.conv1(torch.cat([up, skip], dim=-1), pack=packs[0]), pack=packs[1])
 
 
 class UNet(nn.Module):
@@ -164,9 +173,13 @@ class UNet(nn.Module):
         for i, enc in enumerate(self.encoders):
             c = enc.conv2.norm.scale.shape[0]
             joint = None
-            if x.is_cuda and x.shape[-3] % 2 == 0 and x.shape[-2] % 2 == 0:
+            dec_k = self.decoders[len(self.encoders) - 1 - i].conv1.conv.kernel
+            two_tensors = (x.is_cuda and self.dtype == torch.bfloat16 and not ops._FORCE_GENERIC[0]
+                           and ops.lib().vvae_conv3d_cat2_supported(2 * c, dec_k.shape[-1], c, *dec_k.shape[:3]) == 1)
+            if x.is_cuda and x.shape[-3] % 2 == 0 and x.shape[-2] % 2 == 0 and not two_tensors:
                 # the decoder at this level will read concat([up, skip]): allocate that buffer now and let the encoder's
-                # last kernel write the skip straight into its upper channel half
+                # last kernel write the skip straight into its upper channel half.  (Not at 16 + 16 channels: there the skip and
+                # the up-conv output stay two dense tensors and the decoder's conv reads both, see UpBlock3D.)
                 joint = torch.empty((*x.shape[:-1], 2 * c), dtype=self.dtype, device=x.device)
             x, skip = enc(x, k1 if i == 0 else None, None if joint is None else joint[..., c:], packs=(pk(1 + 2 * i), pk(2 + 2 * i)))
             skips.append(skip)
