@@ -101,6 +101,11 @@ int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx
 int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, long V, int Cin, int Cout,
                               int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- PatchUnEmbedding's "b t (h w) (p1 p2 cu) -> b t (h p1) (w p2) cu" (train/layers.py:48) fused with the zero padding of the
+ *      channel axis from cu to c (the multiple of 16 the conv kernels take), and its transpose.  frames = b*t; bf16; cu, c % 4 == 0. ---- */
+int vvae_unpatch_pad_fwd(const void* x, void* y, long frames, int h, int w, int p, int cu, int c, int dtype, void* stream);
+int vvae_unpatch_pad_bwd(const void* g, void* gx, long frames, int h, int w, int p, int cu, int c, int dtype, void* stream);
+
 /* ---- GroupNorm(G, eps) + SiLU: nnx.GroupNorm + nnx.silu at train/unet.py:22-23,28-29.
  *      sums: fp64 [N][G][2] (sum, sum of squares) produced by vvae_gn_stats; S = voxels per sample. ---- */
 size_t vvae_gn_part_floats(int N, long S, int C);   /* fp32 scratch floats for `part` below (per-workgroup partial sums) */

@@ -229,24 +229,25 @@ class PatchEmbedding(nn.Module):
 
 class _UnpatchPad(torch.autograd.Function):
     """"b t (h w) (p1 p2 c u) -> b t (h p1) (w p2) (c u)" (reference train/layers.py:48) into a buffer whose channel count is
-    rounded up to a multiple of 16, pad channels zero: one strided copy each way."""
+    rounded up to a multiple of 16, pad channels zero: one HIP launch each way (vvae_unpatch_pad_fwd / _bwd)."""
 
     @staticmethod
     def forward(ctx, x, p, h, w, u, pad):
         b, t = x.shape[:2]
         cu = x.shape[-1] // (p * p)
-        src = rearrange(x, "b t (h w) (p1 p2 cu) -> b t (h p1) (w p2) cu", p1=p, p2=p, h=h, w=w)
+        x = x.contiguous()
         out = torch.empty((b, t, h * p, w * p, cu + pad), dtype=x.dtype, device=x.device)
-        out[..., :cu].copy_(src)
-        out[..., cu:].zero_()
-        ctx.dims = (p, h, w, cu)
+        ops.unpatch_pad(x, out, b * t, h, w, p, cu, cu + pad, backward=False)
+        ctx.dims = (p, h, w, cu, pad, tuple(x.shape))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        p, h, w, cu = ctx.dims
-        gx = rearrange(g[..., :cu], "b t (h p1) (w p2) cu -> b t (h w) (p1 p2 cu)", p1=p, p2=p, h=h, w=w)
-        return gx.contiguous(), None, None, None, None, None
+        p, h, w, cu, pad, shape = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty(shape, dtype=g.dtype, device=g.device)
+        ops.unpatch_pad(g, gx, shape[0] * shape[1], h, w, p, cu, cu + pad, backward=True)
+        return gx, None, None, None, None, None
 
 
 class PatchUnEmbedding(nn.Module):

@@ -493,6 +493,12 @@ def conv3d_with_gn_stats(x, kernel, bias, groups, pack=None):
     return y, (part, nblk)
 
 
+def unpatch_pad(src, dst, frames, h, w, p, cu, c, backward):
+    """PatchUnEmbedding's rearrange fused with the channel padding (layers._UnpatchPad); bf16 GPU tensors, contiguous."""
+    fn = lib().vvae_unpatch_pad_bwd if backward else lib().vvae_unpatch_pad_fwd
+    check(fn(_p(src), _p(dst), frames, h, w, p, cu, c, _dt(src), _stream()), "vvae_unpatch_pad")
+
+
 # --------------------------------------------------------------------------------------------- GroupNorm + SiLU
 def gn_stats_raw(x, groups):
     x, ldx = rows(x)
