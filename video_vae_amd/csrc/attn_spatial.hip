@@ -18,7 +18,8 @@
 //     before the exponentials start; exp2 is the bare v_exp_f32 (arguments are <= 0).
 // Forward saves the base-2 log-sum-exp per query for the backward pass.
 // Where the time goes (tools/sattn_probe.py, A = 64, S = 256, 8 heads): every workgroup of the launch is resident at once, so the
-// phases run chip-wide in lock step -- staging and the tile epilogues at HBM rate, the tile loops with HBM idle.
+// phases run chip-wide in lock step -- staging and the tile epilogues at HBM rate, the tile loops with HBM idle.  (Starting every
+// other workgroup a few microseconds late, so that one half's memory phases meet the other half's tile loops, measured the same.)
 #include "attn_rows.hpp"
 
 #ifndef SATTN_PROBE          // tools/sattn_probe.py builds timing-only variants with phases cut out (results are garbage there)
