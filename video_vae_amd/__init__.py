@@ -10,4 +10,4 @@ from .layers import (PatchEmbedding, PatchUnEmbedding, RotaryEmbedding, Attentio
                      round_ste, GumbelSigmoidSTE)
 from .model import Encoder, Decoder, VideoVAE  # noqa: F401
 from .model_loader import load_checkpoint, save_checkpoint  # noqa: F401
-from . import rl_model, loss, optim, ddp, ops  # noqa: F401
+from . import rl_model, loss, optim, ddp, ops, perceptual, classifier  # noqa: F401
