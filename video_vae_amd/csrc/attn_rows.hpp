@@ -106,13 +106,16 @@ __device__ __forceinline__ void ln_rope_row(float (&x)[D / LPR], int p, const fl
     using S = Slice<T_, D, LPR>;
     xhat_row<S::DL, LPR, D>(x, eps);
 #pragma unroll
-    for (int i = 0; i < S::DL; ++i) x[i] = round_to<T_>(x[i] * scale[S::ch(i, p)]);
-#pragma unroll
-    for (int i = 0; i < S::HL; ++i) {                    // rotate-half pair (i, i + HL) = channels (c, c + D/2)
-        const float lo = x[i], hi = x[i + S::HL];
+    for (int i = 0; i < S::HL; ++i) {                    // rotate-half pair (i, i + HL) = channels (c, c + D/2); roundings in pairs
         const int cl = S::ch(i, p), chh = S::ch(i + S::HL, p);
-        x[i] = round_to<T_>(round_to<T_>(lo * cosr[cl]) + round_to<T_>(-hi * sinr[cl]));
-        x[i + S::HL] = round_to<T_>(round_to<T_>(hi * cosr[chh]) + round_to<T_>(lo * sinr[chh]));
+        float lo = x[i] * scale[cl], hi = x[i + S::HL] * scale[chh];
+        round2<T_>(lo, hi);
+        float a = lo * cosr[cl], b = -hi * sinr[cl], c = hi * cosr[chh], e = lo * sinr[chh];
+        round2<T_>(a, b);
+        round2<T_>(c, e);
+        float y0 = a + b, y1 = c + e;
+        round2<T_>(y0, y1);
+        x[i] = y0; x[i + S::HL] = y1;
     }
 }
 
@@ -155,12 +158,15 @@ __device__ __forceinline__ void ln_rope_row_reg(float (&x)[D / LPR], float eps, 
     using S = Slice<T_, D, LPR>;
     xhat_row<S::DL, LPR, D>(x, eps);
 #pragma unroll
-    for (int i = 0; i < S::DL; ++i) x[i] = round_to<T_>(x[i] * sc[i]);
-#pragma unroll
     for (int i = 0; i < S::HL; ++i) {
-        const float lo = x[i], hi = x[i + S::HL];
-        x[i] = round_to<T_>(round_to<T_>(lo * cs[i]) + round_to<T_>(-hi * sn[i]));
-        x[i + S::HL] = round_to<T_>(round_to<T_>(hi * cs[i + S::HL]) + round_to<T_>(lo * sn[i + S::HL]));
+        float lo = x[i] * sc[i], hi = x[i + S::HL] * sc[i + S::HL];
+        round2<T_>(lo, hi);
+        float a = lo * cs[i], b = -hi * sn[i], c = hi * cs[i + S::HL], e = lo * sn[i + S::HL];
+        round2<T_>(a, b);
+        round2<T_>(c, e);
+        float y0 = a + b, y1 = c + e;
+        round2<T_>(y0, y1);
+        x[i] = y0; x[i + S::HL] = y1;
     }
 }
 template <typename T_, int D, int LPR>

@@ -83,12 +83,15 @@ __device__ __forceinline__ void ln_rope16(float (&x)[16], const float* __restric
                                           const float* __restrict__ sn) {
     xhat16(x, eps);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = round_to<bf16_t>(x[i] * sc[i]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float lo = x[i], hi = x[i + 8];
-        x[i] = round_to<bf16_t>(round_to<bf16_t>(lo * cs[i]) + round_to<bf16_t>(-hi * sn[i]));
-        x[i + 8] = round_to<bf16_t>(round_to<bf16_t>(hi * cs[i + 8]) + round_to<bf16_t>(lo * sn[i + 8]));
+    for (int i = 0; i < 8; ++i) {                        // roundings in pairs: one v_cvt_pk_bf16_f32 per two values
+        float lo = x[i] * sc[i], hi = x[i + 8] * sc[i + 8];
+        round2<bf16_t>(lo, hi);
+        float a = lo * cs[i], b = -hi * sn[i], c = hi * cs[i + 8], e = lo * sn[i + 8];
+        round2<bf16_t>(a, b);
+        round2<bf16_t>(c, e);
+        float y0 = a + b, y1 = c + e;
+        round2<bf16_t>(y0, y1);
+        x[i] = y0; x[i + 8] = y1;
     }
 }
 // this lane's 16 table entries (scale, or the cos / sin row of its frame) in row layout

@@ -39,6 +39,17 @@ __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f2bf(v); }
 template <typename T> __device__ __forceinline__ float round_to(float v);
 template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
+// Two values at once: one v_cvt_pk_bf16_f32 rounds both (a scalar round_to spends one on each), then a shift and a mask unpack.
+template <typename T> __device__ __forceinline__ void round2(float& a, float& b);
+template <> __device__ __forceinline__ void round2<float>(float&, float&) {}
+template <> __device__ __forceinline__ void round2<bf16_t>(float& a, float& b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    a = __uint_as_float(w << 16);
+    b = __uint_as_float(w & 0xffff0000u);
+}
 
 // ---- vector access: VEC channels per lane (VEC*sizeof(T) = 16 B when aligned) -------------
 template <typename T, int VEC> struct VecIO;
