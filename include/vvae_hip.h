@@ -55,14 +55,17 @@ int vvae_conv3d_roll_config(int on, int tchunk);   /* test/tuning hook: rolling 
 int vvae_conv3d_wgrad_config(int cob16, int blocks); /* tuning hook: 16 output channels per wgrad workgroup (default 0), persistent grid size (0 = per-config default) */
 int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out, int which, int flags);
 size_t vvae_conv3d_bf16_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int which);
+/* flags (pack and forward calls of one layer must agree): bit 0 = input-gradient form; bits 8-15 = how many of the layer's K channels
+   (Cin forward, Cout for the input gradient) are real when tensor and weights are zero-padded to 16 (0 = all).  The 3x7x7 patch mixer
+   with 12 real channels (train/unet.py:111-113) then multiplies K = 3*7*12 = 252 instead of 336; other values are accepted and ignored. */
 int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, int Cin, int Cout, int kt, int kh, int kw,
-                          int dgrad, void* stream);
+                          int flags, void* stream);
 /* n <= 64 packings in one launch (every conv layer of the UNet, forward + input-gradient forms: the weights change once per
    optimizer step); host arrays of device pointers / ints, kt = 3, kw = kh in {3, 7}. */
 int vvae_conv3d_pack_grouped_bf16(const float* const* w, void* const* ws, const size_t* ws_bytes, const int* Cin, const int* Cout,
-                                  const int* kh, const int* dgrad, int n, void* stream);
+                                  const int* kh, const int* flags, int n, void* stream);
 int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
-                         int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
+                         int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int flags,
                          int prepacked, void* ws, size_t ws_bytes, void* stream);
 /* Forward Conv3d that also emits the GroupNorm statistics of its (rounded) output -- ConvBlock3D's conv + norm statistics in one
    pass (reference train/unet.py:13-23).  vvae_conv3d_gn_blocks: rows per sample of the partial buffer (0 = layer not eligible,

@@ -1119,3 +1119,44 @@ def test_unet_decoder_two_tensor_level_matches_joint_buffer_free_path(dev):
     assert torch.equal(y1, y0)
     for k in g0:
         assert torch.equal(g1[k], g0[k]), k
+
+
+def test_patch_mixer_real_channel_product_equals_padded_product(dev):
+    """The 3x7x7 mixer on 16-channel voxels of which 12 are real (UNet.forward pads 12 -> 16, reference train/unet.py:111-113): told
+    the real count, the rolling kernel multiplies K = 3*7*12 = 252 instead of 336.  Same products in a different order: outputs and
+    input gradients agree with the padded product to bf16 rounding of fp32 sums (mostly bitwise), and with the oracle."""
+    from video_vae_amd import ops
+    n, t, h, w, c, pad = 1, 5, 40, 52, 12, 4
+    x = torch.zeros(n, t, h, w, c + pad)
+    x[..., :c] = _bf16_exact((n, t, h, w, c), 70, 1.0)
+    k = torch.zeros(3, 7, 7, c + pad, c + pad)
+    k[..., :c, :c] = _bf16_exact((3, 7, 7, c, c), 71, (147 * c) ** -0.5)
+    b = torch.zeros(c + pad); b[:c] = rnd((c,), 72, 0.1)
+    gy = torch.zeros(n, t, h, w, c + pad)
+    gy[..., :c] = _bf16_exact((n, t, h, w, c), 73, 1.0)
+    xg, kg, bg, gyg = x.to(dev, torch.bfloat16), k.to(dev), b.to(dev), gy.to(dev, torch.bfloat16)
+    y_pad = ops.conv3d_fwd_raw(xg, kg, bg)
+    y_real = ops.conv3d_fwd_raw(xg, kg, bg, k_real=c)
+    dx_pad = ops.conv3d_dgrad_raw(gyg, kg)
+    dx_real = ops.conv3d_dgrad_raw(gyg, kg, k_real=c)
+    assert float(y_real[..., c:].float().abs().max()) == 0 and float(dx_real[..., c:].float().abs().max()) == 0
+    assert_close(y_real, y_pad, rtol=1e-2, atol=1e-2, what="real-K vs padded y")
+    assert_close(dx_real, dx_pad, rtol=1e-2, atol=1e-2 * float(dx_pad.float().abs().max()), what="real-K vs padded dx")
+    assert float((y_real != y_pad).float().mean()) < 0.05 and float((dx_real != dx_pad).float().mean()) < 0.05
+    xo = x.clone().requires_grad_(True)
+    yo = O.conv3d_same(xo, k, b, torch.bfloat16)
+    yo.backward(gy)
+    assert_close(y_real, yo, rtol=2e-2, atol=2e-2, what="real-K vs oracle y")
+    assert_close_scaled(dx_real, xo.grad, rel=2e-2, what="real-K vs oracle dx")
+    # through the prepacked path and autograd, as UNet.forward runs it
+    pack = ops.conv3d_prepack([kg], [(c, c)])[0]
+    xr = xg.clone().requires_grad_(True)
+    yy = ops.conv3d(xr, kg, bg, pack=pack, real=(c, c))
+    yy.backward(gyg)
+    assert torch.equal(yy, y_real) and torch.equal(xr.grad, dx_real)
+    # the per-frame kernel (rolling kernel switched off) ignores the hint: padded product, padded packing
+    ops.lib().vvae_conv3d_roll_config(0, 0)
+    try:
+        assert torch.equal(ops.conv3d_fwd_raw(xg, kg, bg, k_real=c), ops.conv3d_fwd_raw(xg, kg, bg))
+    finally:
+        ops.lib().vvae_conv3d_roll_config(1, 0)

@@ -50,10 +50,12 @@ constexpr Split2 NO_SPLIT{nullptr, 0, 0, nullptr, 0, 0};
 //   lane l: co = co_tile*16 + (l & 15), k = 32*kstep + 8*(l >> 4) + e,  slot = k / CKB -> (dt, dx), ci = chunk*CKB + k % CKB
 // dgrad=0: value = w[dt][dy][dx][ci][co]                (K channels = Cin,  produced = Cout)
 // dgrad=1: value = w[KT-1-dt][KH-1-dy][KW-1-dx][co][ci] (K channels = Cout, produced = Cin; "co" indexes Cin here)
-template <int CKB, int KT, int KH, int KW>
+// CR < CKB ("real" K channels): the tensor carries CKB channels per voxel of which only the first CR are not padding; K then runs
+// over (dt, dx, ci < CR) -- for the 12-channel patch mixer 3 * 7 * 12 = 252 -> 8 k-steps instead of 3 * 7 * 16 = 336 -> 11.
+template <int CKB, int KT, int KH, int KW, int CR = CKB>
 __device__ __forceinline__ void pack_fragment(const float* __restrict__ w, uint4* __restrict__ wp, int Cin, int Cout, int dgrad, long i)
 {
-    constexpr int KSTEPS = (KT * KW * CKB + 31) / 32;
+    constexpr int KSTEPS = (KT * KW * CR + 31) / 32;
     const int CO = dgrad ? Cin : Cout;
     const int co_tiles = CO / 16;
     const int l = (int)(i & 63); long q = i >> 6;
@@ -65,7 +67,7 @@ __device__ __forceinline__ void pack_fragment(const float* __restrict__ w, uint4
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = 32 * j + 8 * (l >> 4) + e;
-        const int slot = k / CKB, ci = chunk * CKB + k % CKB;
+        const int slot = k / CR, ci = chunk * CKB + k % CR;
         float v = 0.f;
         if (slot < KT * KW) {
             const int dt = slot / KW, dx = slot % KW;
@@ -78,20 +80,20 @@ __device__ __forceinline__ void pack_fragment(const float* __restrict__ w, uint4
     wp[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
-template <int CKB, int KT, int KH, int KW>
+template <int CKB, int KT, int KH, int KW, int CR = CKB>
 __global__ void pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int Cin, int Cout, int dgrad)
 {
-    constexpr int KSTEPS = (KT * KW * CKB + 31) / 32;
+    constexpr int KSTEPS = (KT * KW * CR + 31) / 32;
     const int CK = dgrad ? Cout : Cin, CO = dgrad ? Cin : Cout;
     const long total = (long)(CK / CKB) * KH * KSTEPS * (CO / 16) * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-        pack_fragment<CKB, KT, KH, KW>(w, wp, Cin, Cout, dgrad, i);
+        pack_fragment<CKB, KT, KH, KW, CR>(w, wp, Cin, Cout, dgrad, i);
 }
 
 // Grouped form: every conv layer of a network (forward and flipped input-gradient packings) in ONE launch -- weights change once
 // per optimizer step, and 28 five-microsecond launches per step were pure launch latency.  Blocks [block_start_e,
 // block_start_{e+1}) belong to entry e, 256 packed 16-byte fragments-lanes each.  variant: 0 = 3x7x7 / 16-channel chunks,
-// 1 = 3x3x3 / 16, 2 = 3x3x3 / 32.
+// 1 = 3x3x3 / 16, 2 = 3x3x3 / 32, 3 = 3x7x7 / 16-channel voxels with 12 real K channels.
 constexpr int PACK_MAX = 64;
 struct PackEntry { const float* w; uint4* wp; long total; int Cin, Cout, variant, dgrad, block_start; };
 struct PackArgs { PackEntry e[PACK_MAX]; int n; };
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackArgs g)
     const long i = ((long)((int)blockIdx.x - E.block_start)) * 256 + threadIdx.x;
     if (i >= E.total) return;
     if (E.variant == 0) pack_fragment<16, 3, 7, 7>(E.w, E.wp, E.Cin, E.Cout, E.dgrad, i);
+    else if (E.variant == 3) pack_fragment<16, 3, 7, 7, 12>(E.w, E.wp, E.Cin, E.Cout, E.dgrad, i);
     else if (E.variant == 1) pack_fragment<16, 3, 3, 3>(E.w, E.wp, E.Cin, E.Cout, E.dgrad, i);
     else pack_fragment<32, 3, 3, 3>(E.w, E.wp, E.Cin, E.Cout, E.dgrad, i);
 }
@@ -269,24 +272,24 @@ int launch_cfg(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf1
     return 0;
 }
 
-template <int CKB, int KT, int KH, int KW>
+template <int CKB, int KT, int KH, int KW, int CR = CKB>
 int launch_pack(const float* w, uint4* wp, int Cin, int Cout, int dgrad, hipStream_t s)
 {
-    constexpr int KSTEPS = (KT * KW * CKB + 31) / 32;
+    constexpr int KSTEPS = (KT * KW * CR + 31) / 32;
     const int CK = dgrad ? Cout : Cin, CO = dgrad ? Cin : Cout;
     const long total = (long)(CK / CKB) * KH * KSTEPS * (CO / 16) * 64;
     long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL((pack_weights_kernel<CKB, KT, KH, KW>), dim3((unsigned)blocks), dim3(256), 0, s, w, wp, Cin, Cout, dgrad);
+    hipLaunchKernelGGL((pack_weights_kernel<CKB, KT, KH, KW, CR>), dim3((unsigned)blocks), dim3(256), 0, s, w, wp, Cin, Cout, dgrad);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
 
 inline int chunk_of(int CK) { return (CK % 32 == 0) ? 32 : 16; }
 
-inline size_t packed_bytes(int CK, int CO, int kt, int kh, int kw)
+inline size_t packed_bytes(int CK, int CO, int kt, int kh, int kw, int k_real = 0)
 {
     const int ckb = chunk_of(CK);
-    const int ksteps = (kt * kw * ckb + 31) / 32;
+    const int ksteps = (kt * kw * (k_real ? k_real : ckb) + 31) / 32;
     return (size_t)(CK / ckb) * kh * ksteps * (CO / 16) * 64 * 16;
 }
 
@@ -297,7 +300,10 @@ extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, in
 namespace {
 bool roll_enabled();
 int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s,
-                    float* gn_part = nullptr, int gn_groups = 0, Split2 sp = NO_SPLIT);
+                    float* gn_part = nullptr, int gn_groups = 0, Split2 sp = NO_SPLIT, int k_real = 0);
+// flags of the pack / forward entry points: bit 0 = input gradient, bits 8-15 = real K channels of a padded layer (0 = all).  Honoured
+// for the 3x7x7 mixer with 12 real channels on the rolling kernel; anything else packs and multiplies the padded product.
+inline int real_k(int flags, int kh) { return (kh == 7 && ((flags >> 8) & 0xff) == 12 && roll_enabled()) ? 12 : 0; }
 int roll_gn_blocks_any(BfDims d, int kh, int groups);
 }
 
@@ -329,13 +335,15 @@ extern "C" size_t vvae_conv3d_bf16_ws_bytes(int N, int T, int H, int W, int Cin,
 // ws must hold vvae_conv3d_bf16_ws_bytes(.., which = dgrad) bytes.  Weights change once per optimizer step, so a caller
 // may pack once and pass prepacked = 1 to every vvae_conv3d_fwd_bf16 call of that step.
 extern "C" int vvae_conv3d_pack_bf16(const float* w, void* ws, size_t ws_bytes, int Cin, int Cout, int kt, int kh, int kw,
-                                     int dgrad, void* stream)
+                                     int flags, void* stream)
 {
+    const int dgrad = flags & 1, kr = real_k(flags, kh);
     if (!w || !ws || ((uintptr_t)ws % 16)) return VVAE_ERR_BAD_ARG;
     if (!vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, 8, 8, dgrad ? 1 : 0, 0)) return VVAE_ERR_BAD_ARG;
     const int CK = dgrad ? Cout : Cin, CO = dgrad ? Cin : Cout;
-    if (ws_bytes < packed_bytes(CK, CO, kt, kh, kw)) return VVAE_ERR_WORKSPACE;
+    if (ws_bytes < packed_bytes(CK, CO, kt, kh, kw, kr)) return VVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (kh == 7 && kr == 12) return launch_pack<16, 3, 7, 7, 12>(w, (uint4*)ws, Cin, Cout, dgrad, s);
     if (kh == 7) return launch_pack<16, 3, 7, 7>(w, (uint4*)ws, Cin, Cout, dgrad, s);
     if (chunk_of(CK) == 16) return launch_pack<16, 3, 3, 3>(w, (uint4*)ws, Cin, Cout, dgrad, s);
     return launch_pack<32, 3, 3, 3>(w, (uint4*)ws, Cin, Cout, dgrad, s);
@@ -353,12 +361,13 @@ extern "C" int vvae_conv3d_pack_grouped_bf16(const float* const* w, void* const*
     long blocks = 0;
     for (int i = 0; i < n; ++i) {
         if (!w[i] || !ws[i] || ((uintptr_t)ws[i] % 16) || (kh[i] != 3 && kh[i] != 7)) return VVAE_ERR_BAD_ARG;
-        if (!vvae_conv3d_bf16_supported(Cin[i], Cout[i], 3, kh[i], kh[i], 8, 8, dgrad[i] ? 1 : 0, 0)) return VVAE_ERR_BAD_ARG;
-        const int CK = dgrad[i] ? Cout[i] : Cin[i], CO = dgrad[i] ? Cin[i] : Cout[i];
-        const size_t need = packed_bytes(CK, CO, 3, kh[i], kh[i]);
+        const int dg = dgrad[i] & 1, kr = real_k(dgrad[i], kh[i]);          // dgrad[i]: the flags word of vvae_conv3d_pack_bf16
+        if (!vvae_conv3d_bf16_supported(Cin[i], Cout[i], 3, kh[i], kh[i], 8, 8, dg, 0)) return VVAE_ERR_BAD_ARG;
+        const int CK = dg ? Cout[i] : Cin[i], CO = dg ? Cin[i] : Cout[i];
+        const size_t need = packed_bytes(CK, CO, 3, kh[i], kh[i], kr);
         if (ws_bytes[i] < need) return VVAE_ERR_WORKSPACE;
-        const int variant = kh[i] == 7 ? 0 : (chunk_of(CK) == 16 ? 1 : 2);
-        g.e[i] = PackEntry{w[i], (uint4*)ws[i], (long)(need / 16), Cin[i], Cout[i], variant, dgrad[i] ? 1 : 0, (int)blocks};
+        const int variant = kh[i] == 7 ? (kr == 12 ? 3 : 0) : (chunk_of(CK) == 16 ? 1 : 2);
+        g.e[i] = PackEntry{w[i], (uint4*)ws[i], (long)(need / 16), Cin[i], Cout[i], variant, dg, (int)blocks};
         blocks += ceil_div((long)(need / 16), 256L);
     }
     hipLaunchKernelGGL(pack_weights_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
@@ -366,18 +375,20 @@ extern "C" int vvae_conv3d_pack_grouped_bf16(const float* const* w, void* const*
     return 0;
 }
 
-// dgrad = 0: y = conv(x, w) + bias.   dgrad = 1: "x" is dy (Cout channels), "y" is dx (Cin channels), bias ignored.
+// flags bit 0 = 0: y = conv(x, w) + bias.   bit 0 = 1 (input gradient): "x" is dy (Cout channels), "y" is dx (Cin channels), bias
+// ignored.  Bits 8-15: real K channels of a zero-padded layer (see real_k; the SAME flags must be given to the pack call).
 // prepacked = 1: ws already holds the packed weights (w may be NULL).
 extern "C" int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
-                                    int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dgrad,
+                                    int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int flags,
                                     int prepacked, void* ws, size_t ws_bytes, void* stream)
 {
+    const int dgrad = flags & 1, kr = real_k(flags, kh);
     if (!x || (!w && !prepacked) || !y || N <= 0 || T <= 0 || H <= 0 || W <= 0) return VVAE_ERR_BAD_ARG;
     if (!vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, ldy, dgrad ? 1 : 0, 0)) return VVAE_ERR_BAD_ARG;
     if (((uintptr_t)x % 16) || ((uintptr_t)y % 8)) return VVAE_ERR_BAD_ARG;
     const int CK = dgrad ? Cout : Cin, CO = dgrad ? Cin : Cout;
     if (ldx < CK || ldy < CO) return VVAE_ERR_BAD_ARG;
-    const size_t need = packed_bytes(CK, CO, kt, kh, kw);
+    const size_t need = packed_bytes(CK, CO, kt, kh, kw, kr);
     if (!ws || ws_bytes < need || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     uint4* wp = (uint4*)ws;
@@ -386,13 +397,14 @@ extern "C" int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, cons
     const float* bp = dgrad ? nullptr : bias;
     BfDims d{N, T, H, W, CK, CO, 0, 0};
     if (!prepacked) {
-        const int rc = vvae_conv3d_pack_bf16(w, ws, ws_bytes, Cin, Cout, kt, kh, kw, dgrad, stream);
+        const int rc = vvae_conv3d_pack_bf16(w, ws, ws_bytes, Cin, Cout, kt, kh, kw, flags, stream);
         if (rc) return rc;
     }
     if (roll_enabled() && CK == chunk_of(CK)) {                     // single channel chunk: rolling time-column kernel
-        const int rc = launch_roll_any(xp, ldx, wp, bp, yp, ldy, d, kh, s);
+        const int rc = launch_roll_any(xp, ldx, wp, bp, yp, ldy, d, kh, s, nullptr, 0, NO_SPLIT, kr);
         if (rc != VVAE_ERR_BAD_ARG) return rc;
     }
+    if (kr) return VVAE_ERR_BAD_ARG;                                // packed for the real-channel K order: only the rolling kernel reads it
     if (kh == 7) return launch_cfg<C377_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
     if (chunk_of(CK) == 16) {
         if (CO == 16) return launch_cfg<C333_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
@@ -554,7 +566,14 @@ struct PlaneStager {
         for (int it = 0; it < ITERS; ++it) {
             const int lin = (rip + it * RPP) * WRP + wc;                   // SWZ: part ^= ((voxel >> 2) & 1) << 1 (64-byte voxels)
             const int p = SWZ ? (part ^ ((lin >> 1) & 2)) : part;
-            if (rip < RPP && rip + it * RPP < HR) *reinterpret_cast<uint4*>(lds + lin * PITCH + p * 16) = v[it];
+            if (rip < RPP && rip + it * RPP < HR) {
+                if (PITCH % 16 == 0) *reinterpret_cast<uint4*>(lds + lin * PITCH + p * 16) = v[it];
+                else {                                                     // 24-byte voxels (12 real of 16 channels): 8-byte pieces,
+                    unsigned char* q = lds + lin * PITCH + part * 16;      // the 4 padding channels are dropped
+                    *reinterpret_cast<uint2*>(q) = make_uint2(v[it].x, v[it].y);
+                    if (part == 0) *reinterpret_cast<uint2*>(q + 8) = make_uint2(v[it].z, v[it].w);
+                }
+            }
         }
     }
 };
@@ -574,15 +593,19 @@ struct PlaneStager {
 // ({r 0-3, 12-15 | part p} + {r 4-11 | part p^1}) on 16 distinct slots of the 256-byte bank row for any tap shift.
 enum { W_REG = 1, W_LDS = 2 };
 
-template <int CKB_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_, int WMODE_, bool PF_>
+// CR_ < CKB_: only the first CR_ of a voxel's CKB_ channels are real (the rest is zero padding in memory): LDS voxels are packed to
+// 2 CR_ bytes, K runs over (dt, dx, ci < CR_) and a lane's 8-element run is read as two 8-byte halves (a half never straddles a
+// frame plane: KW * CR_ is a multiple of 4).
+template <int CKB_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_, int WMODE_, bool PF_, int CR_ = CKB_>
 struct RollCfg {
-    static constexpr int CKB = CKB_, KT = 3, KH = KH_, KW = KW_, MT_W = MT_W_, NT_W = NT_W_, WM = WM_, WN = WN_, WMODE = WMODE_;
+    static constexpr int CKB = CKB_, KT = 3, KH = KH_, KW = KW_, MT_W = MT_W_, NT_W = NT_W_, WM = WM_, WN = WN_, WMODE = WMODE_, CR = CR_;
     static constexpr bool PF = PF_;                          // request the fragments of k-step j+1 before multiplying k-step j
     static constexpr int NTHREADS = 64 * WM * WN;
     static constexpr int TH = MT_W * WM, TW = 16, HR = TH + KH - 1, WR = TW + KW - 1;
-    static constexpr int PITCH = 2 * CKB;
+    static constexpr int PITCH = 2 * CR;
     static constexpr bool SWZ = CKB == 32;
-    static constexpr int KSTEPS = (KT * KW * CKB + 31) / 32;
+    static constexpr int KSTEPS = (KT * KW * CR + 31) / 32;
+    static_assert(CR == CKB || (CKB == 16 && CR % 4 == 0 && (KW * CR) % 4 == 0), "real-channel form: 16-channel voxels, whole 8-byte pieces");
     static constexpr int PLANE = HR * WR * PITCH;
     static constexpr int CO_T = NT_W * WN, CO_BLK = 16 * CO_T;
     static constexpr int WFRAGS = KH * KSTEPS * CO_T;
@@ -690,6 +713,26 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
 #pragma unroll
                     for (int i = 0; i < NT_W; ++i)
                         wo[dy][i] = __builtin_bit_cast(bf16x8, wl[((dy * KSTEPS + j) * CO_T + wn * NT_W + i) * 64 + lane]);
+            }
+            if (C::CR != CKB) {
+                // K element k = (dt, dx, ci) flattened with ci < CR: the lane's run 32 j + 8 g .. + 7 as two 8-byte halves; the run past
+                // the end of K (zero weights) re-reads the last real one (finite data)
+                constexpr int KP = KW * C::CR, KALL = KT * KP;
+                const unsigned char* hb[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    int k0 = 32 * j + 8 * g + 4 * hh;
+                    if (k0 >= KALL) k0 = KALL - 4;
+                    const int dt = (k0 >= KP) + (k0 >= 2 * KP);
+                    hb[hh] = smem + ((tt + dt - 1) & 3) * PLANE + lin_w * PITCH + (k0 - dt * KP) * 2;
+                }
+#pragma unroll
+                for (int hr = 0; hr < NX; ++hr) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(hb[0] + hr * WR * PITCH);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(hb[1] + hr * WR * PITCH);
+                    xo[hr] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+                return;
             }
             int slot, part;
             if (CKB == 32) { slot = j < KT * KW ? j : 0; part = g; }
@@ -832,6 +875,8 @@ int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf
 
 //              CKB KH KW MT_W NT_W WM WN weights prefetch                 (per-layer sweep: tools/conv_bench.py)
 typedef RollCfg<16, 7, 7, 2, 1, 8, 1, W_LDS, true> R377;         // patch mixer: TH 16, 77 KB of weights behind a 61 KB ring
+typedef RollCfg<16, 7, 7, 4, 1, 8, 1, W_LDS, true, 12> R377_12;  // ... with 12 real of its 16 K channels: 8 k-steps instead of 11, and
+                                                                 // TH 32: a weight fragment read from LDS feeds 4 output rows
 typedef RollCfg<16, 3, 3, 4, 1, 4, 1, W_REG, false> R16_16;      // TH 16
 typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false> R16_32;      // TH 8, one output-channel tile per wave
 typedef RollCfg<32, 3, 3, 2, 1, 8, 1, W_REG, false> R32_16;      // TH 16, 8 waves
@@ -840,10 +885,11 @@ typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false> R32_32;      // TH 16, 8 wav
 #define ROLL(C) do { if (gn_part) return launch_roll<C, true>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups, sp); \
                      return launch_roll<C, false>(x, ldx, wp, bias, y, ldy, d, s, nullptr, 0, sp); } while (0)
 int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, int kh, hipStream_t s,
-                    float* gn_part, int gn_groups, Split2 sp)
+                    float* gn_part, int gn_groups, Split2 sp, int k_real)
 {
     if (kh == 7) {
         if (gn_part || sp.x2 || sp.y2) return VVAE_ERR_BAD_ARG;
+        if (k_real == 12) return launch_roll<R377_12, false>(x, ldx, wp, bias, y, ldy, d, s, nullptr, 0, NO_SPLIT);
         return launch_roll<R377, false>(x, ldx, wp, bias, y, ldy, d, s, nullptr, 0, NO_SPLIT);
     }
     if (d.CK == 16 && d.CO == 16) ROLL(R16_16);

@@ -152,9 +152,10 @@ def force_generic_conv(on):
     lib().vvae_conv3d_force_generic(1 if on else 0)
 
 
-def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None):
+def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None, k_real=0):
     """Shared by fwd (dgrad=0) and dgrad (dgrad=1): bf16 fast path (weights packed here, or already packed for the whole step by
-    conv3d_prepack: ``packed``), else the dispatcher."""
+    conv3d_prepack: ``packed``), else the dispatcher.  ``k_real``: how many of the layer's K channels are not zero padding (0 = all):
+    the matrix-core kernels that know the count skip the padded part of the product (the 12-of-16 channel patch mixer)."""
     n, t, h, w, cin, cout, kt, kh, kw = dims
     dt = _dt(x)
     ldo = out.stride(-2)
@@ -166,16 +167,17 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None):
     name = "dgrad" if dgrad else "fwd"
     tag = f"conv3d_{name} {ck}->{co} k{kt}{kh}{kw} @{h}x{w}"
     if _bf16_fast(cin, cout, kt, kh, kw, ldx, ldo, 1 if dgrad else 0, dt):
+        flags = (1 if dgrad else 0) | (int(k_real) << 8)             # include/vvae_hip.h: vvae_conv3d_fwd_bf16
         if packed is not None:
             ws, wsb = packed, packed.numel()
         else:
             wsb = lib().vvae_conv3d_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw, 1 if dgrad else 0)
             ws, wsb = _ws(wsb, x.device)
-            check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, 1 if dgrad else 0, _stream()),
+            check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, flags, _stream()),
                   "vvae_conv3d_pack_bf16")
         check(_launch(tag, alg, flops, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
                       lambda: lib().vvae_conv3d_fwd_bf16(_p(x), ldx, None, _p(bias), _p(out), ldo, n, t, h, w, cin, cout, kt, kh,
-                                                         kw, 1 if dgrad else 0, 1, _p(ws), wsb, _stream())),
+                                                         kw, flags, 1, _p(ws), wsb, _stream())),
               "vvae_conv3d_fwd_bf16")
         return out
     fn = lib().vvae_conv3d_dgrad if dgrad else lib().vvae_conv3d_fwd
@@ -188,24 +190,24 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None):
 
 
 # --------------------------------------------------------------------------------------------- Conv3d
-def conv3d_fwd_raw(x, kernel, bias, out=None, packed=None):
+def conv3d_fwd_raw(x, kernel, bias, out=None, packed=None, k_real=0):
     x, ldx = rows(x)
     n, t, h, w, cin = x.shape
     kt, kh, kw, cin2, cout = kernel.shape
     assert cin == cin2, (cin, cin2)
     if out is None:
         out = torch.empty((n, t, h, w, cout), dtype=x.dtype, device=x.device)
-    return _conv_fwd_like(x, ldx, kernel, bias, out, (n, t, h, w, cin, cout, kt, kh, kw), 0, packed)
+    return _conv_fwd_like(x, ldx, kernel, bias, out, (n, t, h, w, cin, cout, kt, kh, kw), 0, packed, k_real)
 
 
-def conv3d_dgrad_raw(dy, kernel, out=None, packed=None):
+def conv3d_dgrad_raw(dy, kernel, out=None, packed=None, k_real=0):
     dy, lddy = rows(dy)
     n, t, h, w, cout = dy.shape
     kt, kh, kw, cin, cout2 = kernel.shape
     assert cout == cout2
     if out is None:
         out = torch.empty((n, t, h, w, cin), dtype=dy.dtype, device=dy.device)
-    return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1, packed)
+    return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1, packed, k_real)
 
 
 class ConvPack:
@@ -216,10 +218,12 @@ class ConvPack:
         self.fwd, self.dgrad = fwd, dgrad
 
 
-def conv3d_prepack(kernels):
+def conv3d_prepack(kernels, reals=None):
     """Pack the weights of every conv layer of a network -- forward and flipped input-gradient forms -- in ONE launch
     (vvae_conv3d_pack_grouped_bf16).  ``kernels``: fp32 GPU tensors (3, kh, kw, Cin, Cout); -> list of ConvPack (None for a layer
-    the bf16 matrix-core kernels do not take).  Weights change once per optimizer step; packing per call was 28 launches a step."""
+    the bf16 matrix-core kernels do not take).  Weights change once per optimizer step; packing per call was 28 launches a step.
+    ``reals``: per kernel None or (real Cin, real Cout) of a zero-padded layer (conv3d's ``real``)."""
+    reals = reals if reals is not None else [None] * len(kernels)
     specs, sizes = [], []
     for k in kernels:
         kt, kh, kw, cin, cout = k.shape
@@ -235,7 +239,7 @@ def conv3d_prepack(kernels):
     buf = torch.empty(sum(sizes), dtype=torch.uint8, device=kernels[0].device)
     packs, off, ent = [], 0, []
     it = iter(sizes)
-    for k, ok in zip(kernels, specs):
+    for k, ok, real in zip(kernels, specs, reals):
         if not ok:
             packs.append(None)
             continue
@@ -245,7 +249,7 @@ def conv3d_prepack(kernels):
             v = buf[off:off + nb]
             off += nb
             views.append(v)
-            ent.append((k.contiguous(), v, which))
+            ent.append((k.contiguous(), v, which | ((int(real[which]) << 8) if real is not None else 0)))
         packs.append(ConvPack(views[0], views[1]))
     for i0 in range(0, len(ent), 64):
         e = ent[i0:i0 + 64]
@@ -309,10 +313,11 @@ def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk, packed=None):
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias, gn_groups=0, gn_blocks=0, pack=None):
+    def forward(ctx, x, kernel, bias, gn_groups=0, gn_blocks=0, pack=None, real=None):
         k32 = _f32(kernel)
         b32 = _f32(bias) if bias is not None else None
         ctx.save_for_backward(x, k32)
+        ctx.real = real                                  # (real Cin, real Cout) of a zero-padded layer, or None
         ctx.has_bias = bias is not None
         ctx.kdtype = kernel.dtype
         ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the gradient may be written directly
@@ -323,18 +328,19 @@ class _Conv3d(torch.autograd.Function):
             ctx.with_part = True
             return y, part
         ctx.with_part = False
-        return conv3d_fwd_raw(x, k32, b32, packed=pack.fwd if pack is not None else None)
+        return conv3d_fwd_raw(x, k32, b32, packed=pack.fwd if pack is not None else None, k_real=real[0] if real is not None else 0)
 
     @staticmethod
     def backward(ctx, dy, dpart=None):
         dx, dw, db = _Conv3d._backward(ctx, dy)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
     @staticmethod
     def _backward(ctx, dy):
         x, k32 = ctx.saved_tensors
         dy = dy.to(x.dtype)
-        dx = conv3d_dgrad_raw(dy, k32, packed=ctx.pack.dgrad if ctx.pack is not None else None) if ctx.needs_input_grad[0] else None
+        dx = (conv3d_dgrad_raw(dy, k32, packed=ctx.pack.dgrad if ctx.pack is not None else None,
+                               k_real=ctx.real[1] if ctx.real is not None else 0) if ctx.needs_input_grad[0] else None)
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             q = WGRAD_QUEUE[0]
@@ -477,9 +483,10 @@ def conv3d_cat2_with_gn_stats(xa, xb, kernel, bias, groups, pack=None):
     return y, (part, nblk)
 
 
-def conv3d(x, kernel, bias=None, pack=None):
-    """NDHWC Conv3d, SAME, stride 1 (nnx.Conv; reference train/unet.py:13-21).  ``pack``: from conv3d_prepack."""
-    return _Conv3d.apply(x, kernel, bias, 0, 0, pack)
+def conv3d(x, kernel, bias=None, pack=None, real=None):
+    """NDHWC Conv3d, SAME, stride 1 (nnx.Conv; reference train/unet.py:13-21).  ``pack``: from conv3d_prepack.  ``real``: (Cin, Cout)
+    actually in use when x / kernel / bias are zero-padded to the kernels' channel granule (must match the prepack call's)."""
+    return _Conv3d.apply(x, kernel, bias, 0, 0, pack, real)
 
 
 def conv3d_with_gn_stats(x, kernel, bias, groups, pack=None):
@@ -488,8 +495,8 @@ def conv3d_with_gn_stats(x, kernel, bias, groups, pack=None):
     (reference train/unet.py:13-23) skips its own statistics pass over the tensor."""
     nblk = conv3d_gn_blocks(x, kernel, groups) if bias is not None else 0
     if not nblk:
-        return _Conv3d.apply(x, kernel, bias, 0, 0, pack), None
-    y, part = _Conv3d.apply(x, kernel, bias, groups, nblk, pack)
+        return _Conv3d.apply(x, kernel, bias, 0, 0, pack, None), None
+    y, part = _Conv3d.apply(x, kernel, bias, groups, nblk, pack, None)
     return y, (part, nblk)
 
 

@@ -157,6 +157,8 @@ class UNet(nn.Module):
                 raise ValueError(f"UNet expects {c} (or {c + pad} zero-padded) input channels, got {x.shape[-1]}")
             km, bm = F.pad(km, (0, pad, 0, pad)), F.pad(bm, (0, pad))
             k1 = F.pad(self.encoders[0].conv1.conv.kernel, (0, 0, 0, pad))
+        # the padded mixer tells the kernels how many of its 16 K channels are real: the product over the padding is skipped
+        mixer_real = (c, c) if pad else None
         # every conv layer's weights are packed for the matrix-core kernels once per step, in one launch (they were 28 launches)
         packs = None
         if x.is_cuda and self.dtype == torch.bfloat16:
@@ -166,9 +168,9 @@ class UNet(nn.Module):
             ks += [self.bottleneck1.conv.kernel, self.bottleneck2.conv.kernel]
             for dec in self.decoders:
                 ks += [dec.conv1.conv.kernel, dec.conv2.conv.kernel]
-            packs = ops.conv3d_prepack([k.detach() for k in ks])
+            packs = ops.conv3d_prepack([k.detach() for k in ks], [mixer_real] + [None] * (len(ks) - 1))
         pk = (lambda j: packs[j]) if packs is not None else (lambda j: None)
-        x = ops.conv3d(x.to(self.patch_mixer.dtype), km, bm, pack=pk(0))
+        x = ops.conv3d(x.to(self.patch_mixer.dtype), km, bm, pack=pk(0), real=mixer_real)
         skips, joints = [], []
         for i, enc in enumerate(self.encoders):
             c = enc.conv2.norm.scale.shape[0]
