@@ -17,7 +17,8 @@ tchunks = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0").split(","
 N, T = 4, 16
 # (cin, cout, (kt,kh,kw), H): fwd runs CK=cin -> CO=cout, dgrad runs CK=cout -> CO=cin
 shapes = [(16, 16, (3, 7, 7), 256), (16, 16, (3, 3, 3), 256), (32, 16, (3, 3, 3), 256), (32, 32, (3, 3, 3), 128),
-          (16, 32, (3, 3, 3), 128), (64, 32, (3, 3, 3), 128), (32, 64, (3, 3, 3), 64)]
+          (16, 32, (3, 3, 3), 128), (64, 32, (3, 3, 3), 128), (32, 64, (3, 3, 3), 64), (64, 64, (3, 3, 3), 64), (128, 64, (3, 3, 3), 64),
+          (64, 128, (3, 3, 3), 32), (128, 128, (3, 3, 3), 32)]
 torch.manual_seed(0)
 for cin, cout, k, H in shapes:
     x = torch.randn(N, T, H, H, cin, device=dev, dtype=torch.bfloat16)

@@ -879,7 +879,8 @@ typedef RollCfg<16, 7, 7, 4, 1, 8, 1, W_LDS, true, 12> R377_12;  // ... with 12 
                                                                  // TH 32: a weight fragment read from LDS feeds 4 output rows
 typedef RollCfg<16, 3, 3, 4, 1, 4, 1, W_REG, false> R16_16;      // TH 16
 typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false> R16_32;      // TH 8, one output-channel tile per wave
-typedef RollCfg<32, 3, 3, 2, 1, 8, 1, W_REG, false> R32_16;      // TH 16, 8 waves
+typedef RollCfg<32, 3, 3, 4, 1, 8, 1, W_REG, false> R32_16;      // TH 32, 8 waves, 157 KB ring (TH 16 with 2 rows per wave read 4 X
+                                                                 // fragments per 6 products: 153 -> 129 us at 256^2; taller tiles lose elsewhere)
 typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false> R32_32;      // TH 16, 8 waves, one output-channel tile per wave
 
 #define ROLL(C) do { if (gn_part) return launch_roll<C, true>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups, sp); \
