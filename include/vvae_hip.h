@@ -29,6 +29,7 @@ extern "C" {
 #define VVAE_DT_BF16 1
 #define VVAE_ERR_BAD_ARG 1001
 #define VVAE_ERR_WORKSPACE 1002
+#define VVAE_ERR_LIBRARY 1003
 
 /* ---- Conv3d, SAME padding, stride 1, odd kernel: nnx.Conv at train/unet.py:13-21 (3x3x3 ConvBlock3D),
  *      :111-113 (3x7x7 patch_mixer), :144-153 (1x1x1 final_conv) and their autodiff (dgrad, wgrad). ---- */
@@ -103,6 +104,13 @@ int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx
                               void* stream);
 int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, long V, int Cin, int Cout,
                               int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Linear + bias + residual in one library product: y (M,N) = x (M,K) w (K,N) + bias (N) + res (M,N), bf16, fp32 accumulation.
+ *      The Linear that closes an attention / MLP branch followed by `x = x + branch` (train/layers.py:212-221, 151, 189): hipBLASLt
+ *      reads the residual stream as its C operand (beta = 1, C != D), so the add costs no pass of its own.  bias: NULL / bf16 / fp32
+ *      (bias_dtype); res: NULL = plain Linear; ws: device scratch for the library (16-byte aligned; 0 allowed). ---- */
+int vvae_linear_residual_bf16(const void* x, int ldx, const void* w, int ldw, const void* bias, int bias_dtype, const void* res, int ldr,
+                              void* y, int ldy, int M, int N, int K, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- PatchUnEmbedding's "b t (h w) (p1 p2 cu) -> b t (h p1) (w p2) cu" (train/layers.py:48) fused with the zero padding of the
  *      channel axis from cu to c (the multiple of 16 the conv kernels take), and its transpose.  frames = b*t; bf16; cu, c % 4 == 0. ---- */

@@ -1160,3 +1160,30 @@ def test_patch_mixer_real_channel_product_equals_padded_product(dev):
         assert torch.equal(ops.conv3d_fwd_raw(xg, kg, bg, k_real=c), ops.conv3d_fwd_raw(xg, kg, bg))
     finally:
         ops.lib().vvae_conv3d_roll_config(1, 0)
+
+
+@pytest.mark.parametrize("m,k,n", [(16384, 512, 768), (4096, 1536, 768), (256, 64, 64)])
+def test_linear_residual_library_product(dev, m, k, n):
+    """y = x W + bias + res in one library product (vvae_linear_residual_bf16: hipBLASLt with the residual as its C operand) against
+    the fp32 oracle of `x_skip + Linear(...)` (reference train/layers.py:151,189,212-221); bf16 operands, one rounding.  Pitched x / res
+    rows and the plain (res = None) form too."""
+    from video_vae_amd import ops
+    x = _bf16_exact((m, k), 80, 1.0)
+    w = _bf16_exact((k, n), 81, k ** -0.5)
+    b = _bf16_exact((n,), 82, 0.1)
+    r = _bf16_exact((m, n), 83, 1.0)
+    ref = x.double() @ w.double() + b.double() + r.double()
+    xg, wg, bg, rg = (t.to(dev, torch.bfloat16) for t in (x, w, b, r))
+    assert ops.linear_residual_ok(xg, wg, bg, rg)
+    y = ops.linear_residual(xg, wg, bg, rg)
+    assert y.dtype == torch.bfloat16 and y.shape == (m, n)
+    assert_close(y, ref, rtol=1e-2, atol=2e-2, what="x W + b + res")
+    # not worse than the separate path (product rounded to bf16, then the add rounded again)
+    two_step = (torch.addmm(bg, xg, wg) + rg)
+    e1 = float((y.double().cpu() - ref).abs().mean()); e2 = float((two_step.double().cpu() - ref).abs().mean())
+    assert e1 <= e2 * 1.05 + 1e-6, (e1, e2)
+    assert_close(ops.linear_residual(xg, wg, bg, None), x.double() @ w.double() + b.double(), rtol=1e-2, atol=2e-2, what="plain form")
+    wide_x = torch.zeros((m, k + 8), dtype=torch.bfloat16, device=dev); wide_x[:, :k] = xg
+    wide_r = torch.zeros((m, n + 8), dtype=torch.bfloat16, device=dev); wide_r[:, :n] = rg
+    assert torch.equal(ops.linear_residual(wide_x[:, :k], wg, bg, wide_r[:, :n]), y)
+    assert torch.equal(ops.linear_residual(xg, wg, bg, rg), y), "bitwise reproducible"

@@ -2,7 +2,7 @@
 
 * production-shaped bf16 FactoredAttention blocks (C = 768, 8 heads x 64, MLP 1536, hw = 256, T = 16, masked tail) -- forward
   and EVERY gradient against the CPU oracle: reaches tattn_*_fast<64>, sattn_*, gemm_nt's silu' epilogue, the deferred
-  gemm_tn256_grouped launch, add+LayerNorm at C = 768 and the pending/defer residual protocol;
+  gemm_tn256_grouped launch, the residual-accumulating library product, LayerNorm at C = 768 and the pending/defer residual protocol;
 * bf16 UNet at C1 size: forward and every parameter gradient against the oracle's bf16 emulation (conv3d_bf16_roll / wgrad /
   GroupNorm-statistics epilogue / ConvTranspose MFMA kernels);
 * loss-curve parity (north_star: "recon+KL loss curve matching the CPU reference"; property source
@@ -136,7 +136,7 @@ def test_factored_attention_production_shape_bf16_vs_oracle(dev):
     # the production instantiations were the ones that ran
     seen = " | ".join(sorted(set(names)))
     for must in ("temporal_attn_fwd T16 D64", "temporal_attn_bwd T16 D64", "spatial_attn_fwd S256 D64", "spatial_attn_bwd S256 D64",
-                 "gemm_tn_grouped", "add_layernorm_fwd C768", "layernorm_bwd C768+skip"):
+                 "gemm_tn_grouped", "linear+residual", "layernorm_fwd C768", "layernorm_bwd C768+skip"):
         assert must in seen, (must, seen)
     report = []
     check_bf16("out", yg, y_emu, y_ref, report)

@@ -14,6 +14,7 @@
 
 #define VVAE_ERR_BAD_ARG 1001     // outside hipError_t's range
 #define VVAE_ERR_WORKSPACE 1002
+#define VVAE_ERR_LIBRARY 1003     // a library call (hipBLASLt) failed
 
 typedef uint16_t bf16_t;
 

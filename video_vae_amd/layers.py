@@ -77,7 +77,9 @@ class _LinearBf16(torch.autograd.Function):
     fp32 weight / bias gradients directly."""
 
     @staticmethod
-    def forward(ctx, x, kernel, bias):
+    def forward(ctx, x, kernel, bias, res=None):
+        """``res``: the residual stream this Linear closes a branch of (x_skip + Linear(...)): added inside the library product
+        (ops.linear_residual); the caller checked ops.linear_residual_ok."""
         wb = getattr(kernel, "bf16", None)
         if wb is None:
             wb = kernel.detach().to(torch.bfloat16)
@@ -88,6 +90,9 @@ class _LinearBf16(torch.autograd.Function):
         ctx.save_for_backward(x2, wb)
         ctx.xshape = x.shape
         ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the parked gradient is to be written
+        ctx.has_res = res is not None
+        if res is not None:
+            return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1])).view(res.shape)
         return torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1])
 
     @staticmethod
@@ -96,19 +101,20 @@ class _LinearBf16(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.dtype != torch.bfloat16:
             dy2 = dy2.to(torch.bfloat16)
+        dres = dy if ctx.has_res else None               # the residual edge: identity
         dx = torch.mm(dy2, wb.t()).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ops.wgrad_deferrable(x2, dy2, ctx.kparam, ctx.bparam):
             # parked: multiplied after backward in a grouped launch, straight into the optimizer's flat gradient buffer
             ops.WGRAD_QUEUE[0].append((x2, dy2, ctx.kparam, ctx.bparam))
-            return dx, None, None
+            return dx, None, None, dres
         if ctx.needs_input_grad[1] and ops.gemm_tn_supported(x2, dy2):
             # split-K weight-gradient GEMM on the HIP kernel (bias gradient rides along): K = tokens >> M, N
             dw, db = ops.gemm_tn(x2, dy2, ctx.needs_input_grad[2])
         else:
             dw = _dw_f32(x2, dy2) if ctx.needs_input_grad[1] else None
             db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, dres
 
 
 class _SiluLinearBf16(torch.autograd.Function):
@@ -117,13 +123,16 @@ class _SiluLinearBf16(torch.autograd.Function):
     round trip through HBM that a separate silu_backward launch costs).  Forward = the library GEMM + the framework's SiLU."""
 
     @staticmethod
-    def forward(ctx, h, kernel, bias):
+    def forward(ctx, h, kernel, bias, res=None):
         wb, bb = kernel.bf16, bias.bf16
         h2 = h.reshape(-1, h.shape[-1])
         a = F.silu(h2)
         ctx.save_for_backward(h2, a, wb)
         ctx.hshape = h.shape
         ctx.kparam, ctx.bparam = kernel, bias
+        ctx.has_res = res is not None
+        if res is not None:                                          # x_skip + linear2(silu(h)): the add rides in the library product
+            return ops.linear_residual(a, wb, bb, res.reshape(-1, wb.shape[1])).view(res.shape)
         return torch.addmm(bb, a, wb).view(*h.shape[:-1], wb.shape[1])
 
     @staticmethod
@@ -133,6 +142,7 @@ class _SiluLinearBf16(torch.autograd.Function):
         if dy2.dtype != torch.bfloat16:
             dy2 = dy2.to(torch.bfloat16)
         dy2 = dy2.contiguous()
+        dres = dy if ctx.has_res else None
         dh = None
         if ctx.needs_input_grad[0]:
             if ops.gemm_nt_supported(dy2, wb):                      # wb (mlp, out) is the (N, K) operand as stored
@@ -143,21 +153,39 @@ class _SiluLinearBf16(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ops.wgrad_deferrable(a, dy2, ctx.kparam, ctx.bparam):
             ops.WGRAD_QUEUE[0].append((a, dy2, ctx.kparam, ctx.bparam))
-            return dh, None, None
+            return dh, None, None, dres
         if ctx.needs_input_grad[1] and ops.gemm_tn_supported(a, dy2):
             dw, db = ops.gemm_tn(a, dy2, ctx.needs_input_grad[2])
         else:
             dw = _dw_f32(a, dy2) if ctx.needs_input_grad[1] else None
             db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        return dh, dw, db
+        return dh, dw, db, dres
+
+
+def _shadowed(linear, h):
+    return (linear.dtype == torch.bfloat16 and h.is_cuda and h.dtype == torch.bfloat16 and linear.kernel.dtype == torch.float32
+            and getattr(linear.kernel, "bf16", None) is not None and getattr(linear.bias, "bf16", None) is not None)
 
 
 def silu_linear(h, linear):
     """linear(silu(h)); fused-backward form when the layer runs the bf16 GPU path with shadowed fp32 parameters."""
-    if (linear.dtype == torch.bfloat16 and h.is_cuda and h.dtype == torch.bfloat16 and linear.kernel.dtype == torch.float32
-            and getattr(linear.kernel, "bf16", None) is not None and getattr(linear.bias, "bf16", None) is not None):
+    if _shadowed(linear, h):
         return _SiluLinearBf16.apply(h, linear.kernel, linear.bias)
     return linear(F.silu(h))
+
+
+def close_branch(linear, o, skip, defer, silu=False):
+    """The end of a residual branch: ``skip + linear(o)`` (``linear(silu(o))`` with silu=True; reference train/layers.py:212-221).
+    On the bf16 GPU path the add rides in the library product as its C operand and the result is the new residual stream:
+    -> (sum, None) if defer else sum.  Elsewhere -> (skip, branch) if defer (the next LayerNorm kernel adds) else skip + branch."""
+    if _shadowed(linear, o) and skip.dtype == torch.bfloat16:
+        o2, r2 = o.reshape(-1, o.shape[-1]), skip.reshape(-1, skip.shape[-1])
+        if ops.linear_residual_ok(o2, linear.kernel.bf16, linear.bias.bf16, r2):
+            fn = _SiluLinearBf16 if silu else _LinearBf16
+            s = fn.apply(o, linear.kernel, linear.bias, skip)
+            return (s, None) if defer else s
+    y = silu_linear(o, linear) if silu else linear(o)
+    return (skip, y) if defer else skip + y
 
 
 class Linear(nn.Module):
@@ -202,9 +230,12 @@ class LayerNorm(nn.Module):
         inside the LayerNorm kernel (one pass over the stream instead of an add launch followed by a LayerNorm launch)."""
         if pending is not None:
             skip, o = pending
-            if skip.dtype == self.dtype and ops.layer_norm_supported(skip):
+            if o is None:                                # the previous branch already added itself (close_branch)
+                x = skip
+            elif skip.dtype == self.dtype and ops.layer_norm_supported(skip):
                 return ops.add_layer_norm_fork(skip, o, self.scale, self.bias, 1e-6)
-            x = skip + o
+            else:
+                x = skip + o
         if x.dtype == self.dtype and ops.layer_norm_supported(x):
             return ops.layer_norm_fork(x, self.scale, self.bias, 1e-6)
         return self.forward(x), x
@@ -349,8 +380,7 @@ class Attention(nn.Module):
             div = (b * hw) // m8.shape[0]
         o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
                                         m8, div, self.num_heads, 1e-6, inner=hw)
-        o = self.out_projection(o)
-        return (skip, o) if defer else skip + o
+        return close_branch(self.out_projection, o, skip, defer)
 
     def residual(self, x, mask=None, pending=None, defer=False):
         """x + self(x) with the skip gradient folded into the input LayerNorm's backward (pending / defer: LayerNorm.fork)."""
@@ -388,10 +418,9 @@ class Attention(nn.Module):
                     mask.to(torch.bool).repeat_interleave(a // mask.shape[0], dim=0)
             o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=am)
             o = rearrange(o, "b h s d -> b s (h d)")
-        o = self.out_projection(o)
         if not _residual:
-            return o
-        return (skip, o) if _defer else skip + o
+            return self.out_projection(o)
+        return close_branch(self.out_projection, o, skip, _defer)
 
 
 class MLP(nn.Module):
@@ -409,8 +438,7 @@ class MLP(nn.Module):
     def residual(self, x, pending=None, defer=False):
         """x + self(x) with the skip gradient folded into the LayerNorm's backward (pending / defer: LayerNorm.fork)."""
         y, skip = self.norm.fork(x, pending)
-        o = silu_linear(self.linear1(y), self.linear2)
-        return (skip, o) if defer else skip + o
+        return close_branch(self.linear2, self.linear1(y), skip, defer, silu=True)
 
 
 class FactoredAttention(nn.Module):
@@ -441,13 +469,13 @@ class FactoredAttention(nn.Module):
             # LayerNorm kernel of the following block
             p = ta.forward_temporal_strided(x, mask=temporal_mask, pending=pending, defer=True)
             p = self.TemporalMLP.residual(None, pending=p, defer=True)
-            p = (p[0].reshape(b * t, hw, c), p[1].reshape(b * t, hw, c))
+            p = (p[0].reshape(b * t, hw, c), None if p[1] is None else p[1].reshape(b * t, hw, c))
             p = self.SpatialAttention.residual(None, pending=p, defer=True)
             p = self.SpatialMLP.residual(None, pending=p, defer=True)
-            p = (p[0].view(b, t, hw, c), p[1].view(b, t, hw, c))
-            return p if defer else p[0] + p[1]
+            p = (p[0].view(b, t, hw, c), None if p[1] is None else p[1].view(b, t, hw, c))
+            return p if defer else (p[0] if p[1] is None else p[0] + p[1])
         if pending is not None:
-            x = pending[0] + pending[1]
+            x = pending[0] if pending[1] is None else pending[0] + pending[1]
         tx = rearrange(x, "b t hw c -> (b hw) t c")
         tx = self.TemporalAttention.residual(tx, mask=temporal_mask)
         tx = self.TemporalMLP.residual(tx)

@@ -1262,6 +1262,33 @@ def layer_norm_fork(x, scale, bias=None, eps=1e-6):
     return _LayerNorm.apply(x, scale, bias, eps, True)
 
 
+# --------------------------------------------------------------------------------------------- Linear + bias + residual (library GEMM)
+_LT_WS = {}
+
+
+def linear_residual_ok(x2, wb, bb, res):
+    """bf16 GPU operands the residual-accumulating library product takes (contiguous rows, 16-byte aligned)."""
+    ts = (x2, wb, res) if bb is None else (x2, wb, res, bb)
+    return (all(t.is_cuda and t.dtype == torch.bfloat16 for t in ts) and x2.dim() == 2 and res.dim() == 2 and x2.stride(1) == 1
+            and wb.is_contiguous() and res.stride(1) == 1 and res.shape == (x2.shape[0], wb.shape[1]) and x2.shape[1] == wb.shape[0]
+            and x2.shape[1] % 8 == 0 and wb.shape[1] % 8 == 0 and x2.stride(0) % 8 == 0 and res.stride(0) % 8 == 0
+            and x2.data_ptr() % 16 == 0 and res.data_ptr() % 16 == 0)
+
+
+def linear_residual(x2, wb, bb, res):
+    """-> x2 @ wb + bb + res (bf16, fp32 accumulation, one rounding): vvae_linear_residual_bf16.  ``res`` None = plain Linear."""
+    m, k = x2.shape
+    n = wb.shape[1]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=x2.device)
+    ws = _LT_WS.get(x2.device)
+    if ws is None:
+        ws = _LT_WS[x2.device] = torch.empty(32 << 20, dtype=torch.uint8, device=x2.device)
+    check(_launch(f"linear+residual {m}x{n} K{k}", (m * k + k * n + (2 if res is not None else 1) * m * n) * 2, 2 * m * n * k, "Cijk_",
+                  lambda: lib().vvae_linear_residual_bf16(_p(x2), x2.stride(0), _p(wb), n, _p(bb), 1, _p(res), res.stride(0) if res is not None else 0,
+                                                          _p(out), n, m, n, k, _p(ws), ws.numel(), _stream())), "vvae_linear_residual_bf16")
+    return out
+
+
 # --------------------------------------------------------------------------------------------- dense NT GEMM (Linear fwd / dgrad)
 EPI_NONE, EPI_RES, EPI_SILU, EPI_MUL_DSILU = 0, 1, 2, 3
 
