@@ -21,7 +21,7 @@ rm -rf $O/prof_default $O/pmc_fetch $O/pmc_write
 for f in bench_default_line bench_input_pipeline_line bench_c5_b2_t32_line bench_force_ddp_line; do python - <<PY
 import json
 try:
-    d = json.load(open("$O/$f.json"))
+    d = json.loads(open("$O/$f.json").read().strip().splitlines()[-1])          # RCCL prints its version banner on stdout first
     print("$f", round(d["value"], 1), "frames/s", round(d["ms_per_step"], 2), "ms/step", d.get("rccl_ranks"), (d.get("roofline") or {}).get("frac"))
 except Exception as e:
     print("$f", "unreadable:", e)
