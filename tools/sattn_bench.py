@@ -2,7 +2,7 @@ import torch, sys
 sys.path.insert(0, ".")
 from video_vae_amd import ops
 
-from oracle import layers as OL
+from video_vae_amd.layers import RotaryEmbedding
 dev = "cuda"
 def tmg(f, n=10):
     st = torch.cuda.Stream()
@@ -21,7 +21,7 @@ def tmg(f, n=10):
 a, s, heads, d = 64, 256, 8, 64
 qkv = torch.randn(a, s, 3 * heads * d, device=dev, dtype=torch.bfloat16)
 qs = torch.ones(d, device=dev); ks = torch.ones(d, device=dev)
-cos, sin = OL.rope_tables(d, 256); cos, sin = cos.to(dev), sin.to(dev)
+rope = RotaryEmbedding(d, 256); cos, sin = rope.cos_cached.to(dev).contiguous(), rope.sin_cached.to(dev).contiguous()
 do = torch.randn(a, s, heads * d, device=dev, dtype=torch.bfloat16)
 out, lse2 = ops.spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads)
 tf = tmg(lambda: ops.spatial_attn_fwd_raw(qkv, qs, ks, cos, sin, heads))

@@ -7,7 +7,7 @@ timed on the production shape through the C ABI (hipGraph replay).  Timing only:
 import ctypes, glob, os, sys
 import torch
 sys.path.insert(0, ".")
-from oracle import layers as OL
+from video_vae_amd.layers import RotaryEmbedding
 
 dev = "cuda"
 a, s, heads, d = 64, 256, 8, 64
@@ -18,7 +18,7 @@ dqkv = torch.empty_like(qkv)
 lse = torch.zeros(a * heads, s, device=dev)
 part = torch.empty(a * heads, 2, d, device=dev)
 qs = torch.ones(d, device=dev); ks = torch.ones(d, device=dev)
-cos, sin = OL.rope_tables(d, 256); cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+rope = RotaryEmbedding(d, 256); cos, sin = rope.cos_cached.to(dev).contiguous(), rope.sin_cached.to(dev).contiguous()
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 
 
