@@ -105,6 +105,10 @@ int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx
 int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, long V, int Cin, int Cout,
                               int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- y = silu(x) over a contiguous bf16 tensor of n elements (n % 8 == 0): the activation between the MLP's two Linear layers
+ *      (train/layers.py:186-189). ---- */
+int vvae_silu_bf16(const void* x, void* y, long n, void* stream);
+
 /* ---- Linear + bias + residual in one library product: y (M,N) = x (M,K) w (K,N) + bias (N) + res (M,N), bf16, fp32 accumulation.
  *      The Linear that closes an attention / MLP branch followed by `x = x + branch` (train/layers.py:212-221, 151, 189): hipBLASLt
  *      reads the residual stream as its C operand (beta = 1, C != D), so the add costs no pass of its own.  bias: NULL / bf16 / fp32

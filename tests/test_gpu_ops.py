@@ -824,9 +824,11 @@ def test_silu_linear_fused_backward(dev, rows, mlp, out):
                 opt._land(b)
         res.append((y.detach(), hh.grad, m.linear2.kernel.gview.clone(), m.linear2.bias.gview.clone()))
     (y1, dh1, dw1, db1), (y0, dh0, dw0, db0) = res
-    assert torch.equal(y1, y0)
+    # the node's activation is the library's own SiLU stream kernel (v_rcp_f32 sigmoid): a rare 1-ulp difference from the framework's
+    assert_close(y1, y0, rtol=1e-2, atol=1e-2, what="y fused vs chain")
+    assert float((y1 != y0).float().mean()) < 0.02
     assert_close_scaled(dh1, dh0, rel=1e-2, what="dh fused vs chain")        # chain rounds dy @ W2^T to bf16 before the multiply
-    assert_close_scaled(dw1, dw0, rel=2e-5, what="dW2")
+    assert_close_scaled(dw1, dw0, rel=1e-3, what="dW2")
     assert_close_scaled(db1, db0, rel=2e-5, what="db2")
     # against fp32 math on the same bf16 operands
     hf = h.float().requires_grad_(True)
@@ -1187,3 +1189,18 @@ def test_linear_residual_library_product(dev, m, k, n):
     wide_r = torch.zeros((m, n + 8), dtype=torch.bfloat16, device=dev); wide_r[:, :n] = rg
     assert torch.equal(ops.linear_residual(wide_x[:, :k], wg, bg, wide_r[:, :n]), y)
     assert torch.equal(ops.linear_residual(xg, wg, bg, rg), y), "bitwise reproducible"
+
+
+def test_silu_stream_kernel(dev):
+    """vvae_silu_bf16 (the MLP's activation, reference train/layers.py:186-189) against fp32 silu rounded to bf16: within one bf16 ulp
+    everywhere (v_rcp_f32 sigmoid), bitwise on all but a sliver; odd sizes fall back to the framework op."""
+    from video_vae_amd import ops
+    x = (torch.randn(4099 * 8, generator=torch.Generator().manual_seed(90)) * 3).to(dev, torch.bfloat16)
+    y = ops.silu_bf16(x)
+    ref = torch.nn.functional.silu(x.float()).to(torch.bfloat16)
+    assert_close(y, ref, rtol=2 ** -7, atol=1e-6, what="silu")
+    assert float((y != ref).float().mean()) < 0.02
+    big = torch.randn(16384, 1536, device=dev, dtype=torch.bfloat16)
+    assert_close(ops.silu_bf16(big), torch.nn.functional.silu(big.float()).to(torch.bfloat16), rtol=2 ** -7, atol=1e-6, what="silu, production shape")
+    odd = torch.randn(13, device=dev, dtype=torch.bfloat16)
+    assert torch.equal(ops.silu_bf16(odd), torch.nn.functional.silu(odd))

@@ -554,3 +554,49 @@ extern "C" int vvae_selftest_xor_lane(const float* x, float* y, double* yd, int 
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------- SiLU stream
+// a = silu(h) between the two Linear layers of the MLP (reference train/layers.py:186-189), 42 x 50 MB per step: one 16-byte vector
+// per lane and iteration, 4 in flight per thread (the framework's elementwise kernel runs this at 4.0 TB/s).
+namespace {
+__global__ __launch_bounds__(256) void silu_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, long nvec)
+{
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = x[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&v[u]), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * sigmoidf_(f[e]);
+            VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(&v[u]), f);
+            y[i + u * stride] = v[u];
+        }
+    }
+    for (; i < nvec; i += stride) {
+        uint4 v = x[i];
+        float f[8];
+        VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(&v), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * sigmoidf_(f[e]);
+        VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(&v), f);
+        y[i] = v;
+    }
+}
+}  // namespace
+
+// y = silu(x), bf16, n elements (a multiple of 8), both 16-byte aligned and contiguous.
+extern "C" int vvae_silu_bf16(const void* x, void* y, long n, void* stream)
+{
+    if (!x || !y || n <= 0 || n % 8 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
+    const long nvec = n / 8;
+    long blocks = (nvec + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(silu_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, nvec);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

@@ -126,7 +126,7 @@ class _SiluLinearBf16(torch.autograd.Function):
     def forward(ctx, h, kernel, bias, res=None):
         wb, bb = kernel.bf16, bias.bf16
         h2 = h.reshape(-1, h.shape[-1])
-        a = F.silu(h2)
+        a = ops.silu_bf16(h2)
         ctx.save_for_backward(h2, a, wb)
         ctx.hshape = h.shape
         ctx.kparam, ctx.bparam = kernel, bias

@@ -7,6 +7,7 @@ Tensors must live on a GPU -- there is no CPU path.
 import ctypes
 
 import torch
+import torch.nn.functional as F
 
 from ._lib import lib, check, VvaeError
 
@@ -1260,6 +1261,16 @@ def layer_norm_fork(x, scale, bias=None, eps=1e-6):
     """-> (LayerNorm(x), x): the second output is x itself, routed through the node so that in ``x_skip + f(y)`` the skip
     gradient is added inside the LayerNorm-backward kernel (pre-norm residual blocks, reference train/layers.py:212-221)."""
     return _LayerNorm.apply(x, scale, bias, eps, True)
+
+
+def silu_bf16(x):
+    """silu(x) for a contiguous bf16 GPU tensor (no autograd: layers._SiluLinearBf16 owns the backward)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0 and x.data_ptr() % 16 == 0):
+        return F.silu(x)
+    y = torch.empty_like(x)
+    check(_launch(f"silu {x.numel() >> 20}M", 4 * x.numel(), 0, "silu_bf16_kernel", lambda: lib().vvae_silu_bf16(_p(x), _p(y), x.numel(), _stream())),
+          "vvae_silu_bf16")
+    return y
 
 
 # --------------------------------------------------------------------------------------------- Linear + bias + residual (library GEMM)
