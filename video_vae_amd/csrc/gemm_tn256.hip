@@ -6,16 +6,16 @@
 // 768 x 1536 x 16 384 product) and measures at the ~11-13 TB/s this chip sustains on that path, not at its matrix rate.
 // A 256 x 256 tile halves the bytes per MAC; the loop then needs ~32 B/clk per CU and is paced by the matrix pipe.
 //
-//   * 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the tile = 4 x 2 v_mfma_f32_32x32x16_bf16 accumulators (128 VGPRs).
+//   * 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the tile = 8 x 4 v_mfma_f32_16x16x32_bf16 accumulators (128 VGPRs).
 //   * operands are K-major in memory (rows = tokens), so fragments (8 consecutive k per lane) come out of LDS through
 //     ds_read_b64_tr_b16; the LDS image is [32 tokens][256 channels] bf16 = 512-byte rows filled by LDS-DMA
 //     (global_load_lds_dwordx4, one piece = 2 whole token rows: full 128-byte lines on the L2 side, no VGPR round trip).
-//     Window swizzle: the 32-byte window W of token row r lives at W ^ (2 (r & 3)) -- applied on the per-lane SOURCE address
-//     of the DMA and on the read address -- so the 4 rows x 2 windows a half-wave transposes cover all 64 banks.
+//     Chunk swizzle: the 16-byte chunk c of token row r lives in slot c ^ ((r & 7) << 1) -- applied on the per-lane SOURCE address
+//     of the DMA and on the read address -- so the 8 rows x 32 bytes a half-wave transposes cover all 64 banks.
 //   * ring of 4 stages (32 tokens each, 128 KB), tiles issued three steps ahead, counted s_waitcnt vmcnt(8), raw s_barrier;
-//     waves 4-7 run one segment behind waves 0-3, so on every SIMD one wave multiplies (16 MFMAs) while its partner reads the
-//     next step's fragments, issues its DMA pieces and waits (the structure of gemm_nt.hip).
-//   * split-K over workgroups (tiles x splits ~ one workgroup per CU); partial tiles go to fp32 slabs with 128-byte row
+//     waves 4-7 run one segment behind waves 0-3, so on every SIMD one wave multiplies (32 MFMAs) while its partner reads the
+//     next step's fragments, issues its DMA pieces and waits (the structure of gemm_nt.hip).  32 MFMAs per wave and stage.
+//   * split-K over workgroups (tiles x splits ~ one workgroup per CU); partial tiles go to fp32 slabs with 64-byte row
 //     segments per store, summed in fixed order by gemm_tn_reduce_kernel: deterministic, no float atomics.
 //   * the bias gradient (column sums of B) rides along as an all-ones row operand in the m-tile-0 workgroups.
 #include "common.hpp"
@@ -46,34 +46,28 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// 8 k-values (two transposed 4 x 16 reads, token rows +0..3 and +4..7) of a 32-channel block for a 32x32x16 MFMA operand
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p)
-{
-    typedef __attribute__((address_space(3))) s16x4v* lds_ptr;
-    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
-    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * ROW));
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-// One 256 x 256 output tile over tokens [k_beg, k_beg + nk * 32): out[m][n] (row pitch ld_out, already offset to the tile's
-// matrix) += nothing -- it is WRITTEN: a split-K slab or, with the whole K range, the final gradient.  out_db (or NULL): column sums of
-// B for this tile's columns (only meaningful for m-tile 0).
+// One 256 x 256 output tile over tokens [k_beg, k_beg + nk * 32): out[m][n] (row pitch ld_out, already offset to the tile's matrix)
+// is WRITTEN: a split-K slab or, with the whole K range, the final gradient.  out_db (or NULL): column sums of B for this tile's
+// columns (only meaningful for m-tile 0).
+// v_mfma_f32_16x16x32_bf16: one 32-token stage = one k-step of 8 x 4 products per wave.  (Round 1 multiplied with 32x32x16: the same
+// LDS bytes and the same cycles per FLOP, but on random data the chip holds a higher clock under the 16x16x32 loop --
+// MI355X_MICROARCH.md, DVFS give-back item 7: 967 -> 875 us per grouped launch.)  Fragment of a 16-channel block: lane (g = l >> 4, q = (l >> 2) & 3, p = l & 3)
+// reads token rows 4g + q and 4g + q + 16, channels 4p .. 4p + 3 (two ds_read_b64_tr_b16); 16-byte chunk c of token row r lives in
+// slot c ^ ((r & 7) << 1) -- on the DMA's per-lane SOURCE address and on the read address -- so the 8 rows x 32 bytes a half-wave
+// reads cover all 64 banks.
 __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int lda, int ldb, int m0, int n0, int k_beg,
-                                           int nk, float* __restrict__ out, int ld_out, float* __restrict__ out_db)
+                                             int nk, float* __restrict__ out, int ld_out, float* __restrict__ out_db)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
 
-    // ---- DMA: piece = 2 token rows x 512 B.  lane -> row 2*piece + (lane >> 5), slot lane & 31; the slot holds source chunk
-    //      slot ^ ((row & 3) << 2).  Wave w issues pieces 2w, 2w+1 of A and of B.
     const bf16_t* ga[2];
     const bf16_t* gb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = 2 * (2 * wave + i) + (lane >> 5);
-        const int chunk = (lane & 31) ^ ((row & 3) << 2);
+        const int chunk = (lane & 31) ^ ((row & 7) << 1);
         ga[i] = A + (long)(k_beg + row) * lda + m0 + chunk * 8;
         gb[i] = B + (long)(k_beg + row) * ldb + n0 + chunk * 8;
     }
@@ -89,34 +83,34 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
         if (tiles_in_flight >= 2) wait_vm<2 * P>(); else if (tiles_in_flight == 1) wait_vm<P>(); else wait_vm<0>();
     };
 
-    // ---- transposed fragment reads.  lane: p = lane & 3 (4-channel group), q = (lane >> 2) & 3 (token row in the 4-row
-    //      group), mh = (lane >> 4) & 1 (16-channel half of the 32-block), kh = lane >> 5 (8-token half of the k16 step).
-    //      Token row = 16 ks + 8 kh + 4 u + q (u = the two reads of tr_frag); 32-channel block b lives at window (b ^ q).
-    const int p4 = lane & 3, qr = (lane >> 2) & 3, mh = (lane >> 4) & 1, kh = lane >> 5;
-    const int lrow = (8 * kh + qr) * ROW + mh * 32 + p4 * 8;
-    int aoff[4], boff[2];
+    const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const int r1 = 4 * g4 + q4, sw = (r1 & 7) << 1;
+    int aoff[8], boff[4];
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) aoff[ib] = lrow + ((4 * wm + ib) ^ qr) * 64;
+    for (int ib = 0; ib < 8; ++ib) aoff[ib] = r1 * ROW + ((((8 * wm + ib) * 2 + (p4 >> 1)) ^ sw) << 4) + (p4 & 1) * 8;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) boff[jb] = OPB + lrow + ((2 * wn + jb) ^ qr) * 64;
+    for (int jb = 0; jb < 4; ++jb) boff[jb] = OPB + r1 * ROW + ((((4 * wn + jb) * 2 + (p4 >> 1)) ^ sw) << 4) + (p4 & 1) * 8;
 
-    f32x16 acc[4][2];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    f32x16 accb[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accb[j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = out_db != nullptr && wm == 0;                       // wave-uniform
     const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
-    // ---- main loop (see gemm_nt.hip):   waves 0-3:  L0 | C0 | L1 | C1 | ...      waves 4-7:  -- | L0 | C0 | L1 | ...
+    auto frag = [&](const unsigned char* p) {
+        typedef __attribute__((address_space(3))) s16x4v* lds_ptr;
+        const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+        const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 16 * ROW));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
     const int npro = nk < S ? nk : S;
     for (int t = 0; t < npro; ++t) issue(t, t);
     wait_tiles(npro - 1);
@@ -125,50 +119,42 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
     int st = 0;
     for (int t = 0; t < nk; ++t) {
         const unsigned char* cur = smem + st * STAGE;
-        bf16x8 af[2][4], bfr[2][2];
+        bf16x8 af[8], bfr[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ib = 0; ib < 8; ++ib) af[ib] = frag(cur + aoff[ib]);
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) af[ks][ib] = tr_frag(cur + aoff[ib] + ks * 16 * ROW);
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) bfr[ks][jb] = tr_frag(cur + boff[jb] + ks * 16 * ROW);
-        }
-        if (t >= 1 && t - 1 + S < nk) issue(t - 1 + S, st == 0 ? S - 1 : st - 1);   // the stage tile t-1 used is free
+        for (int jb = 0; jb < 4; ++jb) bfr[jb] = frag(cur + boff[jb]);
+        if (t >= 1 && t - 1 + S < nk) issue(t - 1 + S, st == 0 ? S - 1 : st - 1);
         const int issued = t + S < nk ? t + S : nk;
-        wait_tiles(issued - t - 2);                              // tile t+1 has landed; the rest may stay in flight
+        wait_tiles(issued - t - 2);
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ib], bfr[jb], acc[ib][jb], 0, 0, 0);
+        if (do_bias) {
 #pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-                    acc[ib][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][ib], bfr[ks][jb], acc[ib][jb], 0, 0, 0);
-            if (do_bias) {
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) accb[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[ks][jb], accb[jb], 0, 0, 0);
-            }
+            for (int jb = 0; jb < 4; ++jb) accb[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[jb], accb[jb], 0, 0, 0);
         }
         __builtin_amdgcn_s_barrier();
         st = st + 1 == S ? 0 : st + 1;
     }
     if (!grp) __builtin_amdgcn_s_barrier();
 
-    // ---- tile -> memory.  acc[ib][jb][r]: m = 128 wm + 32 ib + 8 (r/4) + 4 kh + r%4, n = 64 wn + 32 jb + (lane & 31):
-    //      one store instruction writes two 128-byte row segments
-    const int nl = lane & 31;
+    // ---- tile -> memory.  acc[ib][jb][j]: m = 128 wm + 16 ib + 4 g + j, n = 64 wn + 16 jb + (lane & 15)
+    const int nl = lane & 15;
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
+    for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
+        for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 128 * wm + 32 * ib + 8 * (r >> 2) + 4 * kh + (r & 3);
-                out[(long)m * ld_out + n0 + 64 * wn + 32 * jb + nl] = acc[ib][jb][r];
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + 128 * wm + 16 * ib + 4 * g4 + j;
+                out[(long)m * ld_out + n0 + 64 * wn + 16 * jb + nl] = acc[ib][jb][j];
             }
-    if (do_bias && kh == 0) {
+    if (do_bias && g4 == 0) {
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) out_db[n0 + 64 * wn + 32 * jb + nl] = accb[jb][0];
+        for (int jb = 0; jb < 4; ++jb) out_db[n0 + 64 * wn + 16 * jb + nl] = accb[jb][0];
     }
 }
 
@@ -289,3 +275,4 @@ extern "C" int vvae_gemm_tn_grouped_bf16(const void* const* A, const int* lda, c
     }
     return tn256::launch_grouped(g, tiles, (hipStream_t)stream);
 }
+
