@@ -8,7 +8,7 @@
 // row blocks, i.e. 258 or 516 workgroups for 256 CUs -- a third round for 2 % of the work.  The tiles here divide the problem
 // exactly: 256 x 192 (N = 768: 256 workgroups, N = 1536: 512) and 256 x 128 (N = 512: 256), one workgroup per CU and round.
 //
-//   * 8 waves as 4 (M) x 2 (N); a wave owns 64 x 96 (or 64 x 64) of C = 2 x 3 (2 x 2) v_mfma_f32_32x32x16_bf16 tiles.  The
+//   * 8 waves as 4 (M) x 2 (N); a wave owns 64 x 96 (or 64 x 64) of C = 4 x 6 (4 x 4) v_mfma_f32_16x16x32_bf16 tiles.  The
 //     WEIGHT rows are the MFMA's row operand, so a lane's 4 consecutive accumulator registers are 4 consecutive output
 //     channels of one token (packed 8-byte writes in the epilogue).
 //   * K advances in 64-element tiles staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into two
@@ -19,7 +19,7 @@
 //     ds_read_b128 fragment reads conflict-free (16-byte chunk c of row r lives in slot c ^ ((r >> 1) & 7)) is applied to the
 //     per-lane SOURCE address and to the read address (the same involution on both sides).
 //   * waves 4-7 run ONE SEGMENT behind waves 0-3 (two waves share a SIMD: w and w + 4): on every SIMD one wave multiplies
-//     (24 MFMAs on fragments it already holds) while its partner reads the next tile's fragments.  Both halves issue their
+//     (48 MFMAs on fragments it already holds) while its partner reads the next tile's fragments.  Both halves issue their
 //     DMA pieces of tile t+1 in the same segment -- the first in which the stage tile t-1 used is free -- and wait for them one
 //     segment before the first read, so a tile has a whole step (two segments) to land:
 //          waves 0-3:  L0 | C0 | L1 | C1 | ...     L_t: read fragments of tile t, issue own pieces of tile t+1
@@ -108,21 +108,21 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         for (int i = 0; i < C::PB; ++i) glds16(gb[i] + k0, sb + C::A_BYTES + (wave * C::PB + i) * 1024);
     };
 
-    // ---- fragment reads: 32 rows x 16 k per ds_read_b128; lane (row = lane & 31, kh = lane >> 5)
-    const int fr = lane & 31, kh = lane >> 5, sw = (fr >> 1) & 7;
-    int koff[4];
+    // ---- fragment reads for v_mfma_f32_16x16x32_bf16: 16 rows x 32 k per ds_read_b128; lane (row = lane & 15, k-group kg = lane >> 4).
+    //      (Round 1 multiplied with 32x32x16: same LDS bytes and cycles per FLOP, lower sustained clock on random data.)
+    constexpr int MB16 = C::WTM / 16, NB16 = C::WTN / 16;
+    const int fr = lane & 15, kg = lane >> 4, sw = (fr >> 1) & 7;      // rows fr and fr + 16 j share (row >> 1) & 7
+    int koff[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = ((2 * ks + kh) ^ sw) << 4;
+    for (int ks = 0; ks < 2; ++ks) koff[ks] = ((4 * ks + kg) ^ sw) << 4;
     const int a_row = (wm * C::WTM + fr) * ROWB;                  // token rows of this wave (MFMA column operand)
     const int b_row = C::A_BYTES + (wn * C::WTN + fr) * ROWB;     // weight rows (MFMA row operand)
 
-    f32x16 acc[C::NB][C::MB];
+    f32x4 acc[NB16][MB16];
 #pragma unroll
-    for (int i = 0; i < C::NB; ++i)
+    for (int i = 0; i < NB16; ++i)
 #pragma unroll
-        for (int j = 0; j < C::MB; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int j = 0; j < MB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = d.K / BK;
     issue(0, 0);
@@ -135,13 +135,13 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     for (int t = 0; t < nk; ++t) {
         const unsigned char* cur = smem + (t & 1) * C::STAGE;
         // ---- L_t
-        bf16x8 tf[4][C::MB], wf[4][C::NB];
+        bf16x8 tf[2][MB16], wf[2][NB16];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int j = 0; j < C::MB; ++j) tf[ks][j] = *reinterpret_cast<const bf16x8*>(cur + a_row + j * 32 * ROWB + koff[ks]);
+            for (int j = 0; j < MB16; ++j) tf[ks][j] = *reinterpret_cast<const bf16x8*>(cur + a_row + j * 16 * ROWB + koff[ks]);
 #pragma unroll
-            for (int i = 0; i < C::NB; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + b_row + i * 32 * ROWB + koff[ks]);
+            for (int i = 0; i < NB16; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + b_row + i * 16 * ROWB + koff[ks]);
         }
         if (!grp) { if (t + 1 < nk) issue(t + 1, (t + 1) & 1); }
         else wait_vm0();                      // waves 4-7: their pieces of tile t+1 (issued a step ago) have landed
@@ -149,11 +149,11 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         // ---- C_t
         if (grp && t + 2 < nk) issue(t + 2, t & 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < C::NB; ++i)
+            for (int i = 0; i < NB16; ++i)
 #pragma unroll
-                for (int j = 0; j < C::MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MB16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
         if (!grp) wait_vm0();                 // waves 0-3: their pieces of tile t+1 have landed
         __builtin_amdgcn_s_barrier();
     }
@@ -173,23 +173,19 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
             rpre[it] = *reinterpret_cast<const uint4*>(res + (long)(m0 + q / CPR) * d.ldr + n0 + (q % CPR) * 8);
         }
     }
-    // ---- epilogue pass 1: acc (+bias) -> bf16 image [BM][BN], pitch CP.  acc[i][j][r]: channel 32 i + 8 (r/4) + 4 kh + r%4,
-    //      token 32 j + fr
+    // ---- epilogue pass 1: acc (+bias) -> bf16 image [BM][BN], pitch CP.  acc[i][j][r]: channel 16 i + 4 kg + r, token 16 j + fr
 #pragma unroll
-    for (int i = 0; i < C::NB; ++i) {
+    for (int i = 0; i < NB16; ++i) {
+        const int n = wn * C::WTN + i * 16 + kg * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) { const float* bp = bias + n0 + n; bv = make_float4(bp[0], bp[1], bp[2], bp[3]); }
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int n = wn * C::WTN + i * 32 + rg * 8 + kh * 4;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias) { const float* bp = bias + n0 + n; bv = make_float4(bp[0], bp[1], bp[2], bp[3]); }
-#pragma unroll
-            for (int j = 0; j < C::MB; ++j) {
-                const int m = wm * C::WTM + j * 32 + fr;
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(acc[i][j][rg * 4 + 0] + bv.x) | ((uint32_t)f2bf(acc[i][j][rg * 4 + 1] + bv.y) << 16);
-                pk.y = (uint32_t)f2bf(acc[i][j][rg * 4 + 2] + bv.z) | ((uint32_t)f2bf(acc[i][j][rg * 4 + 3] + bv.w) << 16);
-                *reinterpret_cast<uint2*>(smem + m * C::CP + n * 2) = pk;
-            }
+        for (int j = 0; j < MB16; ++j) {
+            const int m = wm * C::WTM + j * 16 + fr;
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(acc[i][j][0] + bv.x) | ((uint32_t)f2bf(acc[i][j][1] + bv.y) << 16);
+            pk.y = (uint32_t)f2bf(acc[i][j][2] + bv.z) | ((uint32_t)f2bf(acc[i][j][3] + bv.w) << 16);
+            *reinterpret_cast<uint2*>(smem + m * C::CP + n * 2) = pk;
         }
     }
     __syncthreads();
