@@ -46,7 +46,6 @@ struct NtCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
     static constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile
-    static constexpr int MB = WTM / 32, NB = WTN / 32;          // 32x32 MFMA tiles per wave
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     static constexpr int PA = BM / 8 / NWAVES, PB = BN / 8 / NWAVES;   // 1 KiB DMA pieces (8 rows) per wave and tile
     static constexpr int CP = BN * 2 + 16;                      // epilogue image row pitch (bytes)
