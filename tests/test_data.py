@@ -97,3 +97,30 @@ def test_uint8_hand_over_matches_the_float_contract(clips):
         assert y["video"].dtype == torch.uint8
         assert np.array_equal(x["video"], y["video"].numpy().astype(np.float32) / 255.0)
         assert np.array_equal(x["mask"], y["mask"].numpy())
+
+
+def test_unbatched_loader_and_batch_to_video_round_trip(tmp_path):
+    """create_dataloader (train/dataloader.py:293-331) yields single clips; batch_to_video (:10-93) drops padded frames, scales to uint8
+    and -- as a .npy frame container -- is read back by the loader bit for bit."""
+    from video_vae_amd import data as D
+    D.write_synthetic_clips(str(tmp_path), 3, 6, 24, 24, seed=1)               # clip 0 has 5 frames, clips 1 and 2 have 6
+    items = list(D.create_dataloader(str(tmp_path), max_frames=8, crop_size=16, shuffle=False, num_workers=0))
+    assert len(items) == 3
+    for it in items:
+        assert it["video"].shape == (8, 16, 16, 3) and it["video"].dtype == np.float32 and it["mask"].shape == (8,)
+        assert it["mask"].sum() in (5, 6) and float(it["video"].max()) <= 1.0
+    out = str(tmp_path / "clip.npy")
+    D.batch_to_video({"video": np.stack([it["video"] for it in items]), "mask": np.stack([it["mask"] for it in items])}, out, sample_idx=1)
+    back = np.load(out)
+    assert back.dtype == np.uint8 and back.shape == (6, 16, 16, 3)                       # padded frames dropped
+    assert np.array_equal(back, (np.clip(items[1]["video"][:6], 0, 1) * 255).astype(np.uint8))
+    v, m = D.load_video(out, max_frames=6, crop_size=16, rng=np.random.default_rng(0))
+    assert np.array_equal((v * 255).round().astype(np.uint8), back) and m.sum() == 6
+    with pytest.raises(ValueError):
+        D.batch_to_video({"video": items[0]["video"], "mask": np.zeros(8)}, out)
+    import shutil
+    if not shutil.which("ffmpeg"):
+        with pytest.raises(RuntimeError):
+            D.batch_to_video({"video": items[0]["video"], "mask": items[0]["mask"]}, str(tmp_path / "clip.mp4"))
+    f = np.arange(24 * 32 * 3, dtype=np.uint8).reshape(24, 32, 3)
+    assert D.apply_crop(f, 16, (24, 32, 2, 5)).shape == (16, 16, 3) and np.array_equal(D.apply_crop(f, 16, (24, 32, 2, 5)), f[2:18, 5:21])

@@ -218,6 +218,83 @@ def create_batched_dataloader(base_dir, batch_size=1, max_frames=None, resize=No
                              drop_remainder, num_epochs, as_uint8)
 
 
+def apply_crop(frame, crop_size, crop_params):
+    """One frame (H, W, 3) uint8 through the pre-computed crop of get_random_crop_params (train/dataloader.py:133-145)."""
+    th, tw, sh, sw = crop_params
+    if frame.shape[:2] != (th, tw):
+        frame = _resize_u8(frame[None], th, tw)[0]
+    return frame[sh:sh + crop_size, sw:sw + crop_size]
+
+
+class _ClipIterator:
+    """Unbatched clips, the reference's create_dataloader (train/dataloader.py:293-331): dicts with 'video' (T, H, W, 3) float32 in
+    [0, 1] and 'mask' (T,)."""
+
+    def __init__(self, source, max_frames, resize, crop_size, shuffle, seed, num_workers, prefetch_size):
+        ds = _ClipDataset(source, max_frames, resize, crop_size, seed)
+        kw = dict(prefetch_factor=max(1, prefetch_size), persistent_workers=False) if num_workers > 0 else {}
+        self.loader = torch.utils.data.DataLoader(ds, batch_size=None, sampler=_EpochSampler(len(source), shuffle, seed, 1),
+                                                  num_workers=num_workers, collate_fn=lambda it: it, **kw)
+
+    def __iter__(self):
+        for v, m in self.loader:
+            yield {"video": np.asarray(v).astype(np.float32) / 255.0, "mask": np.asarray(m)}
+
+
+def create_dataloader(base_dir, batch_size=1, max_frames=None, resize=None, crop_size=512, shuffle=True, seed=42, num_workers=4,
+                      prefetch_size=2):
+    """train/dataloader.py:293-331: one clip per item (``batch_size`` is accepted and ignored there too: batching is
+    create_batched_dataloader's)."""
+    source = VideoDataSource(base_dir)
+    if len(source) == 0:
+        raise ValueError(f"no clips under {base_dir}")
+    if max_frames is None:
+        raise ValueError("create_dataloader needs max_frames (frame containers are read by range)")
+    return _ClipIterator(source, max_frames, resize, crop_size, shuffle, seed, num_workers, prefetch_size)
+
+
+def batch_to_video(batch, output_path, fps=30.0, use_mask=True, sample_idx=0, crf=18, preset="medium"):
+    """Write one sample of a batch as a video (train/dataloader.py:10-93): clip to [0, 1], scale to uint8, drop padded frames when
+    ``use_mask``, H.264 through an ffmpeg pipe.  ``output_path`` ending in .npy / .npz writes the uint8 (T, H, W, 3) frame container
+    the loader reads natively instead (no ffmpeg needed)."""
+    import shutil
+    import subprocess
+    video, mask = batch["video"], batch["mask"]
+    if isinstance(video, torch.Tensor):
+        video = video.detach().float().cpu().numpy()
+    if isinstance(mask, torch.Tensor):
+        mask = mask.detach().float().cpu().numpy()
+    video = np.clip(np.asarray(video, dtype=np.float32), 0, 1)
+    mask = np.asarray(mask)
+    if video.ndim == 5:
+        video, mask = video[sample_idx], mask[sample_idx]
+    video = (video * 255).astype(np.uint8)
+    if use_mask:
+        video = video[mask > 0.5]
+    if len(video) == 0:
+        raise ValueError("No frames to write (all frames are padded)")
+    t, h, w, _ = video.shape
+    if output_path.endswith(".npy"):
+        np.save(output_path, video)
+    elif output_path.endswith(".npz"):
+        np.savez(output_path, frames=video)
+    else:
+        if not shutil.which("ffmpeg"):
+            raise RuntimeError("ffmpeg not found on PATH.")
+        cmd = ["ffmpeg", "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{w}x{h}", "-r", str(fps), "-i", "pipe:0", "-vcodec", "libx264",
+               "-pix_fmt", "yuv420p", "-crf", str(crf), "-preset", preset, output_path]
+        proc = subprocess.Popen(cmd, stdin=subprocess.PIPE)
+        try:
+            for frame in video:
+                proc.stdin.write(frame.tobytes())
+        finally:
+            proc.stdin.close()
+            proc.wait()
+            if proc.returncode != 0:
+                raise RuntimeError("ffmpeg failed.")
+    print(f"Saved video to {output_path} ({len(video)} frames, {w}x{h}, {fps} fps)", file=sys.stderr)
+
+
 class DevicePrefetcher:
     """Host batches -> device batches, one step ahead, on a side stream.
 
