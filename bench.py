@@ -347,8 +347,8 @@ def main():
                 def step():
                     loss, _aux = gstep(*batch()) if feed is not None else gstep()
                     return loss
-                mode = ("2 hipgraphs (fwd + decoder bwd | encoder bwd), decoder all-reduce under the second" if gstep.graph2 is not None
-                        else "hipgraph(fwd+bwd)") + " + eager all-reduce/clip/Adam"
+                mode = (f"{1 + len(gstep.graphs)} hipgraphs (fwd + decoder bwd | encoder bwd in {len(gstep.graphs)} segments), each stage's "
+                        "all-reduce under the next" if gstep.graphs else "hipgraph(fwd+bwd)") + " + eager all-reduce/clip/Adam"
             except Exception as e:                       # capture is an optimisation, never a requirement
                 print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 step, mode = eager_step, "eager"

@@ -201,16 +201,18 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert torch.allclose(opt.p, opt2.p, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_graphed_train_step_matches_eager(dev, split):
+@pytest.mark.parametrize("split,depth,graphs", [(False, 1, 1), (True, 1, 2), (True, 4, 4), (True, 2, 3)])
+def test_graphed_train_step_matches_eager(dev, split, depth, graphs):
     """hipGraph replay of forward+backward must produce the eager step's loss and gradients (same weights, same noise);
-    split = the two-graph form used under data parallelism (cut at the encoder's outputs)."""
+    split = the staged form used under data parallelism: forward + decoder backward, then the encoder's backward in up to three
+    segments (cut at the outputs of encoder blocks; fewer when the encoder is shallower)."""
     import video_vae_amd as V
     from video_vae_amd import optim, loss as L
     from video_vae_amd.graph import GraphedTrainStep
     torch.manual_seed(0)
-    ma = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **TINY).to(dev)
-    mb = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **TINY).to(dev)
+    cfg = dict(TINY, encoder_depth=depth)
+    ma = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **cfg).to(dev)
+    mb = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **cfg).to(dev)
     with torch.no_grad():
         for m in (ma, mb):
             m.decoder.unet.final_conv.kernel.copy_(rnd(m.decoder.unet.final_conv.kernel.shape, 5, 0.2).to(dev))
@@ -220,7 +222,10 @@ def test_graphed_train_step_matches_eager(dev, split):
     mask = torch.ones(2, 8, device=dev); mask[1, 5:] = 0
     ra, rb = V.Rngs(3), V.Rngs(3)
     gstep = GraphedTrainStep(ma, oa, video, mask, L.HPARAMS, 16, ra, warmup=1, split=split)     # runs 1 + 1 + 1 updates on model a
-    assert (gstep.graph2 is not None) == split
+    assert 1 + len(gstep.graphs) == graphs
+    if split:                                          # every parameter belongs to exactly one stage; stages own runs of buckets
+        assert sorted(i for st in gstep.stage_idx for i in st) == list(range(len(oa.params)))
+        assert max(gstep.bucket_stage) == graphs - 1
     with torch.no_grad():                                                         # re-align the two replicas
         oa.p.copy_(ob.p); oa.m.copy_(ob.m); oa.v.copy_(ob.v); oa.refresh_shadow()
     oa.count = ob.count
@@ -332,7 +337,7 @@ def _ddp_gpu_worker(rank, world, port, out):
         res["buckets"] = list(opt.buckets)
         # ---- (b) the VAE train step: eager (hooks) then hipGraph replay (all-reduce after the replay)
         torch.manual_seed(0)
-        vae = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **TINY).to(dev)
+        vae = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **dict(TINY, encoder_depth=3)).to(dev)      # 3 encoder blocks: 4 graphs
         vopt = optim.Optimizer(vae, 1e-3, bucket_bytes=64 << 10)
         vred = ddp.GradReducer(vopt)
         vred.broadcast_parameters(0)
@@ -341,6 +346,8 @@ def _ddp_gpu_worker(rank, world, port, out):
         rngs = V.Rngs(3 + rank)
         # graph first, eager after: the order bench.py uses (capture wants no earlier pass on another stream)
         gstep = GraphedTrainStep(vae, vopt, video, mask, L.HPARAMS, 16, rngs, warmup=1)
+        res["ngraphs"] = 1 + len(gstep.graphs)
+        res["stage_buckets"] = [sum(1 for b in gstep.bucket_stage if b == st) for st in range(gstep.nstages)]
         for i in range(2):
             loss, _ = gstep()
             res[f"graph_loss{i}"] = float(loss)
@@ -397,6 +404,8 @@ def test_data_parallel_world2_sharing_one_gpu(dev, tmp_path):
             raise AssertionError(f"replicas diverged ({k}): {len(bad)} of {len(r0['vlayout'])} parameters, {bad[:10]}")
         assert torch.isfinite(r0[k]).all()
     assert not torch.equal(r0["p_eager"], r0["p_graph"])
+    # the captured step was staged: forward + decoder backward, then three encoder segments, each stage owning buckets of its own
+    assert r0["ngraphs"] == 4 and len(r0["stage_buckets"]) == 4 and all(n > 0 for n in r0["stage_buckets"]), r0["stage_buckets"]
     # resume: count and moments travelled with the parameters (reference claude_distributed/distributed_train.py:321-341)
     assert r0["resume_count"] == 3 and r1["resume_count"] == 3 and r0["resume_count1"] == 4 and r1["resume_count1"] == 4
     for k in ("resume_p", "resume_m", "resume_v"):

@@ -12,10 +12,11 @@ What the capture needs and how it gets it:
   * stochastic ops: ``Rngs.draw`` is pointed at fixed noise buffers (its injection hook) that are refilled before each replay
     from a device generator seeded from ``rngs.seed`` (per-rank under data parallelism: the driver builds ``Rngs(3 + rank)``),
     so every step still sees fresh noise of the right distribution and ranks draw different noise, as in eager mode;
-  * no collective inside a graph: with a ``GradReducer`` attached the step is captured as TWO graphs cut at the output of the
-    encoder's last block -- (forward + decoder backward) and (encoder backward).  The buckets that hold only decoder-side gradients are
-    handed to the reducer between the two replays, so their all-reduce (RCCL's own stream) runs under the encoder's backward;
-    the remaining buckets follow after the second replay.  Without a reducer one graph holds the whole pass.
+  * no collective inside a graph: with a ``GradReducer`` attached the step is captured as 1 + ``enc_segments`` graphs: (forward +
+    everything downstream of the encoder's last block) and the encoder's backward in runs of blocks.  The buckets a stage completed
+    are handed to the reducer before the next replay, so their all-reduce (RCCL's own stream) runs under the stages still to come;
+    only the last segment's buckets (a third of the encoder: ~95 of the 683 MB) wait for the end.  Without a reducer one graph
+    holds the whole pass.
   * streams: capture happens on a private stream (autograd's stream bookkeeping needs one that nothing else has used), but the
     graphs are REPLAYED on the caller's current stream, on purpose: the input copies, the noise refill, the eager clip+Adam and --
     the part that matters next to RCCL -- the collectives all order themselves against the current stream (ProcessGroupNCCL makes
@@ -35,23 +36,34 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None):
+    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None, enc_segments=3):
         self.model, self.opt, self.hparams, self.hw, self.rngs = model, optimizer, hparams, hw, rngs
         self.split = (optimizer.reducer is not None) if split is None else bool(split)
         enc = model.encoder
         if not (hasattr(enc, "layers") and hasattr(enc, "patch_embedding") and len(enc.layers) > 0):
             self.split = False
-        self.graph2 = None
+        self.graphs = []
         if self.split:
-            # the cut: the output of the encoder's last FactoredAttention block (ONE tensor; the mean / variance / selection
-            # heads behind it depend on each other and stay with stage 1).  Stage 2 owns the patch embedding and the blocks --
-            # the tail of the flat buffer, which is laid out in reverse registration order.
-            self.cut_module = enc.layers[-1]
-            late = {id(p) for mod in [enc.patch_embedding, *enc.layers] for p in mod.parameters()}
-            self.enc_idx = [i for i, p in enumerate(optimizer.params) if id(p) in late]
-            self.dec_idx = [i for i, p in enumerate(optimizer.params) if id(p) not in late]
-            dec = set(self.dec_idx)
-            self.early_buckets = [b for b, members in enumerate(optimizer.bucket_params) if all(i in dec for i in members)]
+            # The cuts: the output of the encoder's last FactoredAttention block (ONE tensor; the mean / variance / selection heads
+            # behind it depend on each other and stay with stage 0), then the outputs of earlier blocks so that the encoder's
+            # backward is ``enc_segments`` graphs of about equal depth.  Stage 0 = forward + everything downstream of the last block;
+            # stage j >= 1 owns a run of encoder blocks (the last one also the patch embedding) -- runs of the flat buffer, which is
+            # laid out in reverse registration order, so the buckets complete stage by stage.
+            n = len(enc.layers)
+            k = max(1, min(int(enc_segments), n))
+            bounds = [round(n * j / k) for j in range(k + 1)]            # segment j (from the top) = layers [bounds[k-j-1], bounds[k-j])
+            self.cut_modules = [enc.layers[bounds[k - j] - 1] for j in range(k)]      # cut j feeds stage j + 1; cut 0 = last block
+            stage_of = {}
+            for j in range(k):
+                for li in range(bounds[k - j - 1], bounds[k - j]):
+                    for prm in enc.layers[li].parameters():
+                        stage_of[id(prm)] = j + 1
+            for prm in enc.patch_embedding.parameters():
+                stage_of[id(prm)] = k
+            self.nstages = k + 1
+            self.stage_idx = [[i for i, prm in enumerate(optimizer.params) if stage_of.get(id(prm), 0) == st] for st in range(k + 1)]
+            pstage = [stage_of.get(id(prm), 0) for prm in optimizer.params]
+            self.bucket_stage = [max(pstage[i] for i in members) for members in optimizer.bucket_params]
         self.video = video.clone()
         self.mask = mask.clone()
         self.rl = L._is_rl(model)
@@ -65,55 +77,70 @@ class GraphedTrainStep:
             return L.loss_fn(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
         return L.loss_fn_plain(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
 
-    # ---- two-stage form (data parallel): cut at the encoder's outputs -----------------------------------------------
-    def _stage1(self):
-        """Forward + backward of everything downstream of the encoder's last block: those gradients land, the gradient of the
-        block's output is kept for stage 2."""
-        grabbed = []
-        hook = self.cut_module.register_forward_hook(lambda m, inp, out: grabbed.append(out))
+    # ---- staged form (data parallel): forward + decoder backward | encoder backward in segments -------------------------
+    @staticmethod
+    def _tensors(out):
+        """The tensors a block handed on: one tensor, or the (sum, None) / (skip, branch) pair of the pending protocol."""
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        return [o for o in outs if isinstance(o, torch.Tensor) and o.requires_grad]
+
+    def _stage0(self):
+        """Forward + backward of everything downstream of the encoder's last block: those gradients land, the gradients of the cut
+        tensors are kept for the next stage."""
+        grabbed = {}
+        hooks = [m.register_forward_hook(lambda mod, inp, out, j=j: grabbed.setdefault(j, []).append(out)) for j, m in enumerate(self.cut_modules)]
         try:
             loss, aux = self._loss()
         finally:
-            hook.remove()
-        if len(grabbed) != 1 or not isinstance(grabbed[0], torch.Tensor) or not grabbed[0].requires_grad:
-            raise RuntimeError("split capture expects the encoder's last block to run once and return one tensor")
-        self._cut = [grabbed[0]]
+            for h in hooks:
+                h.remove()
+        self._cuts = []
+        for j in range(len(self.cut_modules)):
+            if len(grabbed.get(j, [])) != 1 or not self._tensors(grabbed[j][0]):
+                raise RuntimeError("split capture expects every cut block of the encoder to run once and hand on differentiable tensors")
+            self._cuts.append(self._tensors(grabbed[j][0]))
         opt = self.opt
         opt.external = set()
         opt.hooks_active = False
-        dec_params = [opt.params[i] for i in self.dec_idx]
+        params = [opt.params[i] for i in self.stage_idx[0]]
         with ops.deferred_wgrad(opt):
-            grads = torch.autograd.grad(loss, dec_params + self._cut, allow_unused=True)
-        self._gcut = grads[len(dec_params):]
-        opt.land_subset(self.dec_idx, grads[:len(dec_params)])
+            grads = torch.autograd.grad(loss, params + self._cuts[0], allow_unused=True)
+        self._gcut = list(grads[len(params):])
+        opt.land_subset(self.stage_idx[0], grads[:len(params)])
         return loss.detach(), {k: v.detach() for k, v in aux.items() if k != "reconstruction"}
 
-    def _stage2(self):
-        """Backward of the encoder's blocks and patch embedding from the kept gradient; the rest of the flat buffer lands."""
+    def _stage(self, st):
+        """Backward of encoder segment ``st`` (>= 1) from the gradients kept at cut st - 1; its slice of the flat buffer lands."""
         opt = self.opt
-        pairs = [(c, g) for c, g in zip(self._cut, self._gcut) if g is not None]
-        enc_params = [opt.params[i] for i in self.enc_idx]
+        pairs = [(c, g) for c, g in zip(self._cuts[st - 1], self._gcut) if g is not None]
+        params = [opt.params[i] for i in self.stage_idx[st]]
+        nxt = self._cuts[st] if st < len(self._cuts) else []
         with ops.deferred_wgrad(opt):
-            grads = torch.autograd.grad([c for c, _ in pairs], enc_params, grad_outputs=[g for _, g in pairs], allow_unused=True)
-        opt.land_subset(self.enc_idx, grads)
-        opt.landed = [True] * len(opt.buckets)
-        self._cut = self._gcut = None
+            grads = torch.autograd.grad([c for c, _ in pairs], params + nxt, grad_outputs=[g for _, g in pairs], allow_unused=True)
+        self._gcut = list(grads[len(params):])
+        opt.land_subset(self.stage_idx[st], grads[:len(params)])
+        if st == self.nstages - 1:
+            opt.landed = [True] * len(opt.buckets)
+            self._cuts = self._gcut = None
 
-    def _prelaunch(self):
-        """Hand the decoder-only buckets to the reducer: their all-reduce overlaps stage 2."""
+    def _prelaunch(self, st):
+        """Hand the buckets that stage ``st`` completed to the reducer: their all-reduce overlaps the stages still to run."""
         opt = self.opt
         if opt.reducer is not None and opt.defer_reduce:
-            opt.reducer.reset()
-            for b in self.early_buckets:
-                opt.reducer.launch(b)
-                opt.prelaunched.add(b)
+            if st == 0:
+                opt.reducer.reset()
+            for b, bs in enumerate(self.bucket_stage):
+                if bs == st:
+                    opt.reducer.launch(b)
+                    opt.prelaunched.add(b)
 
     def _pass(self):
         if not self.split:
             return self._fwd_bwd()
-        out = self._stage1()
-        self._prelaunch()
-        self._stage2()
+        out = self._stage0()
+        for st in range(1, self.nstages):
+            self._prelaunch(st - 1)
+            self._stage(st)
         return out
 
     def _fwd_bwd(self):
@@ -174,11 +201,12 @@ class GraphedTrainStep:
         mode = "thread_local" if opt.reducer is not None else "global"
         if self.split:
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
-                self.loss, self.aux = self._stage1()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=self.stream, pool=g.pool(), capture_error_mode=mode):
-                self._stage2()
-            self.graph2 = g2
+                self.loss, self.aux = self._stage0()
+            for st in range(1, self.nstages):
+                gs = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs, stream=self.stream, pool=g.pool(), capture_error_mode=mode):
+                    self._stage(st)
+                self.graphs.append(gs)
         else:
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
                 self.loss, self.aux = self._fwd_bwd()
@@ -198,8 +226,8 @@ class GraphedTrainStep:
             self.mask.copy_(mask)
         self._refill()
         self.graph.replay()
-        if self.graph2 is not None:
-            self._prelaunch()
-            self.graph2.replay()
+        for st, gs in enumerate(self.graphs, start=1):
+            self._prelaunch(st - 1)                      # buckets the previous stage completed: reduced under this stage
+            gs.replay()
         self.opt.update()
         return self.loss, self.aux
