@@ -397,7 +397,8 @@ def main():
             "data": "synthetic" if not args.with_input_pipeline else
                     "synthetic clips on disk through the host input pipeline (worker processes -> pinned uint8 -> H2D on a side stream)",
             "rccl_ranks": world if (ddp_on and args.backend == "nccl") else 0,
-            "config": {"workload": ("C3: full VideoVAE (enc 9 / dec 12 FactoredAttention + 3D-conv UNet) train step, "
+            "config": {"workload": ((("C3" if (B, T, S) == (4, 16, 256) else "C5 per-GPU shape" if (B, T, S) == (2, 32, 256) else "custom shape")
+                                     + ": full VideoVAE (enc 9 / dec 12 FactoredAttention + 3D-conv UNet) train step, ")
                                     if args.workload == "vae" else "Conv3d UNet stack alone (diagnostic), ")
                                    + f"B={B}/GPU x 3x{T}x{S}x{S}, {args.dtype} compute, fp32 params, recon+KL loss, clip+Adam",
                        "flavour": args.flavour if args.workload == "vae" else "unet", "params": nparams,
