@@ -146,3 +146,24 @@ def test_rl_loss_with_perceptual_term_vs_oracle(dev):
     ref_grads = {k: v.grad for k, v in pr.items()}
     for k, prm in m.named_parameters():
         assert_close_scaled(prm.grad, ref_grads[k], rel=2e-3, what=k, floor=grad_floor(k, ref_grads))
+
+
+@pytest.mark.gpu
+def test_train_driver_with_perceptual_term(dev, tmp_path):
+    """python -m video_vae_amd.train --vgg random: the driver wires load_vgg / get_adversarial_perceptual_loss_fn into train_step as
+    rl_nonadversarial.py:272-274,332 does; the logged perceptual term is positive and the loss finite."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONUNBUFFERED="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "video_vae_amd.train", "--small", "--steps", "3", "--size", "32", "--max_frames", "8", "--vgg", "random"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("Epoch 0, Step")]
+    assert lines, out.stdout[-2000:]
+    m = re.search(r"Loss = ([-0-9.e+naif]+).*perceptual_loss = ([-0-9.e+naif]+)", lines[-1])
+    assert m, lines[-1]
+    assert float(m.group(1)) == float(m.group(1)) and float(m.group(2)) > 0

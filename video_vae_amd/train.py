@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--small", action="store_true", help="tiny model (depth 1) for smoke runs")
     ap.add_argument("--data", type=str, default=None, help="directory of clips (videos{i}/*.npy|npz|mp4...): the host input pipeline")
     ap.add_argument("--num_workers", type=int, default=4)
+    ap.add_argument("--vgg", type=str, default=None,
+                    help="perceptual loss (rl flavour; rl_nonadversarial.py:125,272-274): 'random' = randomly initialised VGG16 head, or the "
+                         "path of an .npz / .pt with its six tensors (the ImageNet weights are a remote download in the reference)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,6 +93,11 @@ def main():
     if rank == 0:
         print(f"Trainable Parameters: {sum(p.numel() for p in model.parameters()) / 1e6} Million", flush=True)
 
+    ploss = vgg_params = None
+    if args.vgg:
+        from video_vae_amd import perceptual
+        vgg, vgg_params = perceptual.load_vgg(None if args.vgg == "random" else args.vgg, device=dev)
+        ploss = perceptual.get_adversarial_perceptual_loss_fn(vgg)
     rngs = V.Rngs(3 + rank)
     start, global_step = time.perf_counter(), 0
     for epoch in range(args.epochs):
@@ -110,7 +118,7 @@ def main():
             if i > NEGATIVE_PENALTY_TRAINING_STEPS:
                 hparams["max_compression_rate"] = 10000
             video = batch["video"].to(torch.bfloat16)             # :330
-            loss, aux = L.train_step(model, opt, video, batch["mask"], hparams, hw, rngs)
+            loss, aux = L.train_step(model, opt, video, batch["mask"], hparams, hw, rngs, ploss, vgg_params)
             global_step += 1
             if i % 10 == 0 or i == args.steps - 1:
                 keys = [k for k in aux if k != "reconstruction"]
