@@ -14,7 +14,8 @@
  *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
  *   - process-global mutable state is limited to six test / tuning hooks, none of which the product path calls:
  *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config,
- *     vvae_layernorm_fwd_mode, vvae_gemm_tn_use_big_tiles (each documented at its declaration); everything else is a pure function of its arguments.
+ *     vvae_layernorm_fwd_mode, vvae_gemm_tn_use_big_tiles (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 keeps the
+ *     hipBLASLt handle and the solution the library's heuristic chose per (shape, pitches) behind a mutex; everything else is a pure function of its arguments.
  */
 #ifndef VVAE_HIP_H
 #define VVAE_HIP_H

@@ -226,6 +226,10 @@ def apply_crop(frame, crop_size, crop_params):
     return frame[sh:sh + crop_size, sw:sw + crop_size]
 
 
+def _identity(item):
+    return item
+
+
 class _ClipIterator:
     """Unbatched clips, the reference's create_dataloader (train/dataloader.py:293-331): dicts with 'video' (T, H, W, 3) float32 in
     [0, 1] and 'mask' (T,)."""
@@ -234,7 +238,7 @@ class _ClipIterator:
         ds = _ClipDataset(source, max_frames, resize, crop_size, seed)
         kw = dict(prefetch_factor=max(1, prefetch_size), persistent_workers=False) if num_workers > 0 else {}
         self.loader = torch.utils.data.DataLoader(ds, batch_size=None, sampler=_EpochSampler(len(source), shuffle, seed, 1),
-                                                  num_workers=num_workers, collate_fn=lambda it: it, **kw)
+                                                  num_workers=num_workers, collate_fn=_identity, **kw)
 
     def __iter__(self):
         for v, m in self.loader:
