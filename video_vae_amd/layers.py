@@ -300,8 +300,8 @@ class PatchUnEmbedding(nn.Module):
         p, u = self.patch_size, self.upsample_rate
         cu = self.downsample.kernel.shape[0]
         pad = (-cu) % 16
-        if not (x.is_cuda and self.upsample.dtype == torch.bfloat16 and self.upsample.kernel.dtype == torch.float32 and pad):
-            return None                                  # the caller falls back to forward()
+        if not (x.is_cuda and self.upsample.dtype == torch.bfloat16 and self.upsample.kernel.dtype == torch.float32 and pad and cu % 4 == 0):
+            return None                                  # the caller falls back to forward() (the fused kernel moves 8-byte pieces)
         x = self.upsample(self.linear(x))
         feat = _UnpatchPad.apply(x, p, self.height // p, self.width // p, u, pad)
         ds = self.downsample
