@@ -12,9 +12,9 @@
  *     parameter gradients are always fp32 in Flax layout (Conv kernel (kt,kh,kw,Cin,Cout));
  *   - `stream` is a hipStream_t; everything is enqueued asynchronously on it, nothing synchronises;
  *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
- *   - process-global mutable state is limited to six test / tuning hooks, none of which the product path calls:
- *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config,
- *     vvae_layernorm_fwd_mode, vvae_gemm_tn_use_big_tiles (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 keeps the
+ *   - process-global mutable state is limited to test / tuning hooks, none of which the product path calls:
+ *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config, vvae_layernorm_fwd_mode,
+ *     vvae_gemm_tn_use_big_tiles, vvae_temporal_attn_mfma_enable, vvae_temporal_attn_mfma32_enable (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 keeps the
  *     hipBLASLt handle and the solution the library's heuristic chose per (shape, pitches) behind a mutex; everything else is a pure function of its arguments.
  */
 #ifndef VVAE_HIP_H
@@ -179,6 +179,7 @@ int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, 
 int vvae_temporal_attn_fast_supported(int T, int D, int ld, int ldo, int dtype);
 int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D, int dtype);
 int vvae_temporal_attn_mfma_enable(int on);   /* test hook: 0 = keep bf16 / T = 16 / head_dim 64 on the VALU kernels (default 1: matrix cores) */
+int vvae_temporal_attn_mfma32_enable(int on);   /* test hook: 0 = T = 32 / 64 temporal attention on the VALU kernels again */
 int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, int ldo, float* lse, const float* q_scale,
                                 const float* k_scale, const float* cos_table, const float* sin_table, const uint8_t* mask,
                                 int mask_div, int inner, int A, int T, int heads, int D, float eps, int dtype, void* stream);

@@ -1002,14 +1002,18 @@ def test_xor_lane_exchange_selftest(dev, o):
     assert torch.equal(yd, x[idx].double() * 1.000000001)
 
 
-@pytest.mark.parametrize("a,heads,inner,masked", [(6, 8, 1, True), (5, 3, 1, False), (8, 8, 4, True), (12, 2, 6, False)])
-def test_temporal_attention_matrix_core_kernels(dev, a, heads, inner, masked):
-    """bf16, T = 16, head_dim 64 (the production temporal shape) runs on the matrix-core kernels (attn_temporal_mfma.hip): against
-    the oracle, and against the VALU kernels it replaces (test hook), contiguous and strided (FactoredAttention's (b, t, hw, c))
-    sequence layouts, item counts that do not fill the last workgroup, shared mask rows."""
+@pytest.mark.parametrize("a,heads,inner,masked,t", [(6, 8, 1, True, 16), (5, 3, 1, False, 16), (8, 8, 4, True, 16), (12, 2, 6, False, 16),
+                                                    (6, 8, 1, True, 32), (5, 3, 1, False, 32), (8, 4, 4, True, 32), (12, 2, 6, False, 32),
+                                                    (4, 2, 2, True, 64), (3, 1, 1, False, 64), (6, 3, 1, True, 64)])
+def test_temporal_attention_matrix_core_kernels(dev, a, heads, inner, masked, t):
+    """bf16, head_dim 64, T = 16 (the production temporal shape, attn_temporal_mfma.hip) and T = 32 / 64 (the later curriculum stages
+    and config C5, attn_temporal_mfma32.hip) run on the matrix-core kernels: against the oracle, and against the VALU kernels they
+    replace (test hooks), contiguous and strided (FactoredAttention's (b, t, hw, c)) sequence layouts, item counts that do not fill
+    the last workgroup, shared mask rows."""
     ops = _ops()
     from video_vae_amd._lib import lib
-    t, d, dtype = 16, 64, torch.bfloat16
+    d, dtype = 64, torch.bfloat16
+    hook = lib().vvae_temporal_attn_mfma_enable if t == 16 else lib().vvae_temporal_attn_mfma32_enable
     bsz = a // inner
     shape = (a, t, 3 * heads * d) if inner == 1 else (bsz, t, inner, 3 * heads * d)
     qkv = rnd(shape, 19).to(dtype).float()
@@ -1033,14 +1037,14 @@ def test_temporal_attention_matrix_core_kernels(dev, a, heads, inner, masked):
     m8 = mask.to(torch.uint8).to(dev) if masked else None
 
     def run(mfma):
-        lib().vvae_temporal_attn_mfma_enable(1 if mfma else 0)
+        hook(1 if mfma else 0)
         try:
             xg = qkv.to(dev, dtype).requires_grad_(True); qsg = qs.to(dev).requires_grad_(True); ksg = ks.to(dev).requires_grad_(True)
             yg = ops.temporal_attention_core(xg, qsg, ksg, cos.to(dev), sin.to(dev), m8, a // nm, heads, inner=inner)
             yg.backward(go.to(dev, dtype))
             return yg.detach(), xg.grad, qsg.grad, ksg.grad
         finally:
-            lib().vvae_temporal_attn_mfma_enable(1)
+            hook(1)
     new, old = run(True), run(False)
     for got in (new, old):
         assert_close(got[0], yo, rtol=3e-2, atol=3e-2, what="out")

@@ -22,6 +22,14 @@ int tmfma_bwd(const void* qkv, int ld, const void* out, int ldo, const void* dou
               const float* qs, const float* ks, const float* cosT, const float* sinT, const uint8_t* mask, int mask_div, int inner,
               float* part, int A, int heads, float eps, hipStream_t s);
 
+// matrix-core form for bf16, head_dim 64, T = 32 / 64 (attn_temporal_mfma32.hip); one partial row per (sequence, head)
+int tm32_supported(int T, int D, int ld, int ldo, int dtype);
+int tm32_fwd(const void* qkv, int ld, void* out, int ldo, float* lse, const float* qs, const float* ks, const float* cosT, const float* sinT,
+             const uint8_t* mask, int mask_div, int inner, int A, int T, int heads, float eps, hipStream_t s);
+int tm32_bwd(const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const float* lse, void* dqkv, int lddq,
+             const float* qs, const float* ks, const float* cosT, const float* sinT, const uint8_t* mask, int mask_div, int inner,
+             float* part, int A, int T, int heads, float eps, hipStream_t s);
+
 namespace {
 
 struct FAttnDims { int A, T, heads, mask_div; float eps; long items; int inner; };
@@ -349,6 +357,7 @@ extern "C" int vvae_temporal_attn_fast_blocks(int A, int T, int heads, int D, in
 {
     if (T < 1 || T > 64 || D < 1) return 0;
     if (tmfma_supported(T, D, 8, 8, dtype)) return tmfma_bwd_rows((long)A * heads);
+    if (tm32_supported(T, D, 8, 8, dtype)) return A * heads;
     return ceil_div((long)A * heads, 64 / (T * pick_lpr(T, D)));
 }
 
@@ -365,6 +374,8 @@ extern "C" int vvae_temporal_attn_fwd_fast(const void* qkv, int ld, void* out, i
     hipStream_t s = (hipStream_t)stream;
     if (tmfma_supported(T, D, ld, ldo, dtype) && (!mask || ((uintptr_t)mask % 4) == 0))
         return tmfma_fwd(qkv, ld, out, ldo, lse, q_scale, k_scale, cos_table, sin_table, mask, mask_div, inner, A, heads, eps, s);
+    if (tm32_supported(T, D, ld, ldo, dtype) && (!mask || ((uintptr_t)mask % 4) == 0))
+        return tm32_fwd(qkv, ld, out, ldo, lse, q_scale, k_scale, cos_table, sin_table, mask, mask_div, inner, A, T, heads, eps, s);
     FATTN_DISPATCH(launch_fwd, qkv, ld, out, ldo, lse, q_scale, k_scale, cos_table, sin_table, mask, d, s);
 }
 
@@ -384,5 +395,8 @@ extern "C" int vvae_temporal_attn_bwd_fast(const void* qkv, int ld, const void* 
     if (tmfma_supported(T, D, ld, ldo, dtype) && tmfma_supported(T, D, lddq, lddo, dtype) && (!mask || ((uintptr_t)mask % 4) == 0))
         return tmfma_bwd(qkv, ld, out, ldo, dout, lddo, lse, dqkv, lddq, q_scale, k_scale, cos_table, sin_table, mask, mask_div, inner,
                          dscale_part, A, heads, eps, s);
+    if (tm32_supported(T, D, ld, ldo, dtype) && tm32_supported(T, D, lddq, lddo, dtype) && (!mask || ((uintptr_t)mask % 4) == 0))
+        return tm32_bwd(qkv, ld, out, ldo, dout, lddo, lse, dqkv, lddq, q_scale, k_scale, cos_table, sin_table, mask, mask_div, inner,
+                        dscale_part, A, T, heads, eps, s);
     FATTN_DISPATCH(launch_bwd, qkv, ld, out, ldo, dout, lddo, lse, dqkv, lddq, q_scale, k_scale, cos_table, sin_table, mask, dscale_part, d, s);
 }
