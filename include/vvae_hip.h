@@ -106,6 +106,10 @@ int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx
 int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, long V, int Cin, int Cout,
                               int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- dst_i (cols_i, rows_i) = src_i (rows_i, cols_i)^T for n <= 64 contiguous bf16 matrices (dims multiples of 64) in one launch: the
+ *      (out, in) shadows of the Linear kernels that vvae_gemm_nt_bf16 multiplies in the forward pass, refreshed once per optimizer step. ---- */
+int vvae_transpose_grouped_bf16(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, void* stream);
+
 /* ---- y = silu(x) over a contiguous bf16 tensor of n elements (n % 8 == 0): the activation between the MLP's two Linear layers
  *      (train/layers.py:186-189). ---- */
 int vvae_silu_bf16(const void* x, void* y, long n, void* stream);

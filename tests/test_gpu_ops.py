@@ -1208,3 +1208,67 @@ def test_silu_stream_kernel(dev):
     assert_close(ops.silu_bf16(big), torch.nn.functional.silu(big.float()).to(torch.bfloat16), rtol=2 ** -7, atol=1e-6, what="silu, production shape")
     odd = torch.randn(13, device=dev, dtype=torch.bfloat16)
     assert torch.equal(ops.silu_bf16(odd), torch.nn.functional.silu(odd))
+
+
+def test_transposed_shadows_follow_the_optimizer(dev):
+    """The (out, in) bf16 shadows of the kernels marked ``want_t`` (the MLP's fc1) equal the bf16 shadow
+    transposed at construction, after every Adam update and after refresh_shadow (vvae_transpose_grouped_bf16)."""
+    import video_vae_amd as V
+    from video_vae_amd import layers as LY, optim
+    m = LY.MLP(128, 320, V.Rngs(2)).to(dev)                        # 320 x 128: both dims multiples of 64, not square
+    opt = optim.Optimizer(m, 1e-2)
+    k = m.linear1.kernel
+    assert k.bf16_t.shape == (320, 128) and getattr(m.linear2.kernel, "bf16_t", None) is None
+    assert torch.equal(k.bf16_t, k.bf16.t())
+    x = rnd((256, 128), 5, 1.0).to(dev, torch.bfloat16)
+    for _ in range(2):
+        opt.zero_grad()
+        m(x).float().square().mean().backward()
+        before = k.bf16_t.clone()
+        opt.update()
+        assert torch.equal(k.bf16_t, k.bf16.t()) and not torch.equal(k.bf16_t, before)
+    with torch.no_grad():
+        k.mul_(0.5)
+    opt.refresh_shadow()
+    assert torch.equal(k.bf16_t, k.detach().to(torch.bfloat16).t())
+
+
+@pytest.mark.parametrize("rows,c,mlp", [(4096, 768, 1536), (1024, 512, 1024)])
+def test_mlp_residual_on_the_nt_products(dev, rows, c, mlp):
+    """MLP.residual with the transposed shadows (fc1 + SiLU out of one NT product, ops.gemm_nt EPI_SILU) against the same block
+    with the shadows removed (library product + SiLU stream kernel) and against the fp32 oracle; reference train/layers.py:174-196."""
+    import video_vae_amd as V
+    from video_vae_amd import layers as LY, optim
+    from oracle import layers as OL
+    m = LY.MLP(c, mlp, V.Rngs(3)).to(dev)
+    opt = optim.Optimizer(m, 1e-3)
+    with torch.no_grad():
+        m.linear1.bias.copy_(rnd((mlp,), 1, 0.1).to(dev)); m.linear2.kernel.mul_(30.0)
+    opt.refresh_shadow()
+    x = rnd((rows, c), 7, 1.0).to(dev, torch.bfloat16)
+    gy = rnd((rows, c), 8, 1.0).to(dev, torch.bfloat16)
+    assert LY.nt_silu_ok(m.linear1, x) and not LY.nt_silu_ok(m.linear1, x[:1000])     # ragged row counts keep the library path
+    assert m.residual(x[:1000]).shape == (1000, c)
+    out = []
+    for fused in (True, False):
+        wt = m.linear1.kernel.bf16_t
+        if not fused:
+            m.linear1.kernel.bf16_t = None
+        xx = x.clone().requires_grad_(True)
+        opt.zero_grad()
+        y = m.residual(xx)
+        y.backward(gy)
+        for b in range(len(opt.buckets)):
+            if not opt.landed[b]:
+                opt._land(b)
+        out.append((y.detach().float().cpu(), xx.grad.float().cpu(), m.linear1.kernel.gview.clone().cpu(), m.linear1.bias.gview.clone().cpu()))
+        m.linear1.kernel.bf16_t = wt
+    (y1, dx1, dw1, db1), (y0, dx0, dw0, db0) = out
+    p = {n: t.detach().float().cpu() for n, t in m.named_parameters()}
+    ref = x.float().cpu() + OL.mlp(p, x.float().cpu())
+    e1 = float((y1 - ref).abs().mean()); e0 = float((y0 - ref).abs().mean())
+    assert e1 <= 1.1 * e0 + 1e-4, (e1, e0)
+    assert_close_scaled(y1, y0, rel=1e-2, what="y nt vs library")
+    assert_close_scaled(dx1, dx0, rel=1e-2, what="dx")
+    assert_close_scaled(dw1, dw0, rel=1e-2, what="dW1")
+    assert_close_scaled(db1, db0, rel=1e-2, what="db1")

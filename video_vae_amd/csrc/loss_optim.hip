@@ -600,3 +600,57 @@ extern "C" int vvae_silu_bf16(const void* x, void* y, long n, void* stream)
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------- transposed weight shadows
+// dst_i (cols_i, rows_i) = src_i (rows_i, cols_i)^T for up to 64 bf16 matrices in one launch: the (out, in) copies of the Linear
+// kernels that the own NT GEMM multiplies in the forward pass (fc1 + SiLU, out-projection + residual), refreshed once per optimizer
+// step from the bf16 shadow the Adam kernel writes.  64 x 64 tiles through LDS, 16-byte accesses on both sides.
+namespace {
+constexpr int TR_MAX = 64;
+struct TrEntry { const bf16_t* src; bf16_t* dst; int rows, cols, tiles_c, tile_start; };
+struct TrArgs { TrEntry e[TR_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void transpose_grouped_kernel(TrArgs g)
+{
+    __shared__ bf16_t tile[64][64 + 8];
+    int ei = 0;
+    for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].tile_start ? i : ei;
+    const TrEntry& E = g.e[ei];
+    const int t = blockIdx.x - E.tile_start;
+    const int r0 = (t / E.tiles_c) * 64, c0 = (t % E.tiles_c) * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;            // 32 rows x 8 chunks of 8 elements per pass
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int r = tr + 32 * ps;
+        const uint4 v = *reinterpret_cast<const uint4*>(E.src + (long)(r0 + r) * E.cols + c0 + tc);
+        *reinterpret_cast<uint4*>(&tile[r][tc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int c = tr + 32 * ps;                                          // output row = source column
+        bf16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = tile[tc + e][c];
+        *reinterpret_cast<uint4*>(E.dst + (long)(c0 + c) * E.rows + r0 + tc) = *reinterpret_cast<const uint4*>(o);
+    }
+}
+}  // namespace
+
+// n <= 64 matrices, rows_i and cols_i multiples of 64, 16-byte aligned, contiguous.  Host arrays of device pointers / ints.
+extern "C" int vvae_transpose_grouped_bf16(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, void* stream)
+{
+    if (!src || !dst || !rows || !cols || n <= 0 || n > TR_MAX) return VVAE_ERR_BAD_ARG;
+    TrArgs g;
+    g.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i] || rows[i] <= 0 || cols[i] <= 0 || rows[i] % 64 || cols[i] % 64 || ((uintptr_t)src[i] % 16) || ((uintptr_t)dst[i] % 16))
+            return VVAE_ERR_BAD_ARG;
+        g.e[i] = TrEntry{(const bf16_t*)src[i], (bf16_t*)dst[i], rows[i], cols[i], cols[i] / 64, tiles};
+        tiles += (rows[i] / 64) * (cols[i] / 64);
+    }
+    hipLaunchKernelGGL(transpose_grouped_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, g);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

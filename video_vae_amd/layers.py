@@ -77,9 +77,10 @@ class _LinearBf16(torch.autograd.Function):
     fp32 weight / bias gradients directly."""
 
     @staticmethod
-    def forward(ctx, x, kernel, bias, res=None):
-        """``res``: the residual stream this Linear closes a branch of (x_skip + Linear(...)): added inside the library product
-        (ops.linear_residual); the caller checked ops.linear_residual_ok."""
+    def forward(ctx, x, kernel, bias, res=None, with_silu=False):
+        """``res``: the residual stream this Linear closes a branch of (x_skip + Linear(...)): added inside the product (the
+        library's, with the residual as its C operand: ops.linear_residual; in situ it beats the own NT kernel's residual epilogue,
+        28.6 vs 34 us on the out-projection); the caller checked ops.linear_residual_ok.  ``with_silu``: also return silu(y) (the caller checked nt_silu_ok)."""
         wb = getattr(kernel, "bf16", None)
         if wb is None:
             wb = kernel.detach().to(torch.bfloat16)
@@ -91,12 +92,21 @@ class _LinearBf16(torch.autograd.Function):
         ctx.xshape = x.shape
         ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the parked gradient is to be written
         ctx.has_res = res is not None
+        ctx.two = bool(with_silu)
+        wt = getattr(kernel, "bf16_t", None)                         # (out, in) shadow: the own NT GEMM's operand (optim.Optimizer)
+        if with_silu:
+            # -> (h, silu(h)) from ONE product (ops.gemm_nt, EPI_SILU): the activation between the MLP's Linear layers costs no pass
+            a, h = ops.gemm_nt(x2, wt, bias.detach(), None, ops.EPI_SILU)
+            h, a = h.view(*x.shape[:-1], wb.shape[1]), a.view(*x.shape[:-1], wb.shape[1])
+            ctx.mark_non_differentiable(a)
+            ctx.set_materialize_grads(False)                        # no zero-filled gradient tensor for ``a`` in backward
+            return h, a
         if res is not None:
             return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1])).view(res.shape)
         return torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1])
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, da=None):
         x2, wb = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.dtype != torch.bfloat16:
@@ -107,14 +117,14 @@ class _LinearBf16(torch.autograd.Function):
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ops.wgrad_deferrable(x2, dy2, ctx.kparam, ctx.bparam):
             # parked: multiplied after backward in a grouped launch, straight into the optimizer's flat gradient buffer
             ops.WGRAD_QUEUE[0].append((x2, dy2, ctx.kparam, ctx.bparam))
-            return dx, None, None, dres
+            return dx, None, None, dres, None
         if ctx.needs_input_grad[1] and ops.gemm_tn_supported(x2, dy2):
             # split-K weight-gradient GEMM on the HIP kernel (bias gradient rides along): K = tokens >> M, N
             dw, db = ops.gemm_tn(x2, dy2, ctx.needs_input_grad[2])
         else:
             dw = _dw_f32(x2, dy2) if ctx.needs_input_grad[1] else None
             db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, dres
+        return dx, dw, db, dres, None
 
 
 class _SiluLinearBf16(torch.autograd.Function):
@@ -123,10 +133,11 @@ class _SiluLinearBf16(torch.autograd.Function):
     round trip through HBM that a separate silu_backward launch costs).  Forward = the library GEMM + the framework's SiLU."""
 
     @staticmethod
-    def forward(ctx, h, kernel, bias, res=None):
+    def forward(ctx, h, kernel, bias, res=None, act=None):
+        """``act``: silu(h) when the producing product already made it (_LinearBf16 with_silu)."""
         wb, bb = kernel.bf16, bias.bf16
         h2 = h.reshape(-1, h.shape[-1])
-        a = ops.silu_bf16(h2)
+        a = act.reshape(-1, h.shape[-1]) if act is not None else ops.silu_bf16(h2)
         ctx.save_for_backward(h2, a, wb)
         ctx.hshape = h.shape
         ctx.kparam, ctx.bparam = kernel, bias
@@ -153,13 +164,13 @@ class _SiluLinearBf16(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ops.wgrad_deferrable(a, dy2, ctx.kparam, ctx.bparam):
             ops.WGRAD_QUEUE[0].append((a, dy2, ctx.kparam, ctx.bparam))
-            return dh, None, None, dres
+            return dh, None, None, dres, None
         if ctx.needs_input_grad[1] and ops.gemm_tn_supported(a, dy2):
             dw, db = ops.gemm_tn(a, dy2, ctx.needs_input_grad[2])
         else:
             dw = _dw_f32(a, dy2) if ctx.needs_input_grad[1] else None
             db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        return dh, dw, db, dres
+        return dh, dw, db, dres, None
 
 
 def _shadowed(linear, h):
@@ -174,17 +185,32 @@ def silu_linear(h, linear):
     return linear(F.silu(h))
 
 
-def close_branch(linear, o, skip, defer, silu=False):
+def nt_silu_ok(linear, x):
+    """linear(x) and silu(linear(x)) can come out of one product of the own NT GEMM (needs the (out, in) weight shadow)."""
+    wt = getattr(linear.kernel, "bf16_t", None)
+    return (_shadowed(linear, x) and wt is not None and linear.bias.dtype == torch.float32
+            and ops.gemm_nt_supported(x.reshape(-1, x.shape[-1]), wt))
+
+
+def linear_with_silu(linear, x):
+    """-> (h, silu(h)) with h = linear(x): one launch when nt_silu_ok, else (h, None) and the consumer applies the activation."""
+    if nt_silu_ok(linear, x):
+        return _LinearBf16.apply(x.to(linear.dtype), linear.kernel, linear.bias, None, True)
+    return linear(x), None
+
+
+def close_branch(linear, o, skip, defer, silu=False, act=None):
     """The end of a residual branch: ``skip + linear(o)`` (``linear(silu(o))`` with silu=True; reference train/layers.py:212-221).
-    On the bf16 GPU path the add rides in the library product as its C operand and the result is the new residual stream:
-    -> (sum, None) if defer else sum.  Elsewhere -> (skip, branch) if defer (the next LayerNorm kernel adds) else skip + branch."""
+    On the bf16 GPU path the add rides in the product and the result is the new residual stream:
+    -> (sum, None) if defer else sum.  Elsewhere -> (skip, branch) if defer (the next LayerNorm kernel adds) else skip + branch.
+    ``act``: silu(o) if the caller already has it (linear_with_silu)."""
     if _shadowed(linear, o) and skip.dtype == torch.bfloat16:
         o2, r2 = o.reshape(-1, o.shape[-1]), skip.reshape(-1, skip.shape[-1])
         if ops.linear_residual_ok(o2, linear.kernel.bf16, linear.bias.bf16, r2):
-            fn = _SiluLinearBf16 if silu else _LinearBf16
-            s = fn.apply(o, linear.kernel, linear.bias, skip)
+            s = (_SiluLinearBf16.apply(o, linear.kernel, linear.bias, skip, act) if silu
+                 else _LinearBf16.apply(o, linear.kernel, linear.bias, skip))
             return (s, None) if defer else s
-    y = silu_linear(o, linear) if silu else linear(o)
+    y = (silu_linear(o, linear) if act is None else linear(act)) if silu else linear(o)
     return (skip, y) if defer else skip + y
 
 
@@ -431,6 +457,7 @@ class MLP(nn.Module):
         self.norm = LayerNorm(in_features, dtype, param_dtype)
         self.linear1 = Linear(in_features, mlp_dim, rngs, dtype, param_dtype)
         self.linear2 = Linear(mlp_dim, in_features, rngs, dtype, param_dtype, kernel_scale=1e-2)
+        self.linear1.kernel.want_t = True          # the optimizer keeps an (out, in) bf16 shadow: fc1 + SiLU on the own NT GEMM
 
     def forward(self, x):
         return silu_linear(self.linear1(self.norm(x)), self.linear2)
@@ -438,7 +465,8 @@ class MLP(nn.Module):
     def residual(self, x, pending=None, defer=False):
         """x + self(x) with the skip gradient folded into the LayerNorm's backward (pending / defer: LayerNorm.fork)."""
         y, skip = self.norm.fork(x, pending)
-        return close_branch(self.linear2, self.linear1(y), skip, defer, silu=True)
+        h, a = linear_with_silu(self.linear1, y)
+        return close_branch(self.linear2, h, skip, defer, silu=True, act=a)
 
 
 class FactoredAttention(nn.Module):

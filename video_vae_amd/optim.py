@@ -92,6 +92,19 @@ class Optimizer:
                 p.bf16 = self.shadow[o:o + n].view(p.shape)       # read by layers.Linear: no per-call weight casts
         if self.shadow is not None:
             self.shadow.copy_(self.p)
+        # transposed bf16 shadows (out, in) of the Linear kernels whose forward runs on the own NT GEMM (layers mark them ``want_t``:
+        # the MLP's fc1, whose product also emits SiLU); refreshed after every update from the bf16 shadow, one grouped launch per 64
+        self.tpairs = []
+        if self.shadow is not None and dev.type == "cuda":
+            want = [p for p in self.params if getattr(p, "want_t", False) and p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0]
+            if want:
+                tbuf = torch.zeros(sum(p.numel() for p in want), dtype=torch.bfloat16, device=dev)
+                o = 0
+                for p in want:
+                    p.bf16_t = tbuf[o:o + p.numel()].view(p.shape[1], p.shape[0])
+                    self.tpairs.append((p.bf16, p.bf16_t))
+                    o += p.numel()
+                self._refresh_transposed()
         # ---- buckets: contiguous [start, end) element ranges aligned to parameter slots ----
         cap = max(1, bucket_bytes // 4)
         ends = [o + (p.numel() + 3) // 4 * 4 for o, p in zip(self.offsets, self.params)]
@@ -254,13 +267,27 @@ class Optimizer:
                                         self.gnorm_part.numel(), vp(self.gnorm_sq), gscale, self.max_norm, lr, self.b1, self.b2,
                                         self.eps, self.count, s),
               "vvae_adam_clip_step")
+        if self.tpairs:
+            self._refresh_transposed()
         self.last_lr = lr
         return lr
 
+    def _refresh_transposed(self):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for i0 in range(0, len(self.tpairs), 64):
+            e = self.tpairs[i0:i0 + 64]
+            n = len(e)
+            VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+            check(lib().vvae_transpose_grouped_bf16(VP(*[a.data_ptr() for a, _ in e]), VP(*[b.data_ptr() for _, b in e]),
+                                                    IA(*[a.shape[0] for a, _ in e]), IA(*[a.shape[1] for a, _ in e]), n, s),
+                  "vvae_transpose_grouped_bf16")
+
     def refresh_shadow(self):
-        """Re-derive the bf16 shadow after parameters were written from outside (checkpoint load, broadcast)."""
+        """Re-derive the bf16 shadows after parameters were written from outside (checkpoint load, broadcast)."""
         if self.shadow is not None:
             self.shadow.copy_(self.p)
+            if self.tpairs:
+                self._refresh_transposed()
 
     def grad_norm(self):
         """||g|| of the last update (host sync)."""
