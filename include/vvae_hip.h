@@ -110,6 +110,14 @@ int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, 
  *      (out, in) shadows of the Linear kernels that vvae_gemm_nt_bf16 multiplies in the forward pass, refreshed once per optimizer step. ---- */
 int vvae_transpose_grouped_bf16(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, void* stream);
 
+/* The scalar end of the recon + KL loss, value and gradients in one launch (reference train/legacy/training_loop_adversarial.py:100-124:
+ * selection density against 1 / max_compression_rate with magnified negatives, MSE + gamma1 selection + gamma2 KL).
+ * mse_ps, kl_ps fp32 [B]; selection, mask fp32 (B, T) contiguous.  out fp32 [5] = loss, MSE, selection_loss, kl_loss, mean kept-frame
+ * density.  grads fp32 [2 B + B T] = d loss / d mse_ps | d loss / d kl_ps | d loss / d selection.  B <= 1024. */
+int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, const float* selection, const float* mask, int B, int T,
+                         float max_compression_rate, float magnify_negatives_rate, float gamma1, float gamma2, float* out,
+                         float* grads, void* stream);
+
 /* ---- y = silu(x) over a contiguous bf16 tensor of n elements (n % 8 == 0): the activation between the MLP's two Linear layers
  *      (train/layers.py:186-189). ---- */
 int vvae_silu_bf16(const void* x, void* y, long n, void* stream);

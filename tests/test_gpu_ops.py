@@ -1272,3 +1272,38 @@ def test_mlp_residual_on_the_nt_products(dev, rows, c, mlp):
     assert_close_scaled(dx1, dx0, rel=1e-2, what="dx")
     assert_close_scaled(dw1, dw0, rel=1e-2, what="dW1")
     assert_close_scaled(db1, db0, rel=1e-2, what="db1")
+
+
+@pytest.mark.parametrize("b,t", [(4, 16), (3, 5), (64, 32)])
+def test_plain_loss_tail_matches_the_framework_ops(dev, b, t):
+    """vvae_loss_tail_plain (loss, aux and all three gradients in one launch) against the same algebra as differentiable framework
+    ops — the reference's per-sample tail, train/legacy/training_loop_adversarial.py:100-124; ragged masks, an all-masked sample
+    (length clamps to 1), densities on both sides of 1 / max_compression_rate."""
+    from video_vae_amd import ops
+    from video_vae_amd.loss import HPARAMS, magnify_negatives
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(b, t, generator=g) < 0.7).float()
+    mask[0] = 0.0
+    mask[-1] = 1.0
+    sel = torch.rand(b, t, 1, 1, generator=g)
+    sel[1] = torch.round(sel[1])
+    mse = torch.rand(b, generator=g); kl = torch.rand(b, generator=g) * 50
+    leaves = [x.to(dev).requires_grad_(True) for x in (mse, kl, sel)]
+    mk = mask.to(dev)
+    assert ops.plain_loss_tail_ok(leaves[0], leaves[1], leaves[2], mk)
+    loss, (MSE, sl, klm, dens) = ops.plain_loss_tail(leaves[0], leaves[1], leaves[2], mk, HPARAMS)
+    (loss * 3.0).backward()
+    got = [x.grad.clone() for x in leaves]
+    ref_leaves = [x.double().requires_grad_(True) for x in (mse, kl, sel)]
+    m64 = mask.double()
+    lens = torch.clamp(m64.sum(1, keepdim=True), min=1.0)
+    density = (ref_leaves[2].reshape(b, t) * m64).sum(1, keepdim=True) / lens
+    s_loss = torch.square(magnify_negatives(density - 1 / HPARAMS["max_compression_rate"], HPARAMS["magnify_negatives_rate"])).mean()
+    ref = ref_leaves[0].mean() + HPARAMS["gamma1"] * s_loss + HPARAMS["gamma2"] * ref_leaves[1].mean()
+    (ref * 3.0).backward()
+    for a, w, what in ((loss, ref, "loss"), (MSE, ref_leaves[0].mean(), "MSE"), (sl, s_loss, "selection_loss"),
+                       (klm, ref_leaves[1].mean(), "kl"), (dens, density.mean(), "density")):
+        assert_close(a, w.detach(), rtol=1e-5, atol=1e-6, what=what)
+    for a, w, what in zip(got, ref_leaves, ("d mse", "d kl", "d selection")):
+        assert a.shape == w.grad.shape
+        assert_close_scaled(a, w.grad, rel=1e-5, what=what)      # fp32 density - 1/rate against the fp64 reference: absolute, not relative

@@ -265,11 +265,19 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                                 T* __restrict__ dx, int lddx, const double* __restrict__ sums,
                                                                 const double* __restrict__ csum, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, GnDims d, int voxels_per_block)
+                                                                const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, GnDims d, int voxels_per_block)
 {
     __shared__ float ab[kMaxC][2];
     __shared__ float mean_g[64], rstd_g[64], m1_g[64], m2_g[64];
     const int n = blockIdx.y;
+    if (blockIdx.x == 0 && n == 0)                        // the affine-parameter gradients ride along in one workgroup (was a launch)
+        for (int c = threadIdx.x; c < d.C; c += 256) {
+            double a = 0.0, b = 0.0;
+            for (int m = 0; m < d.N; ++m) { a += csum[((long)m * d.C + c) * 2]; b += csum[((long)m * d.C + c) * 2 + 1]; }
+            dgamma[c] = (float)a;
+            dbeta[c] = (float)b;
+        }
     load_affine(sums, gamma, beta, d, n, ab, mean_g, rstd_g);
     const int cvecs = d.C / VEC, cpg = d.C / d.G;
     if (threadIdx.x < d.G) {
@@ -313,17 +321,6 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restr
             }
             VecIO<T, VEC>::store(dxs + v * lddx, t);
         }
-}
-
-__global__ void gn_param_grad_kernel(const double* __restrict__ csum, int N, int C, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int n = 0; n < N; ++n) { a += csum[((long)n * C + c) * 2]; b += csum[((long)n * C + c) * 2 + 1]; }
-    dgamma[c] = (float)a;
-    dbeta[c] = (float)b;
 }
 
 inline int pick_vpb(long S, int N, int total_blocks = 4096) {
@@ -434,9 +431,8 @@ extern "C" int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(2 * C, 32), N), dim3(256), 0, s, part, csum, (int)grid.x, C);
         VVAE_LAUNCH_CHECK();
     }
-    GN_DISPATCH(gn_silu_bwd_apply_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, sums, csum, gamma, beta, d, vpb);
-    VVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, csum, N, C, dgamma, dbeta);
+    GN_DISPATCH(gn_silu_bwd_apply_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, sums, csum, gamma, beta, dgamma, dbeta, d,
+                vpb);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -171,6 +171,56 @@ __global__ __launch_bounds__(64) void sum_chunks_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
+// two partial arrays of B rows each, laid one behind the other, folded by one launch (grid 2B): rows [0, B) -> out0, [B, 2B) -> out1
+__global__ __launch_bounds__(64) void sum_chunks2_kernel(const float* __restrict__ part, int nchunks, float* __restrict__ out0,
+                                                        float* __restrict__ out1, int B)
+{
+    const float* row = part + (long)blockIdx.x * nchunks;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < nchunks; c += 64) acc += row[c];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) { if ((int)blockIdx.x < B) out0[blockIdx.x] = acc; else out1[blockIdx.x - B] = acc; }
+}
+
+// The scalar end of the recon + KL loss (reference train/legacy/training_loop_adversarial.py:100-124), value AND gradients in one
+// launch: as framework ops this tail is ~45 kernels of a few hundred bytes each per step, every one a 5 us dispatch.
+//   len_b = max(sum_t mask, 1); density_b = sum_t sel * mask / len_b; d_b = density_b - 1 / max_rate; m_b = d_b < 0 ? R d_b : d_b
+//   selection_loss = mean_b m_b^2;  loss = mean_b mse + gamma1 selection_loss + gamma2 mean_b kl
+// out[5] = loss, MSE, selection_loss, kl_loss, mean density.   grads = [d loss / d mse_b (B) | d / d kl_b (B) | d / d sel_bt (B T)].
+// One workgroup; sample b is thread b's (strided), the means are summed by thread 0 in index order: deterministic.
+constexpr int TAIL_MAX_B = 1024;
+__global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __restrict__ mse, const float* __restrict__ kl,
+                                                             const float* __restrict__ sel, const float* __restrict__ mask, int B, int T,
+                                                             float inv_max_rate, float magnify, float gamma1, float gamma2,
+                                                             float* __restrict__ out, float* __restrict__ grads)
+{
+    __shared__ float sq[TAIL_MAX_B], dens[TAIL_MAX_B];
+    const float invB = 1.f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float len = 0.f, ssum = 0.f;
+        for (int t = 0; t < T; ++t) { const float m = mask[b * T + t]; len += m; ssum += sel[b * T + t] * m; }
+        len = fmaxf(len, 1.f);
+        const float density = ssum / len;
+        const float d = density - inv_max_rate;
+        const float slope = d < 0.f ? magnify : 1.f;
+        const float m = d * slope;
+        sq[b] = m * m;
+        dens[b] = density;
+        const float gd = gamma1 * invB * 2.f * m * slope / len;     // d loss / d ssum
+        for (int t = 0; t < T; ++t) grads[2 * B + b * T + t] = gd * mask[b * T + t];
+        grads[b] = invB;
+        grads[B + b] = gamma2 * invB;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, k = 0.f, q = 0.f, dn = 0.f;
+        for (int b = 0; b < B; ++b) { a += mse[b]; k += kl[b]; q += sq[b]; dn += dens[b]; }
+        a *= invB; k *= invB; q *= invB; dn *= invB;
+        out[0] = a + gamma1 * q + gamma2 * k;
+        out[1] = a; out[2] = q; out[3] = k; out[4] = dn;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- optimiser
 constexpr int SQN_MAX_BLOCKS = 1024;
 
@@ -307,8 +357,20 @@ extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, con
         if (al && M % 8 == 0) hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
         else hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
     } else return VVAE_ERR_BAD_ARG;
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3(B), dim3(64), 0, s, mse, (int)grid.x, mse_out);
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3(B), dim3(64), 0, s, mae, (int)grid.x, mae_out);
+    hipLaunchKernelGGL(sum_chunks2_kernel, dim3(2 * B), dim3(64), 0, s, part, (int)grid.x, mse_out, mae_out, B);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// mse_ps, kl_ps fp32 [B]; selection, mask fp32 (B, T) contiguous.  out fp32 [5], grads fp32 [2 B + B T] (see loss_tail_plain_kernel).
+extern "C" int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, const float* selection, const float* mask, int B, int T,
+                                    float max_compression_rate, float magnify_negatives_rate, float gamma1, float gamma2, float* out,
+                                    float* grads, void* stream)
+{
+    if (!mse_ps || !kl_ps || !selection || !mask || !out || !grads || B <= 0 || B > TAIL_MAX_B || T <= 0 || !(max_compression_rate > 0.f))
+        return VVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL(loss_tail_plain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_ps, kl_ps, selection, mask, B, T,
+                       1.f / max_compression_rate, magnify_negatives_rate, gamma1, gamma2, out, grads);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -96,13 +96,19 @@ def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
     om = original_mask.to(torch.float32)
     sequence_lengths = torch.clamp(reduce(om, "b time -> b 1", "sum"), min=1.0)
     mse_ps, _ = ops.masked_mse_mae(video, reconstruction, om, video_div=1)
+    kl_ps = kl_from_model(model, mean, logvar, om)
+    if ops.plain_loss_tail_ok(mse_ps, kl_ps, selection, om):
+        # GPU: the per-sample algebra below (and its backward) as ONE launch instead of ~45 framework kernels of a few bytes each
+        loss, (MSE, selection_loss, kl_loss, density) = ops.plain_loss_tail(mse_ps, kl_ps, selection, om, hparams)
+        return loss, {"MSE": MSE, "selection_loss": selection_loss, "kl_loss": kl_loss, "reconstruction": reconstruction,
+                      "kept_frame_density": density}
     MSE = mse_ps.mean()
     kl_and_selection_mask = rearrange(om, "b time -> b time 1 1")
     selection_sum = reduce(selection * kl_and_selection_mask, "b time 1 1 -> b 1", "sum")
     kept_frame_density = selection_sum / sequence_lengths
     diff = kept_frame_density - (1 / hparams["max_compression_rate"])
     selection_loss = torch.square(magnify_negatives(diff, hparams["magnify_negatives_rate"])).mean()
-    kl_loss = kl_from_model(model, mean, logvar, om).mean()
+    kl_loss = kl_ps.mean()
     loss = MSE + hparams["gamma1"] * selection_loss + hparams["gamma2"] * kl_loss
     return loss, {"MSE": MSE, "selection_loss": selection_loss, "kl_loss": kl_loss, "reconstruction": reconstruction,
                   "kept_frame_density": kept_frame_density.mean()}

@@ -326,6 +326,7 @@ class _Conv3d(torch.autograd.Function):
         if gn_blocks:
             y, part = conv3d_fwd_gn_raw(x, k32, b32, gn_groups, gn_blocks, pack.fwd if pack is not None else None)
             ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)             # no zero-filled gradient tensor for the partials in backward
             ctx.with_part = True
             return y, part
         ctx.with_part = False
@@ -447,6 +448,7 @@ class _Conv3dCat2(torch.autograd.Function):
         if gn_blocks:
             y, part = conv3d_cat2_fwd_raw(xa, xb, k32, b32, gn_groups, gn_blocks, pk)
             ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
             return y, part
         return conv3d_cat2_fwd_raw(xa, xb, k32, b32, packed=pk)
 
@@ -1111,15 +1113,18 @@ class _MaskedMseMae(torch.autograd.Function):
                                             _dt(recon), _stream()), "vvae_masked_mse_mae_fwd")
         ctx.save_for_backward(video, recon, mask)
         ctx.video_div = video_div
+        ctx.set_materialize_grads(False)                 # an unused output's gradient stays None (the kernel takes NULL), no zero fill
         return mse, mae
 
     @staticmethod
     def backward(ctx, gmse, gmae):
         video, recon, mask = ctx.saved_tensors
+        if gmse is None and gmae is None:
+            return None, None, None, None
         b, t = recon.shape[0], recon.shape[1]
         p = recon.numel() // (b * t)
-        gmse = gmse.to(torch.float32).contiguous()
-        gmae = gmae.to(torch.float32).contiguous()
+        gmse = gmse.to(torch.float32).contiguous() if gmse is not None else None
+        gmae = gmae.to(torch.float32).contiguous() if gmae is not None else None
         dr = torch.empty_like(recon)
         check(lib().vvae_masked_mse_mae_bwd(_p(video), _p(recon), _p(mask), _p(gmse), _p(gmae), _p(dr), b, t, p, ctx.video_div,
                                             _dt(recon), _stream()), "vvae_masked_mse_mae_bwd")
@@ -1129,6 +1134,47 @@ class _MaskedMseMae(torch.autograd.Function):
 def masked_mse_mae(video, recon, mask_bt, video_div=1):
     """Per-sample masked MSE and MAE (reference train/rl_nonadversarial.py:114-121); gradient flows to recon only."""
     return _MaskedMseMae.apply(video, recon, mask_bt, video_div)
+
+
+class _PlainLossTail(torch.autograd.Function):
+    """The scalar end of loss.loss_fn_plain in one launch, gradients included (vvae_loss_tail_plain)."""
+
+    @staticmethod
+    def forward(ctx, mse_ps, kl_ps, selection, mask, max_rate, magnify, gamma1, gamma2):
+        b, t = mask.shape
+        out = torch.empty((5,), dtype=torch.float32, device=mse_ps.device)
+        grads = torch.empty((2 * b + b * t,), dtype=torch.float32, device=mse_ps.device)
+        sel = selection.reshape(b, t).to(torch.float32).contiguous()
+        check(lib().vvae_loss_tail_plain(_p(mse_ps.contiguous()), _p(kl_ps.contiguous()), _p(sel), _p(mask), b, t, float(max_rate),
+                                         float(magnify), float(gamma1), float(gamma2), _p(out), _p(grads), _stream()),
+              "vvae_loss_tail_plain")
+        ctx.save_for_backward(grads)
+        ctx.bt, ctx.sel_shape, ctx.sel_dtype = (b, t), selection.shape, selection.dtype
+        aux = out[1:]
+        ctx.mark_non_differentiable(aux)
+        ctx.set_materialize_grads(False)
+        return out[0], aux
+
+    @staticmethod
+    def backward(ctx, go, _gaux):
+        if go is None:
+            return (None,) * 8
+        (grads,) = ctx.saved_tensors
+        b, t = ctx.bt
+        g = grads * go                                   # one launch for the three gradients
+        return g[:b], g[b:2 * b], g[2 * b:].view(ctx.sel_shape).to(ctx.sel_dtype), None, None, None, None, None
+
+
+def plain_loss_tail_ok(mse_ps, kl_ps, selection, mask):
+    return (mse_ps.is_cuda and mse_ps.dtype == torch.float32 and kl_ps.dtype == torch.float32 and mask.dtype == torch.float32
+            and mask.dim() == 2 and mask.is_contiguous() and mask.shape[0] <= 1024 and selection.numel() == mask.numel())
+
+
+def plain_loss_tail(mse_ps, kl_ps, selection, mask, hparams):
+    """-> (loss, (MSE, selection_loss, kl_loss, kept_frame_density)) of loss.loss_fn_plain from the per-sample sums."""
+    loss, aux = _PlainLossTail.apply(mse_ps, kl_ps, selection, mask, hparams["max_compression_rate"], hparams["magnify_negatives_rate"],
+                                     hparams["gamma1"], hparams["gamma2"])
+    return loss, aux.unbind(0)
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm
