@@ -94,7 +94,6 @@ def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn
 def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
     reconstruction, _comp, selection, logvar, mean = model(video, mask, rngs, train=train)
     om = original_mask.to(torch.float32)
-    sequence_lengths = torch.clamp(reduce(om, "b time -> b 1", "sum"), min=1.0)
     mse_ps, _ = ops.masked_mse_mae(video, reconstruction, om, video_div=1)
     kl_ps = kl_from_model(model, mean, logvar, om)
     if ops.plain_loss_tail_ok(mse_ps, kl_ps, selection, om):
@@ -103,6 +102,7 @@ def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
         return loss, {"MSE": MSE, "selection_loss": selection_loss, "kl_loss": kl_loss, "reconstruction": reconstruction,
                       "kept_frame_density": density}
     MSE = mse_ps.mean()
+    sequence_lengths = torch.clamp(reduce(om, "b time -> b 1", "sum"), min=1.0)
     kl_and_selection_mask = rearrange(om, "b time -> b time 1 1")
     selection_sum = reduce(selection * kl_and_selection_mask, "b time 1 1 -> b 1", "sum")
     kept_frame_density = selection_sum / sequence_lengths

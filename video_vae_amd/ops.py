@@ -1499,11 +1499,8 @@ def flush_wgrad(items, optimizer, tiles=None, k=None):
     if tiles >= GROUP_MIN_TILES:
         _gemm_tn_grouped(items, k)
     else:                                                    # too few tiles to fill the chip without splitting K
-        for x2, dy2, kernel, bias in items:
-            dw, db = gemm_tn(x2, dy2, bias is not None)
-            kernel.gview.copy_(dw)
-            if bias is not None:
-                bias.gview.copy_(db)
+        for x2, dy2, kernel, bias in items:                  # straight into the flat-buffer slots: no copies behind the product
+            gemm_tn(x2, dy2, bias is not None, kernel.gview, bias.gview if bias is not None else None)
     for _, _, kernel, bias in items:
         optimizer.mark_external(kernel)
         if bias is not None:
@@ -1534,12 +1531,14 @@ def gemm_tn_supported(a, b):
             and lib().vvae_gemm_tn_supported(a.shape[1], b.shape[1], a.shape[0], a.stride(0), b.stride(0)) == 1)
 
 
-def gemm_tn(a, b, want_colsum=True):
-    """(a^T @ b, b.sum(0)) in fp32 for bf16 token-major a (K, M), b (K, N): dW and db of a Linear layer in one pass."""
+def gemm_tn(a, b, want_colsum=True, out=None, out_colsum=None):
+    """(a^T @ b, b.sum(0)) in fp32 for bf16 token-major a (K, M), b (K, N): dW and db of a Linear layer in one pass.
+    ``out`` / ``out_colsum``: contiguous fp32 destinations (the parameters' slots of the flat gradient buffer) instead of fresh tensors."""
     k, m = a.shape
     n = b.shape[1]
-    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    db = torch.empty((n,), dtype=torch.float32, device=a.device) if want_colsum else None
+    c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
+    db = (out_colsum if out_colsum is not None else torch.empty((n,), dtype=torch.float32, device=a.device)) if want_colsum else None
+    assert c.is_contiguous() and c.dtype == torch.float32 and c.shape == (m, n)
     wsb = lib().vvae_gemm_tn_ws_bytes(m, n, k)
     ws, wsb = _ws(wsb, a.device)
     kern = ("gemm_tn256_kernel" if m % 256 == 0 and n % 256 == 0 and k % 32 == 0 else "gemm_tn_bf16_kernel") + " + gemm_tn_reduce_kernel"
