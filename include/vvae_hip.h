@@ -128,6 +128,9 @@ int vvae_silu_bf16(const void* x, void* y, long n, void* stream);
  *      (bias_dtype); res: NULL = plain Linear; ws: device scratch for the library (16-byte aligned; 0 allowed). ---- */
 int vvae_linear_residual_bf16(const void* x, int ldx, const void* w, int ldw, const void* bias, int bias_dtype, const void* res, int ldr,
                               void* y, int ldy, int M, int N, int K, void* ws, size_t ws_bytes, void* stream);
+/* The same product with the weight given as its (N, K) row-major transpose, pitch ldwt >= K (the optimizer's second bf16 shadow). */
+int vvae_linear_residual_wt_bf16(const void* x, int ldx, const void* wt, int ldwt, const void* bias, int bias_dtype, const void* res, int ldr,
+                                 void* y, int ldy, int M, int N, int K, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- PatchUnEmbedding's "b t (h w) (p1 p2 cu) -> b t (h p1) (w p2) cu" (train/layers.py:48) fused with the zero padding of the
  *      channel axis from cu to c (the multiple of 16 the conv kernels take), and its transpose.  frames = b*t; bf16; cu, c % 4 == 0. ---- */

@@ -1193,6 +1193,10 @@ def test_linear_residual_library_product(dev, m, k, n):
     wide_r = torch.zeros((m, n + 8), dtype=torch.bfloat16, device=dev); wide_r[:, :n] = rg
     assert torch.equal(ops.linear_residual(wide_x[:, :k], wg, bg, wide_r[:, :n]), y)
     assert torch.equal(ops.linear_residual(xg, wg, bg, rg), y), "bitwise reproducible"
+    y_t = ops.linear_residual(xg, wg, bg, rg, wg.t().contiguous())       # the (N, K) shadow form: another library kernel, same product
+    assert_close(y_t, ref, rtol=1e-2, atol=2e-2, what="x W + b + res, transposed weight")
+    e3 = float((y_t.double().cpu() - ref).abs().mean())
+    assert e3 <= e2 * 1.05 + 1e-6, (e3, e2)
 
 
 def test_silu_stream_kernel(dev):
@@ -1218,7 +1222,8 @@ def test_transposed_shadows_follow_the_optimizer(dev):
     m = LY.MLP(128, 320, V.Rngs(2)).to(dev)                        # 320 x 128: both dims multiples of 64, not square
     opt = optim.Optimizer(m, 1e-2)
     k = m.linear1.kernel
-    assert k.bf16_t.shape == (320, 128) and getattr(m.linear2.kernel, "bf16_t", None) is None
+    assert k.bf16_t.shape == (320, 128) and torch.equal(m.linear2.kernel.bf16_t, m.linear2.kernel.bf16.t())
+    assert getattr(m.norm.scale, "bf16_t", None) is None
     assert torch.equal(k.bf16_t, k.bf16.t())
     x = rnd((256, 128), 5, 1.0).to(dev, torch.bfloat16)
     for _ in range(2):

@@ -102,7 +102,9 @@ class _LinearBf16(torch.autograd.Function):
             ctx.set_materialize_grads(False)                        # no zero-filled gradient tensor for ``a`` in backward
             return h, a
         if res is not None:
-            return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1])).view(res.shape)
+            return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1]), wt).view(res.shape)
+        if wt is not None:                                           # the library's K-contiguous-both-sides kernel: 8 % faster on qkv
+            return torch.addmm(bb, x2, wt.t()).view(*x.shape[:-1], wb.shape[1])
         return torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1])
 
     @staticmethod
@@ -142,9 +144,10 @@ class _SiluLinearBf16(torch.autograd.Function):
         ctx.hshape = h.shape
         ctx.kparam, ctx.bparam = kernel, bias
         ctx.has_res = res is not None
+        wt = getattr(kernel, "bf16_t", None)
         if res is not None:                                          # x_skip + linear2(silu(h)): the add rides in the library product
-            return ops.linear_residual(a, wb, bb, res.reshape(-1, wb.shape[1])).view(res.shape)
-        return torch.addmm(bb, a, wb).view(*h.shape[:-1], wb.shape[1])
+            return ops.linear_residual(a, wb, bb, res.reshape(-1, wb.shape[1]), wt).view(res.shape)
+        return torch.addmm(bb, a, wb if wt is None else wt.t()).view(*h.shape[:-1], wb.shape[1])
 
     @staticmethod
     def backward(ctx, dy):
@@ -386,6 +389,7 @@ class Attention(nn.Module):
         self.num_heads = num_heads
         head_dim = qkv_features // num_heads
         self.qkv_projection = Linear(in_features, qkv_features * 3, rngs, dtype, param_dtype)
+        self.qkv_projection.kernel.want_t = True   # (out, in) bf16 shadow: the library's K-contiguous kernel for the forward product
         self.out_projection = Linear(qkv_features, in_features, rngs, dtype, param_dtype, kernel_scale=1e-2)
         self.input_norm = LayerNorm(in_features, dtype, param_dtype)
         self.ROPE = RotaryEmbedding(head_dim=head_dim, max_len=max_len)
@@ -458,6 +462,7 @@ class MLP(nn.Module):
         self.linear1 = Linear(in_features, mlp_dim, rngs, dtype, param_dtype)
         self.linear2 = Linear(mlp_dim, in_features, rngs, dtype, param_dtype, kernel_scale=1e-2)
         self.linear1.kernel.want_t = True          # the optimizer keeps an (out, in) bf16 shadow: fc1 + SiLU on the own NT GEMM
+        self.linear2.kernel.want_t = True          # fc2 + residual: the library's faster operand form (ops.linear_residual wt)
 
     def forward(self, x):
         return silu_linear(self.linear1(self.norm(x)), self.linear2)

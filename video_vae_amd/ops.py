@@ -1332,17 +1332,24 @@ def linear_residual_ok(x2, wb, bb, res):
             and x2.data_ptr() % 16 == 0 and res.data_ptr() % 16 == 0)
 
 
-def linear_residual(x2, wb, bb, res):
-    """-> x2 @ wb + bb + res (bf16, fp32 accumulation, one rounding): vvae_linear_residual_bf16.  ``res`` None = plain Linear."""
+def linear_residual(x2, wb, bb, res, wt=None):
+    """-> x2 @ wb + bb + res (bf16, fp32 accumulation, one rounding): vvae_linear_residual_bf16.  ``res`` None = plain Linear.
+    ``wt``: wb's (N, K) contiguous transpose, if the caller keeps one: the library's faster operand form (vvae_linear_residual_wt_bf16)."""
     m, k = x2.shape
     n = wb.shape[1]
     out = torch.empty((m, n), dtype=torch.bfloat16, device=x2.device)
     ws = _LT_WS.get(x2.device)
     if ws is None:
         ws = _LT_WS[x2.device] = torch.empty(32 << 20, dtype=torch.uint8, device=x2.device)
-    check(_launch(f"linear+residual {m}x{n} K{k}", (m * k + k * n + (2 if res is not None else 1) * m * n) * 2, 2 * m * n * k, "Cijk_",
-                  lambda: lib().vvae_linear_residual_bf16(_p(x2), x2.stride(0), _p(wb), n, _p(bb), 1, _p(res), res.stride(0) if res is not None else 0,
-                                                          _p(out), n, m, n, k, _p(ws), ws.numel(), _stream())), "vvae_linear_residual_bf16")
+    ldr = res.stride(0) if res is not None else 0
+    if wt is not None and wt.is_contiguous() and wt.shape == (n, k) and wt.dtype == torch.bfloat16:
+        fn = lambda: lib().vvae_linear_residual_wt_bf16(_p(x2), x2.stride(0), _p(wt), k, _p(bb), 1, _p(res), ldr, _p(out), n, m, n, k, _p(ws),
+                                                        ws.numel(), _stream())
+    else:
+        fn = lambda: lib().vvae_linear_residual_bf16(_p(x2), x2.stride(0), _p(wb), n, _p(bb), 1, _p(res), ldr, _p(out), n, m, n, k, _p(ws),
+                                                     ws.numel(), _stream())
+    check(_launch(f"linear+residual {m}x{n} K{k}", (m * k + k * n + (2 if res is not None else 1) * m * n) * 2, 2 * m * n * k, "Cijk_", fn),
+          "vvae_linear_residual_bf16")
     return out
 
 
