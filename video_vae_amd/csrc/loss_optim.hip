@@ -670,13 +670,15 @@ extern "C" int vvae_silu_bf16(const void* x, void* y, long n, void* stream)
 namespace {
 constexpr int TR_MAX = 64;
 struct TrEntry { const bf16_t* src; bf16_t* dst; int rows, cols, tiles_c, tile_start; };
-struct TrArgs { TrEntry e[TR_MAX]; int n; };
+// start[] apart from the entries: the search for a workgroup's matrix is then four wide scalar loads, not 63 dependent ones
+struct TrArgs { int start[TR_MAX]; TrEntry e[TR_MAX]; int n; };
 
 __global__ __launch_bounds__(256) void transpose_grouped_kernel(TrArgs g)
 {
     __shared__ bf16_t tile[64][64 + 8];
     int ei = 0;
-    for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].tile_start ? i : ei;
+#pragma unroll
+    for (int i = 1; i < TR_MAX; ++i) ei += (int)blockIdx.x >= g.start[i] ? 1 : 0;     // start[] is non-decreasing, INT_MAX behind n
     const TrEntry& E = g.e[ei];
     const int t = blockIdx.x - E.tile_start;
     const int r0 = (t / E.tiles_c) * 64, c0 = (t % E.tiles_c) * 64;
@@ -710,8 +712,10 @@ extern "C" int vvae_transpose_grouped_bf16(const void* const* src, void* const* 
         if (!src[i] || !dst[i] || rows[i] <= 0 || cols[i] <= 0 || rows[i] % 64 || cols[i] % 64 || ((uintptr_t)src[i] % 16) || ((uintptr_t)dst[i] % 16))
             return VVAE_ERR_BAD_ARG;
         g.e[i] = TrEntry{(const bf16_t*)src[i], (bf16_t*)dst[i], rows[i], cols[i], cols[i] / 64, tiles};
+        g.start[i] = tiles;
         tiles += (rows[i] / 64) * (cols[i] / 64);
     }
+    for (int i = n; i < TR_MAX; ++i) g.start[i] = 0x7fffffff;
     hipLaunchKernelGGL(transpose_grouped_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, g);
     VVAE_LAUNCH_CHECK();
     return 0;
