@@ -14,7 +14,7 @@
  *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
  *   - process-global mutable state is limited to test / tuning hooks, none of which the product path calls:
  *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config, vvae_layernorm_fwd_mode,
- *     vvae_gemm_tn_use_big_tiles, vvae_temporal_attn_mfma_enable, vvae_temporal_attn_mfma32_enable (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 keeps the
+ *     vvae_gemm_tn_use_big_tiles, vvae_temporal_attn_mfma_enable, vvae_temporal_attn_mfma32_enable (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 / vvae_linear_residual_wt_bf16 keep the
  *     hipBLASLt handle and the solution the library's heuristic chose per (shape, pitches) behind a mutex; everything else is a pure function of its arguments.
  */
 #ifndef VVAE_HIP_H
