@@ -39,7 +39,7 @@ constexpr int ROWB = BK * 2;
 
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SILU = 2, EPI_MUL_DSILU = 3 };
 
-struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi; };
+struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi, stagger; };
 
 template <int BM_, int BN_, int WM_, int WN_>
 struct NtCfg {
@@ -83,6 +83,13 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     int t0 = blockIdx.x;
     if ((ntiles & 7) == 0) t0 = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
     const int m0 = (t0 / tn_count) * C::BM, n0 = (t0 % tn_count) * C::BN;
+    // Start-time stagger (OFF by default, vvae_gemm_nt_stagger): every other workgroup of an XCD (of the first round) sleeps
+    // d.stagger x 2048 cycles before its first load.  As a graph of 20 back-to-back launches two cohorts ~2 us apart measured 55.9 -> 47.4 us
+    // on the plain 16384 x 1536 x 768 product and 59.5 -> 53.1 with the SiLU pair of outputs (tools/nt_stagger_probe.py) -- but inside the
+    // train step, between LayerNorm and attention kernels, the same setting changes nothing (35.43 vs 35.48 ms per step, tools/ab_hook.py):
+    // back-to-back copies of one GEMM are not the condition the kernel runs in.
+    if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < d.stagger; ++i) __builtin_amdgcn_s_sleep(32);
 
     // ---- staging: a DMA piece = 8 rows x 128 bytes; lane -> row lane >> 3, slot lane & 7; the slot holds source chunk
     //      slot ^ ((row >> 1) & 7).  Wave w issues A pieces w*PA .. and B pieces w*PB ..
@@ -239,6 +246,8 @@ inline int nt_pick(int M, int N, int K)
     return 0;
 }
 
+int g_nt_stagger = 0;
+
 template <typename C>
 int launch_nt(const void* A, const void* B, void* Cout, const float* bias, const void* res, void* C2, const NtDims& d, hipStream_t s)
 {
@@ -258,6 +267,14 @@ int launch_nt(const void* A, const void* B, void* Cout, const float* bias, const
 
 }  // namespace
 
+// Test / tuning hook: the start-time stagger of vvae_gemm_nt_bf16 in units of 2048 cycles (default 0 = every workgroup starts at once).
+extern "C" int vvae_gemm_nt_stagger(int units)
+{
+    if (units < 0 || units > 64) return VVAE_ERR_BAD_ARG;
+    g_nt_stagger = units;
+    return 0;
+}
+
 // 1 if vvae_gemm_nt_bf16 takes this shape (M % 256 == 0, K % 64 == 0, N % 192 == 0 or N % 128 == 0, 16-byte aligned pitches).
 extern "C" int vvae_gemm_nt_supported(int M, int N, int K, int lda, int ldb, int ldc)
 {
@@ -274,7 +291,7 @@ extern "C" int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
         ((uintptr_t)B % 16) || ((uintptr_t)C % 16)) return VVAE_ERR_BAD_ARG;
     if ((epi == EPI_RES || epi == EPI_MUL_DSILU) && (!res || ldr % 8 || ldr < N || ((uintptr_t)res % 16))) return VVAE_ERR_BAD_ARG;
     if (epi == EPI_SILU && (!C2 || ldc2 % 8 || ldc2 < N || ((uintptr_t)C2 % 16))) return VVAE_ERR_BAD_ARG;
-    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi};
+    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, g_nt_stagger};
     hipStream_t s = (hipStream_t)stream;
     if (nt_pick(M, N, K) == 192) return launch_nt<Nt192>(A, B, C, bias, res, C2, d, s);
     return launch_nt<Nt128>(A, B, C, bias, res, C2, d, s);

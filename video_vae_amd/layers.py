@@ -94,6 +94,7 @@ class _LinearBf16(torch.autograd.Function):
         ctx.has_res = res is not None
         ctx.two = bool(with_silu)
         wt = getattr(kernel, "bf16_t", None)                         # (out, in) shadow: the own NT GEMM's operand (optim.Optimizer)
+        wl = wt if WT_LIBRARY else None
         if with_silu:
             # -> (h, silu(h)) from ONE product (ops.gemm_nt, EPI_SILU): the activation between the MLP's Linear layers costs no pass
             a, h = ops.gemm_nt(x2, wt, bias.detach(), None, ops.EPI_SILU)
@@ -102,9 +103,9 @@ class _LinearBf16(torch.autograd.Function):
             ctx.set_materialize_grads(False)                        # no zero-filled gradient tensor for ``a`` in backward
             return h, a
         if res is not None:
-            return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1]), wt).view(res.shape)
-        if wt is not None:                                           # the library's K-contiguous-both-sides kernel: 8 % faster on qkv
-            return torch.addmm(bb, x2, wt.t()).view(*x.shape[:-1], wb.shape[1])
+            return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1]), wl).view(res.shape)
+        if wl is not None:                                           # the library's K-contiguous-both-sides kernel: 8 % faster on qkv
+            return torch.addmm(bb, x2, wl.t()).view(*x.shape[:-1], wb.shape[1])
         return torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1])
 
     @staticmethod
@@ -144,7 +145,7 @@ class _SiluLinearBf16(torch.autograd.Function):
         ctx.hshape = h.shape
         ctx.kparam, ctx.bparam = kernel, bias
         ctx.has_res = res is not None
-        wt = getattr(kernel, "bf16_t", None)
+        wt = getattr(kernel, "bf16_t", None) if WT_LIBRARY else None
         if res is not None:                                          # x_skip + linear2(silu(h)): the add rides in the library product
             return ops.linear_residual(a, wb, bb, res.reshape(-1, wb.shape[1]), wt).view(res.shape)
         return torch.addmm(bb, a, wb if wt is None else wt.t()).view(*h.shape[:-1], wb.shape[1])
@@ -188,10 +189,14 @@ def silu_linear(h, linear):
     return linear(F.silu(h))
 
 
+NT_SILU = 1            # fc1 + SiLU as one own NT product (0: library product + SiLU stream kernel); a switch for tools/ab_hook.py
+WT_LIBRARY = 1         # qkv / fc2 on the library's K-contiguous kernels through the transposed shadows (0: the (in, out) operand)
+
+
 def nt_silu_ok(linear, x):
     """linear(x) and silu(linear(x)) can come out of one product of the own NT GEMM (needs the (out, in) weight shadow)."""
     wt = getattr(linear.kernel, "bf16_t", None)
-    return (_shadowed(linear, x) and wt is not None and linear.bias.dtype == torch.float32
+    return (NT_SILU and _shadowed(linear, x) and wt is not None and linear.bias.dtype == torch.float32
             and ops.gemm_nt_supported(x.reshape(-1, x.shape[-1]), wt))
 
 
