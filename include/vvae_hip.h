@@ -14,7 +14,7 @@
  *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
  *   - process-global mutable state is limited to test / tuning hooks, none of which the product path calls:
  *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config, vvae_layernorm_fwd_mode,
- *     vvae_gemm_tn_use_big_tiles, vvae_gemm_nt_stagger, vvae_temporal_attn_mfma_enable, vvae_temporal_attn_mfma32_enable (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 / vvae_linear_residual_wt_bf16 keep the
+ *     vvae_gemm_tn_use_big_tiles, vvae_gemm_nt_stagger, vvae_linear_residual_algo, vvae_temporal_attn_mfma_enable, vvae_temporal_attn_mfma32_enable (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 / vvae_linear_residual_wt_bf16 keep the
  *     hipBLASLt handle and the solution the library's heuristic chose per (shape, pitches) behind a mutex; everything else is a pure function of its arguments.
  */
 #ifndef VVAE_HIP_H
@@ -131,6 +131,8 @@ int vvae_linear_residual_bf16(const void* x, int ldx, const void* w, int ldw, co
 /* The same product with the weight given as its (N, K) row-major transpose, pitch ldwt >= K (the optimizer's second bf16 shadow). */
 int vvae_linear_residual_wt_bf16(const void* x, int ldx, const void* wt, int ldwt, const void* bias, int bias_dtype, const void* res, int ldr,
                                  void* y, int ldy, int M, int N, int K, void* ws, size_t ws_bytes, void* stream);
+/* Test / tuning hook: new plans take the idx-th solution of the library's ranked list (0 = default). */
+int vvae_linear_residual_algo(int idx);
 
 /* ---- PatchUnEmbedding's "b t (h w) (p1 p2 cu) -> b t (h p1) (w p2) cu" (train/layers.py:48) fused with the zero padding of the
  *      channel axis from cu to c (the multiple of 16 the conv kernels take), and its transpose.  frames = b*t; bf16; cu, c % 4 == 0. ---- */

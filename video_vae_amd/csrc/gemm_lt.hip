@@ -23,6 +23,7 @@ typedef std::tuple<int, int, int, int, int, int, int, int, int, int, size_t> LtK
 hipblasLtHandle_t g_lt = nullptr;
 std::mutex g_lt_mu;
 std::map<LtKey, LtPlan> g_lt_plans;
+int g_lt_algo = 0;              // which of the heuristic's ranked solutions new plans take (vvae_linear_residual_algo)
 
 #define LT_OK(call) do { if ((call) != HIPBLAS_STATUS_SUCCESS) return VVAE_ERR_LIBRARY; } while (0)
 
@@ -53,12 +54,13 @@ int lt_plan(const LtKey& key, int M, int N, int K, int ldx, int ldw, int ldr, in
     hipblasLtMatmulPreference_t pref = nullptr;
     LT_OK(hipblasLtMatmulPreferenceCreate(&pref));
     LT_OK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes)));
-    hipblasLtMatmulHeuristicResult_t res[1];
+    hipblasLtMatmulHeuristicResult_t res[16];
     int found = 0;
-    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.ld, pref, 1, res, &found);
+    const int want = g_lt_algo < 0 ? 1 : (g_lt_algo > 15 ? 16 : g_lt_algo + 1);
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.ld, pref, want, res, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) return VVAE_ERR_LIBRARY;
-    p.algo = res[0].algo;
+    p.algo = res[found >= want ? want - 1 : found - 1].algo;          // the library's first choice unless the tuning hook asks further down
     *out = &g_lt_plans.emplace(key, p).first->second;
     return 0;
 }
@@ -101,4 +103,15 @@ extern "C" int vvae_linear_residual_wt_bf16(const void* x, int ldx, const void* 
                                             void* stream)
 {
     return linear_residual(x, ldx, wt, ldwt, true, bias, bias_dtype, res, ldr, y, ldy, M, N, K, ws, ws_bytes, stream);
+}
+
+// Test / tuning hook: plans made from now on take the idx-th solution of the library's ranked list (0 = its first choice, the default); cached
+// plans are dropped.
+extern "C" int vvae_linear_residual_algo(int idx)
+{
+    if (idx < 0 || idx > 15) return VVAE_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(g_lt_mu);
+    g_lt_algo = idx;
+    g_lt_plans.clear();                                             // descriptors of dropped plans are a bounded leak of a test hook
+    return 0;
 }
