@@ -735,7 +735,10 @@ def test_conv_pointwise_stream_kernels(dev, cin, dtype, shape):
     assert_close_scaled(db, db_gen, rel=2e-4, floor=1e-6, what="db vs generic")
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 192, 64), (512, 768, 512), (256, 128, 128), (1024, 1536, 768), (256, 512, 192)])
+@pytest.mark.parametrize("m,n,k", [(256, 192, 64), (512, 768, 512), (256, 128, 128), (1024, 1536, 768), (256, 512, 192),
+                                   # more than 256 tiles: persistent workgroups walk 2 (production shape), 3 and 2 (128-wide) tiles,
+                                   # the shortest even K (next tile requested in k-step 1 of 2), and an odd K (one tile per workgroup)
+                                   (16384, 1536, 768), (16384, 2304, 256), (16384, 1024, 256), (8192, 3072, 128), (16384, 1536, 192)])
 def test_gemm_nt_linear_forms(dev, m, n, k):
     """C = epi(A B^T + bias) (LDS-DMA ring NT GEMM) vs fp32 torch: plain, + residual, SiLU (+ saved pre-activation) and
     * silu'(h); the fused tails act on the bf16-rounded linear output, i.e. equal Linear followed by the separate op."""
@@ -760,6 +763,15 @@ def test_gemm_nt_linear_forms(dev, m, n, k):
     sg = torch.sigmoid(res.float())
     assert_close(c3, base.float() * (sg * (1 + res.float() * (1 - sg))), rtol=1e-2, atol=1e-2, what="dsilu")
     assert torch.equal(c, ops.gemm_nt(a, b, bias)), "deterministic"
+    if m * n > 256 * 256 * 192:                                    # persistent launch form == one tile per workgroup, bit for bit
+        from video_vae_amd._lib import lib
+        assert lib().vvae_gemm_nt_persistent(0) == 0
+        try:
+            assert torch.equal(c, ops.gemm_nt(a, b, bias)) and torch.equal(c3, ops.gemm_nt(a, b, None, res, ops.EPI_MUL_DSILU))
+            c2n, hn = ops.gemm_nt(a, b, bias, None, ops.EPI_SILU)
+            assert torch.equal(c2, c2n) and torch.equal(h, hn) and torch.equal(c1, ops.gemm_nt(a, b, bias, res, ops.EPI_RES))
+        finally:
+            lib().vvae_gemm_nt_persistent(1)
 
 
 @pytest.mark.parametrize("ci,co,shape", [(32, 16, (2, 3, 6, 10)), (64, 32, (1, 2, 5, 7)), (128, 64, (1, 2, 4, 8))])

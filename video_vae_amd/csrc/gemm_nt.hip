@@ -39,7 +39,7 @@ constexpr int ROWB = BK * 2;
 
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SILU = 2, EPI_MUL_DSILU = 3 };
 
-struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi, stagger; };
+struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi, stagger, tiles; };
 
 template <int BM_, int BN_, int WM_, int WN_>
 struct NtCfg {
@@ -49,7 +49,7 @@ struct NtCfg {
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     static constexpr int PA = BM / 8 / NWAVES, PB = BN / 8 / NWAVES;   // 1 KiB DMA pieces (8 rows) per wave and tile
     static constexpr int CP = BN * 2 + 16;                      // epilogue image row pitch (bytes)
-    static constexpr int LDS = 2 * STAGE > BM * CP ? 2 * STAGE : BM * CP;
+    static constexpr int LDS = 2 * STAGE;                       // the C image of a half tile reuses stage 1
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0 && NWAVES == 8, "tile / wave layout");
     static_assert((BN * 2 / 16) * BM % NT == 0 && LDS <= 160 * 1024, "epilogue chunks per thread / LDS");
 };
@@ -67,7 +67,18 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // d/dx silu(x) = s (1 + x (1 - s)), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
 
-template <typename C>
+template <int N_>
+__device__ __forceinline__ void wait_vm()                       // s_waitcnt vmcnt(N_) only: at most the N_ youngest vector-memory ops outstanding
+{
+    static_assert(N_ >= 0 && N_ < 64, "vmcnt is six bits");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N_ & 15) | ((N_ >> 4) << 14));
+}
+
+// PERSISTENT over the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the launch takes min(tiles, 256) workgroups): at N = 1536 every CU
+// multiplies two tiles, and what used to lie between them -- the first tile's stores draining before its workgroup could retire, the launch
+// of the next workgroup, the first DMA of its operands, ~8 us of a ~60 us product -- now overlaps: the next tile's first k-tile is requested
+// in the current tile's last k-step, and the current tile's stores drain under the next tile's main loop.
+template <typename C, int EPI>
 __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ Cout,
                                                            const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                            bf16_t* __restrict__ C2, NtDims d)
@@ -79,32 +90,32 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     // XCD-aware tile map: blockIdx round-robins over the 8 XCDs; give each XCD a contiguous run of tiles (n fastest), so the
     // tiles that share an A row panel hit the same L2
     const int tn_count = d.N / C::BN;
-    const int ntiles = gridDim.x;
-    int t0 = blockIdx.x;
-    if ((ntiles & 7) == 0) t0 = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
-    const int m0 = (t0 / tn_count) * C::BM, n0 = (t0 % tn_count) * C::BN;
-    // Start-time stagger (OFF by default, vvae_gemm_nt_stagger): every other workgroup of an XCD (of the first round) sleeps
-    // d.stagger x 2048 cycles before its first load.  As a graph of 20 back-to-back launches two cohorts ~2 us apart measured 55.9 -> 47.4 us
-    // on the plain 16384 x 1536 x 768 product and 59.5 -> 53.1 with the SiLU pair of outputs (tools/nt_stagger_probe.py) -- but inside the
-    // train step, between LayerNorm and attention kernels, the same setting changes nothing (35.43 vs 35.48 ms per step, tools/ab_hook.py):
-    // back-to-back copies of one GEMM are not the condition the kernel runs in.
-    if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
-        for (int i = 0; i < d.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    const int ntiles = d.tiles;
+    auto origin = [&](int b, int& m0, int& n0) {
+        int t0 = b;
+        if ((ntiles & 7) == 0) t0 = (b & 7) * (ntiles >> 3) + (b >> 3);
+        m0 = (t0 / tn_count) * C::BM;
+        n0 = (t0 % tn_count) * C::BN;
+    };
 
     // ---- staging: a DMA piece = 8 rows x 128 bytes; lane -> row lane >> 3, slot lane & 7; the slot holds source chunk
     //      slot ^ ((row >> 1) & 7).  Wave w issues A pieces w*PA .. and B pieces w*PB ..
     const bf16_t* ga[C::PA];
     const bf16_t* gb[C::PB];
+    auto setup = [&](int m0, int n0) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));              // recomputed per tile: hoisted out of the tile loop these 14 offsets were spilled
 #pragma unroll
-    for (int i = 0; i < C::PA; ++i) {
-        const int row = (wave * C::PA + i) * 8 + (lane >> 3);
-        ga[i] = A + (long)(m0 + row) * d.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
-    }
+        for (int i = 0; i < C::PA; ++i) {
+            const int row = (wave * C::PA + i) * 8 + (ln >> 3);
+            ga[i] = A + (long)(m0 + row) * d.lda + (((ln & 7) ^ ((row >> 1) & 7)) << 3);
+        }
 #pragma unroll
-    for (int i = 0; i < C::PB; ++i) {
-        const int row = (wave * C::PB + i) * 8 + (lane >> 3);
-        gb[i] = B + (long)(n0 + row) * d.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
-    }
+        for (int i = 0; i < C::PB; ++i) {
+            const int row = (wave * C::PB + i) * 8 + (ln >> 3);
+            gb[i] = B + (long)(n0 + row) * d.ldb + (((ln & 7) ^ ((row >> 1) & 7)) << 3);
+        }
+    };
     auto issue = [&](int kt, int stage) {
         unsigned char* sb = smem + stage * C::STAGE;
         const int k0 = kt * BK;
@@ -113,6 +124,14 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < C::PB; ++i) glds16(gb[i] + k0, sb + C::A_BYTES + (wave * C::PB + i) * 1024);
     };
+
+    // Start-time stagger (OFF by default, vvae_gemm_nt_stagger): every other workgroup of an XCD sleeps
+    // d.stagger x 2048 cycles before its first load.  As a graph of 20 back-to-back launches two cohorts ~2 us apart measured 55.9 -> 47.4 us
+    // on the plain 16384 x 1536 x 768 product and 59.5 -> 53.1 with the SiLU pair of outputs (tools/nt_stagger_probe.py) -- but inside the
+    // train step, between LayerNorm and attention kernels, the same setting changes nothing (35.43 vs 35.48 ms per step, tools/ab_hook.py):
+    // back-to-back copies of one GEMM are not the condition the kernel runs in.
+    if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < d.stagger; ++i) __builtin_amdgcn_s_sleep(32);
 
     // ---- fragment reads for v_mfma_f32_16x16x32_bf16: 16 rows x 32 k per ds_read_b128; lane (row = lane & 15, k-group kg = lane >> 4).
     //      (Round 1 multiplied with 32x32x16: same LDS bytes and cycles per FLOP, lower sustained clock on random data.)
@@ -123,115 +142,163 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     for (int ks = 0; ks < 2; ++ks) koff[ks] = ((4 * ks + kg) ^ sw) << 4;
     const int a_row = (wm * C::WTM + fr) * ROWB;                  // token rows of this wave (MFMA column operand)
     const int b_row = C::A_BYTES + (wn * C::WTN + fr) * ROWB;     // weight rows (MFMA row operand)
-
-    f32x4 acc[NB16][MB16];
-#pragma unroll
-    for (int i = 0; i < NB16; ++i)
-#pragma unroll
-        for (int j = 0; j < MB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = d.K / BK;
-    issue(0, 0);
-    wait_vm0();
-    __builtin_amdgcn_s_barrier();             // tile 0 visible to all
-    if (grp) {
-        if (nk > 1) issue(1, 1);              // this half's pieces of tile 1 (the other half issues its own in L0)
-        __builtin_amdgcn_s_barrier();         // the stagger
-    }
-    for (int t = 0; t < nk; ++t) {
-        const unsigned char* cur = smem + (t & 1) * C::STAGE;
-        // ---- L_t
-        bf16x8 tf[2][MB16], wf[2][NB16];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int j = 0; j < MB16; ++j) tf[ks][j] = *reinterpret_cast<const bf16x8*>(cur + a_row + j * 16 * ROWB + koff[ks]);
-#pragma unroll
-            for (int i = 0; i < NB16; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + b_row + i * 16 * ROWB + koff[ks]);
-        }
-        if (!grp) { if (t + 1 < nk) issue(t + 1, (t + 1) & 1); }
-        else wait_vm0();                      // waves 4-7: their pieces of tile t+1 (issued a step ago) have landed
-        __builtin_amdgcn_s_barrier();
-        // ---- C_t
-        if (grp && t + 2 < nk) issue(t + 2, t & 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < NB16; ++i)
-#pragma unroll
-                for (int j = 0; j < MB16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
-        if (!grp) wait_vm0();                 // waves 0-3: their pieces of tile t+1 have landed
-        __builtin_amdgcn_s_barrier();
-    }
-    if (!grp) __builtin_amdgcn_s_barrier();
-    __syncthreads();                          // every wave is done with the operand buffers: reuse them for the C image
-
-    // the second operand of the tail (residual / saved pre-activation) does not depend on the product: request this thread's
-    // chunks now, so they arrive while the accumulators are parked in LDS (they were three exposed memory latencies per tile)
     constexpr int CPR = C::BN * 2 / 16;                          // 16-byte chunks per row of the C tile
-    constexpr int NIT = C::BM * CPR / C::NT;                     // chunks per thread
-    const bool has_res = d.epi == EPI_RES || d.epi == EPI_MUL_DSILU;
-    uint4 rpre[NIT];
-    if (has_res) {
+    constexpr int NIT = C::BM * CPR / C::NT;                     // chunks per thread and tile
+    constexpr int HIT = NIT / 2;                                 // ... and half tile
+    static_assert(C::WM == 4 && C::BM == 256 && NIT % 2 == 0 && (C::BM / 2) * C::CP <= C::STAGE, "half-tile C image behind stage 0");
+    unsigned char* img = smem + C::STAGE;                        // the C image of a HALF tile (128 rows) lives in stage 1's bytes
+    constexpr bool has_res = EPI == EPI_RES || EPI == EPI_MUL_DSILU;
+    const int nk = d.K / BK;
+
+    int tb = blockIdx.x, m0, n0;
+    origin(tb, m0, n0);
+    setup(m0, n0);
+    issue(0, 0);
+    bool first = true;
+    while (true) {
+        const int nb = tb + (int)gridDim.x;
+        const bool more = nb < ntiles;
+        int nm0 = 0, nn0 = 0;
+        if (more) origin(nb, nm0, nn0);
+        f32x4 acc[NB16][MB16];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int q = tid + it * C::NT;
-            rpre[it] = *reinterpret_cast<const uint4*>(res + (long)(m0 + q / CPR) * d.ldr + n0 + (q % CPR) * 8);
+        for (int i = 0; i < NB16; ++i)
+#pragma unroll
+            for (int j = 0; j < MB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // k-tile 0 of this tile has landed.  After the first tile it was requested during the previous tile's last k-step, ahead of
+        // that tile's stores: those (NIT per thread, twice that with the SiLU pair) may stay in flight.
+        if (first) wait_vm0();
+        else wait_vm<(EPI == EPI_SILU ? 2 : 1) * NIT>();
+        __builtin_amdgcn_s_barrier();             // tile 0 visible to all; every wave is done with the C image
+        if (grp) {
+            if (nk > 1) issue(1, 1);              // this half's pieces of tile 1 (the other half issues its own in L0)
+            __builtin_amdgcn_s_barrier();         // the stagger
         }
-    }
-    // ---- epilogue pass 1: acc (+bias) -> bf16 image [BM][BN], pitch CP.  acc[i][j][r]: channel 16 i + 4 kg + r, token 16 j + fr
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* cur = smem + (t & 1) * C::STAGE;
+            // ---- L_t
+            bf16x8 tf[2][MB16], wf[2][NB16];
 #pragma unroll
-    for (int i = 0; i < NB16; ++i) {
-        const int n = wn * C::WTN + i * 16 + kg * 4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) { const float* bp = bias + n0 + n; bv = make_float4(bp[0], bp[1], bp[2], bp[3]); }
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < MB16; ++j) {
-            const int m = wm * C::WTM + j * 16 + fr;
-            uint2 pk;
-            pk.x = (uint32_t)f2bf(acc[i][j][0] + bv.x) | ((uint32_t)f2bf(acc[i][j][1] + bv.y) << 16);
-            pk.y = (uint32_t)f2bf(acc[i][j][2] + bv.z) | ((uint32_t)f2bf(acc[i][j][3] + bv.w) << 16);
-            *reinterpret_cast<uint2*>(smem + m * C::CP + n * 2) = pk;
+                for (int j = 0; j < MB16; ++j) tf[ks][j] = *reinterpret_cast<const bf16x8*>(cur + a_row + j * 16 * ROWB + koff[ks]);
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + b_row + i * 16 * ROWB + koff[ks]);
+            }
+            // the last k-step has nothing of this tile left to request: the NEXT tile's first k-tile goes out instead (nk is even, so
+            // it lands in stage 0, free since k-step nk - 2), a k-step and the whole epilogue ahead of its first use
+            const bool ahead = more && t + 1 == nk;
+            if (!grp) {
+                if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+                else if (ahead) { setup(nm0, nn0); issue(0, 0); }
+            } else wait_vm0();                    // waves 4-7: their pieces of tile t+1 (issued a step ago) have landed
+            __builtin_amdgcn_s_barrier();
+            // ---- C_t
+            if (grp) {
+                if (t + 2 < nk) issue(t + 2, t & 1);
+                else if (ahead) { setup(nm0, nn0); issue(0, 0); }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < NB16; ++i)
+#pragma unroll
+                    for (int j = 0; j < MB16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
+            if (!grp && t + 1 < nk) wait_vm0();   // waves 0-3: their pieces of tile t+1 have landed
+            __builtin_amdgcn_s_barrier();
         }
-    }
-    __syncthreads();
-    // ---- epilogue pass 2: coalesced 16-byte rows, fused elementwise tail on the ROUNDED linear output
+        if (!grp) __builtin_amdgcn_s_barrier();
+        __syncthreads();                          // every wave is done with the operand buffers
+
+        // ---- acc (+bias) -> packed bf16, in registers (48 instead of 96: the half of the waves that parks second holds them through the
+        //      first half's stores).  acc[i][j][r]: channel 16 i + 4 kg + r, token 16 j + fr
+        uint2 pk[NB16][MB16];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int q = tid + it * C::NT;
-        const int row = q / CPR, cc = q % CPR;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + row * C::CP + cc * 16);
-        const long gm = m0 + row;
-        const int gn = n0 + cc * 8;
-        if (d.epi != EPI_NONE) {
-            float x[8];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int i = 0; i < NB16; ++i) {
+            const int n = wn * C::WTN + i * 16 + kg * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) { const float* bp = bias + n0 + n; bv = make_float4(bp[0], bp[1], bp[2], bp[3]); }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
-            float y[8];
-            if (d.epi == EPI_SILU) {
-                *reinterpret_cast<uint4*>(C2 + gm * d.ldc2 + gn) = v;         // pre-activation, kept for backward
+            for (int j = 0; j < MB16; ++j) {
+                pk[i][j].x = (uint32_t)f2bf(acc[i][j][0] + bv.x) | ((uint32_t)f2bf(acc[i][j][1] + bv.y) << 16);
+                pk[i][j].y = (uint32_t)f2bf(acc[i][j][2] + bv.z) | ((uint32_t)f2bf(acc[i][j][3] + bv.w) << 16);
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
-            } else {
-                float r[8];
-                {
-                    const uint32_t rw[4] = {rpre[it].x, rpre[it].y, rpre[it].z, rpre[it].w};
+        for (int h = 0; h < 2; ++h) {
+            // the second operand of the tail (residual / saved pre-activation) does not depend on the product: request this half's
+            // chunks now, so they arrive while the image is written (they were three exposed memory latencies per tile)
+            uint4 rpre[HIT];
+            if (has_res) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { r[2 * e] = __uint_as_float(rw[e] << 16); r[2 * e + 1] = __uint_as_float(rw[e] & 0xffff0000u); }
-                }
-                if (d.epi == EPI_RES) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = x[e] + r[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = x[e] * dsilu_f(r[e]);
+                for (int it = 0; it < HIT; ++it) {
+                    const int q = tid + it * C::NT;
+                    rpre[it] = *reinterpret_cast<const uint4*>(res + (long)(m0 + 128 * h + q / CPR) * d.ldr + n0 + (q % CPR) * 8);
                 }
             }
-            VecIO<bf16_t, 8>::store(Cout + gm * d.ldc + gn, y);
-        } else {
-            *reinterpret_cast<uint4*>(Cout + gm * d.ldc + gn) = v;
+            // ---- pass 1: the waves that own rows [128 h, 128 h + 128) -> bf16 image [128][BN], pitch CP
+            if ((wm >> 1) == h) {
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) {
+                    const int n = wn * C::WTN + i * 16 + kg * 4;
+#pragma unroll
+                    for (int j = 0; j < MB16; ++j) {
+                        const int m = (wm & 1) * C::WTM + j * 16 + fr;
+                        *reinterpret_cast<uint2*>(img + m * C::CP + n * 2) = pk[i][j];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- pass 2: coalesced 16-byte rows, fused elementwise tail on the ROUNDED linear output
+            uint4 v[HIT];
+#pragma unroll
+            for (int it = 0; it < HIT; ++it) {
+                const int q = tid + it * C::NT;
+                v[it] = *reinterpret_cast<const uint4*>(img + (q / CPR) * C::CP + (q % CPR) * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < HIT; ++it) {
+                const int q = tid + it * C::NT;
+                const int row = 128 * h + q / CPR, cc = q % CPR;
+                const long gm = m0 + row;
+                const int gn = n0 + cc * 8;
+                if (EPI != EPI_NONE) {
+                    float x[8];
+                    const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+                    float y[8];
+                    if (EPI == EPI_SILU) {
+                        *reinterpret_cast<uint4*>(C2 + gm * d.ldc2 + gn) = v[it];     // pre-activation, kept for backward
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
+                    } else {
+                        float r[8];
+                        {
+                            const uint4 rp = rpre[it];
+                            const uint32_t rw[4] = {rp.x, rp.y, rp.z, rp.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { r[2 * e] = __uint_as_float(rw[e] << 16); r[2 * e + 1] = __uint_as_float(rw[e] & 0xffff0000u); }
+                        }
+                        if (EPI == EPI_RES) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) y[e] = x[e] + r[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) y[e] = x[e] * dsilu_f(r[e]);
+                        }
+                    }
+                    VecIO<bf16_t, 8>::store(Cout + gm * d.ldc + gn, y);
+                } else {
+                    *reinterpret_cast<uint4*>(Cout + gm * d.ldc + gn) = v[it];
+                }
+            }
+            if (h == 0) __syncthreads();          // the image is read before the second half overwrites it
         }
+        if (!more) break;
+        tb = nb; m0 = nm0; n0 = nn0;
+        first = false;
     }
 }
 
@@ -246,12 +313,12 @@ inline int nt_pick(int M, int N, int K)
     return 0;
 }
 
-int g_nt_stagger = 0;
+int g_nt_stagger = 0, g_nt_persistent = 1;
 
-template <typename C>
-int launch_nt(const void* A, const void* B, void* Cout, const float* bias, const void* res, void* C2, const NtDims& d, hipStream_t s)
+template <typename C, int EPI>
+int launch_nt_epi(const void* A, const void* B, void* Cout, const float* bias, const void* res, void* C2, const NtDims& d, hipStream_t s)
 {
-    auto k = gemm_nt_kernel<C>;
+    auto k = gemm_nt_kernel<C, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
@@ -259,10 +326,27 @@ int launch_nt(const void* A, const void* B, void* Cout, const float* bias, const
         attr_done = true;
     }
     const int tiles = (d.M / C::BM) * (d.N / C::BN);
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(C::NT), C::LDS, s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)Cout, bias, (const bf16_t*)res,
-                       (bf16_t*)C2, d);
+    NtDims dd = d;
+    dd.tiles = tiles;
+    // persistent: one workgroup per CU walks tiles b, b + 256, ... -- when they divide evenly (else one tile per workgroup, as before)
+    //             and K is an even number of k-tiles (the next tile's first k-tile is requested into stage 0 during k-step nk - 1)
+    const int grid = (g_nt_persistent && tiles > 256 && tiles % 256 == 0 && (d.K / BK) % 2 == 0) ? 256 : tiles;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::NT), C::LDS, s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)Cout, bias, (const bf16_t*)res,
+                       (bf16_t*)C2, dd);
     VVAE_LAUNCH_CHECK();
     return 0;
+}
+
+// the epilogue kind is a template parameter: straight-line tails, so the compiler's own s_waitcnt are counted ones
+template <typename C>
+int launch_nt(const void* A, const void* B, void* Cout, const float* bias, const void* res, void* C2, const NtDims& d, hipStream_t s)
+{
+    switch (d.epi) {
+    case EPI_NONE: return launch_nt_epi<C, EPI_NONE>(A, B, Cout, bias, res, C2, d, s);
+    case EPI_RES: return launch_nt_epi<C, EPI_RES>(A, B, Cout, bias, res, C2, d, s);
+    case EPI_SILU: return launch_nt_epi<C, EPI_SILU>(A, B, Cout, bias, res, C2, d, s);
+    default: return launch_nt_epi<C, EPI_MUL_DSILU>(A, B, Cout, bias, res, C2, d, s);
+    }
 }
 
 }  // namespace
@@ -272,6 +356,13 @@ extern "C" int vvae_gemm_nt_stagger(int units)
 {
     if (units < 0 || units > 64) return VVAE_ERR_BAD_ARG;
     g_nt_stagger = units;
+    return 0;
+}
+
+// Test / tuning hook: 0 = one tile per workgroup (round 1's launch form), 1 = persistent workgroups (default).
+extern "C" int vvae_gemm_nt_persistent(int on)
+{
+    g_nt_persistent = on ? 1 : 0;
     return 0;
 }
 
@@ -291,7 +382,7 @@ extern "C" int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
         ((uintptr_t)B % 16) || ((uintptr_t)C % 16)) return VVAE_ERR_BAD_ARG;
     if ((epi == EPI_RES || epi == EPI_MUL_DSILU) && (!res || ldr % 8 || ldr < N || ((uintptr_t)res % 16))) return VVAE_ERR_BAD_ARG;
     if (epi == EPI_SILU && (!C2 || ldc2 % 8 || ldc2 < N || ((uintptr_t)C2 % 16))) return VVAE_ERR_BAD_ARG;
-    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, g_nt_stagger};
+    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, g_nt_stagger, 0};
     hipStream_t s = (hipStream_t)stream;
     if (nt_pick(M, N, K) == 192) return launch_nt<Nt192>(A, B, C, bias, res, C2, d, s);
     return launch_nt<Nt128>(A, B, C, bias, res, C2, d, s);
