@@ -67,6 +67,14 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // d/dx silu(x) = s (1 + x (1 - s)), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
 
+#ifdef NT_STAMPS
+// diagnostic build (tools/nt_timeline_probe.py): wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries of its tiles
+__device__ unsigned long long g_nt_stamps[256 * 16];
+#define NT_STAMP(i) do { if (tid == 0 && (i) < 16) g_nt_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NT_STAMP(i) do {} while (0)
+#endif
+
 template <int N_>
 __device__ __forceinline__ void wait_vm()                       // s_waitcnt vmcnt(N_) only: at most the N_ youngest vector-memory ops outstanding
 {
@@ -153,8 +161,10 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     int tb = blockIdx.x, m0, n0;
     origin(tb, m0, n0);
     setup(m0, n0);
+    NT_STAMP(0);
     issue(0, 0);
     bool first = true;
+    int stamp = 1;
     while (true) {
         const int nb = tb + (int)gridDim.x;
         const bool more = nb < ntiles;
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         if (first) wait_vm0();
         else wait_vm<(EPI == EPI_SILU ? 2 : 1) * NIT>();
         __builtin_amdgcn_s_barrier();             // tile 0 visible to all; every wave is done with the C image
+        NT_STAMP(stamp); ++stamp;                 // k-tile 0 landed
         if (grp) {
             if (nk > 1) issue(1, 1);              // this half's pieces of tile 1 (the other half issues its own in L0)
             __builtin_amdgcn_s_barrier();         // the stagger
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         }
         if (!grp) __builtin_amdgcn_s_barrier();
         __syncthreads();                          // every wave is done with the operand buffers
+        NT_STAMP(stamp); ++stamp;                 // main loop done
 
         // ---- acc (+bias) -> packed bf16, in registers (48 instead of 96: the half of the waves that parks second holds them through the
         //      first half's stores).  acc[i][j][r]: channel 16 i + 4 kg + r, token 16 j + fr
@@ -296,6 +308,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
             }
             if (h == 0) __syncthreads();          // the image is read before the second half overwrites it
         }
+        NT_STAMP(stamp); ++stamp;                 // epilogue issued
         if (!more) break;
         tb = nb; m0 = nm0; n0 = nn0;
         first = false;
@@ -387,3 +400,10 @@ extern "C" int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     if (nt_pick(M, N, K) == 192) return launch_nt<Nt192>(A, B, C, bias, res, C2, d, s);
     return launch_nt<Nt128>(A, B, C, bias, res, C2, d, s);
 }
+
+#ifdef NT_STAMPS
+extern "C" int vvae_nt_stamps_copy(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 256 * 16, 0, hipMemcpyDeviceToHost);
+}
+#endif
