@@ -164,7 +164,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
     NT_STAMP(0);
     issue(0, 0);
     bool first = true;
-    int stamp = 1;
+    [[maybe_unused]] int stamp = 1;
     while (true) {
         const int nb = tb + (int)gridDim.x;
         const bool more = nb < ntiles;
