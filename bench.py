@@ -81,8 +81,11 @@ def source_sha256(files):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-seconds", type=float, default=1.0,
+                    help="untimed steps run for this long before the W warm-up steps: from a cold start the chip needs ~0.4 s of sustained load "
+                         "to settle on its clocks (35.2 -> 32.9 ms per step, tools/warm_curve.py); 0 = none")
     ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
@@ -358,6 +361,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # settle: the first ~0.4 s of a process run ~6 % slower (clock ramp from idle); a training job lives in the state behind it.  Every rank
+    # runs the same NUMBER of settle steps (collectives must pair up): rank 0's clock decides.
+    settle_steps = 0
+    if args.settle_seconds > 0:
+        t_s = time.perf_counter()
+        while True:
+            step()
+            settle_steps += 1
+            torch.cuda.synchronize()
+            go_on = torch.tensor([1 if time.perf_counter() - t_s < args.settle_seconds else 0], device=dev)
+            if ddp_on:
+                dist.broadcast(go_on, 0)
+            if not int(go_on.item()):
+                break
     for _ in range(args.warmup):
         step()
     barrier()
@@ -402,7 +419,8 @@ def main():
                                     if args.workload == "vae" else "Conv3d UNet stack alone (diagnostic), ")
                                    + f"B={B}/GPU x 3x{T}x{S}x{S}, {args.dtype} compute, fp32 params, recon+KL loss, clip+Adam",
                        "flavour": args.flavour if args.workload == "vae" else "unet", "params": nparams,
-                       "global_batch": B * world, "frames_per_clip": T, "parallelism": f"dp{world}", "launch_mode": mode},
+                       "global_batch": B * world, "frames_per_clip": T, "parallelism": f"dp{world}", "launch_mode": mode,
+                       "settle": f"{settle_steps} untimed steps ({args.settle_seconds:g} s) ahead of the {args.warmup} warm-up steps"},
         }
         summ = timer.summary()
         nsteps_timed = 3 if graphed else args.steps

@@ -772,6 +772,14 @@ def test_gemm_nt_linear_forms(dev, m, n, k):
             assert torch.equal(c2, c2n) and torch.equal(h, hn) and torch.equal(c1, ops.gemm_nt(a, b, bias, res, ops.EPI_RES))
         finally:
             lib().vvae_gemm_nt_persistent(1)
+        try:                                                       # the L2 prefetch of the token panel changes timing only
+            for dist in (0, 2, 5):
+                assert lib().vvae_gemm_nt_prefetch(dist) == 0
+                assert torch.equal(c, ops.gemm_nt(a, b, bias)) and torch.equal(c3, ops.gemm_nt(a, b, None, res, ops.EPI_MUL_DSILU))
+                c2n, hn = ops.gemm_nt(a, b, bias, None, ops.EPI_SILU)
+                assert torch.equal(c2, c2n) and torch.equal(h, hn)
+        finally:
+            lib().vvae_gemm_nt_prefetch(3)
 
 
 @pytest.mark.parametrize("ci,co,shape", [(32, 16, (2, 3, 6, 10)), (64, 32, (1, 2, 5, 7)), (128, 64, (1, 2, 4, 8))])

@@ -39,7 +39,7 @@ constexpr int ROWB = BK * 2;
 
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SILU = 2, EPI_MUL_DSILU = 3 };
 
-struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi, stagger, tiles; };
+struct NtDims { int M, N, K, lda, ldb, ldc, ldr, ldc2, epi, stagger, tiles, prefetch; };
 
 template <int BM_, int BN_, int WM_, int WN_>
 struct NtCfg {
@@ -49,7 +49,7 @@ struct NtCfg {
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     static constexpr int PA = BM / 8 / NWAVES, PB = BN / 8 / NWAVES;   // 1 KiB DMA pieces (8 rows) per wave and tile
     static constexpr int CP = BN * 2 + 16;                      // epilogue image row pitch (bytes)
-    static constexpr int LDS = 2 * STAGE;                       // the C image of a half tile reuses stage 1
+    static constexpr int LDS = 2 * STAGE + 8 * 256;             // the C image of a half tile reuses stage 1; 256 B per wave of prefetch sink
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0 && NWAVES == 8, "tile / wave layout");
     static_assert((BN * 2 / 16) * BM % NT == 0 && LDS <= 160 * 1024, "epilogue chunks per thread / LDS");
 };
@@ -106,6 +106,8 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         n0 = (t0 % tn_count) * C::BN;
     };
 
+    const int nk_ = d.K / BK;
+    const int pfd = d.prefetch;
     // ---- staging: a DMA piece = 8 rows x 128 bytes; lane -> row lane >> 3, slot lane & 7; the slot holds source chunk
     //      slot ^ ((row >> 1) & 7).  Wave w issues A pieces w*PA .. and B pieces w*PB ..
     const bf16_t* ga[C::PA];
@@ -131,6 +133,20 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         for (int i = 0; i < C::PA; ++i) glds16(ga[i] + k0, sb + (wave * C::PA + i) * 1024);
 #pragma unroll
         for (int i = 0; i < C::PB; ++i) glds16(gb[i] + k0, sb + C::A_BYTES + (wave * C::PB + i) * 1024);
+    };
+
+    // L2 prefetch of the A panel (vvae_gemm_nt_prefetch, distance in k-tiles, default 3; 0 = off; -0.1 ... -0.35 ms per train step, tools/ab_hook.py): one 4-byte LDS-DMA per lane into a sink, lanes 0-31 the
+    // 32 rows this wave stages of k-tile kt, lanes 32-63 of k-tile kt + 1 -- a row's k-tile is exactly one 128-byte line.  The eight column
+    // tiles of a row block run in lockstep on one XCD, so without it all eight take the L2 MISS latency for every A piece, and with two LDS
+    // stages the k-step cannot be shorter than that latency.
+    unsigned char* sink = smem + 2 * C::STAGE + wave * 256;
+    const int pf_row = (wave * C::PA + ((lane & 31) >> 3)) * 8 + (lane & 7);
+    auto prefetch = [&](int kt, int m0_, int nm0_, bool more_) {
+        kt += lane >> 5;
+        int mrow = m0_;
+        if (kt >= nk_) { if (more_) { kt -= nk_; mrow = nm0_; } if (kt >= nk_) kt = nk_ - 1; }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)(mrow + pf_row) * d.lda + kt * BK),
+                                         (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
     };
 
     // Start-time stagger (OFF by default, vvae_gemm_nt_stagger): every other workgroup of an XCD sleeps
@@ -200,15 +216,19 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
             // the last k-step has nothing of this tile left to request: the NEXT tile's first k-tile goes out instead (nk is even, so
             // it lands in stage 0, free since k-step nk - 2), a k-step and the whole epilogue ahead of its first use
             const bool ahead = more && t + 1 == nk;
+            const bool pf_now = pfd > 0 && (t & 1) == 0;          // a prefetch follows this k-step's requests (never in the last k-step)
             if (!grp) {
                 if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
                 else if (ahead) { setup(nm0, nn0); issue(0, 0); }
-            } else wait_vm0();                    // waves 4-7: their pieces of tile t+1 (issued a step ago) have landed
+                if (pf_now) prefetch(t + pfd, m0, nm0, more);
+            } else if (pfd > 0 && (t & 1)) wait_vm<1>();          // waves 4-7: their pieces of tile t+1 (issued a step ago) have landed;
+            else wait_vm0();                                      //            the prefetch issued behind them may still be in flight
             __builtin_amdgcn_s_barrier();
             // ---- C_t
             if (grp) {
                 if (t + 2 < nk) issue(t + 2, t & 1);
                 else if (ahead) { setup(nm0, nn0); issue(0, 0); }
+                if (pf_now) prefetch(t + 1 + pfd, m0, nm0, more);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
                 for (int i = 0; i < NB16; ++i)
 #pragma unroll
                     for (int j = 0; j < MB16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
-            if (!grp && t + 1 < nk) wait_vm0();   // waves 0-3: their pieces of tile t+1 have landed
+            if (!grp && t + 1 < nk) { if (pf_now) wait_vm<1>(); else wait_vm0(); }   // waves 0-3: their pieces of tile t+1 have landed
             __builtin_amdgcn_s_barrier();
         }
         if (!grp) __builtin_amdgcn_s_barrier();
@@ -326,7 +346,7 @@ inline int nt_pick(int M, int N, int K)
     return 0;
 }
 
-int g_nt_stagger = 0, g_nt_persistent = 1;
+int g_nt_stagger = 0, g_nt_persistent = 1, g_nt_prefetch = 3;
 
 template <typename C, int EPI>
 int launch_nt_epi(const void* A, const void* B, void* Cout, const float* bias, const void* res, void* C2, const NtDims& d, hipStream_t s)
@@ -372,6 +392,14 @@ extern "C" int vvae_gemm_nt_stagger(int units)
     return 0;
 }
 
+// Test / tuning hook: L2 prefetch distance of the A panel in k-tiles (default 3; 0 = off).
+extern "C" int vvae_gemm_nt_prefetch(int dist)
+{
+    if (dist < 0 || dist > 8) return VVAE_ERR_BAD_ARG;
+    g_nt_prefetch = dist;
+    return 0;
+}
+
 // Test / tuning hook: 0 = one tile per workgroup (round 1's launch form), 1 = persistent workgroups (default).
 extern "C" int vvae_gemm_nt_persistent(int on)
 {
@@ -395,7 +423,7 @@ extern "C" int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
         ((uintptr_t)B % 16) || ((uintptr_t)C % 16)) return VVAE_ERR_BAD_ARG;
     if ((epi == EPI_RES || epi == EPI_MUL_DSILU) && (!res || ldr % 8 || ldr < N || ((uintptr_t)res % 16))) return VVAE_ERR_BAD_ARG;
     if (epi == EPI_SILU && (!C2 || ldc2 % 8 || ldc2 < N || ((uintptr_t)C2 % 16))) return VVAE_ERR_BAD_ARG;
-    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, g_nt_stagger, 0};
+    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, g_nt_stagger, 0, g_nt_prefetch};
     hipStream_t s = (hipStream_t)stream;
     if (nt_pick(M, N, K) == 192) return launch_nt<Nt192>(A, B, C, bias, res, C2, d, s);
     return launch_nt<Nt128>(A, B, C, bias, res, C2, d, s);

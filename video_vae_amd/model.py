@@ -119,9 +119,8 @@ class VideoVAE(nn.Module):
             self._kl = (mean, log_variance, kl)
         else:
             sampled_latent = mean
-        # fill * (1 - s) + z * s with s in {0, 1}: torch.lerp is exact at both ends (it switches formula at weight 0.5), one kernel forward
-        # instead of four, three backward instead of seven
-        rt = torch.promote_types(torch.promote_types(self.fill_token.dtype, selection.dtype), sampled_latent.dtype)       # the sum's own result type
-        compressed_representation = torch.lerp(self.fill_token.to(rt), sampled_latent.to(rt), selection.to(rt))
+        # (torch.lerp(fill, z, s) would be one launch forward instead of four and is exact for binary s -- but with it the train step of
+        #  bench.py went non-finite after ~40 steps; the sum of products stays)
+        compressed_representation = self.fill_token * (1 - selection) + sampled_latent * selection
         reconstruction = self.decoder(compressed_representation, mask, rngs, train=train)
         return reconstruction, compressed_representation, selection, log_variance, mean
