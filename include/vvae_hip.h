@@ -14,7 +14,7 @@
  *   - return value: 0 on success, a hipError_t value, or VVAE_ERR_* (>= 1000);
  *   - process-global mutable state is limited to test / tuning hooks, none of which the product path calls:
  *     vvae_conv3d_force_generic, vvae_conv3d_roll_config, vvae_conv3d_wgrad_config, vvae_layernorm_config, vvae_layernorm_fwd_mode,
- *     vvae_gemm_tn_use_big_tiles, vvae_gemm_nt_stagger, vvae_gemm_nt_persistent, vvae_gemm_nt_prefetch, vvae_linear_residual_algo, vvae_temporal_attn_mfma_enable, vvae_temporal_attn_mfma32_enable (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 / vvae_linear_residual_wt_bf16 keep the
+ *     vvae_gemm_tn_use_big_tiles, vvae_gemm_nt_stagger, vvae_gemm_nt_persistent, vvae_gemm_nt_prefetch, vvae_gemm_nt_prefetch_mask, vvae_linear_residual_algo, vvae_temporal_attn_mfma_enable, vvae_temporal_attn_mfma32_enable (each documented at its declaration), plus one cache: vvae_linear_residual_bf16 / vvae_linear_residual_wt_bf16 keep the
  *     hipBLASLt handle and the solution the library's heuristic chose per (shape, pitches) behind a mutex; everything else is a pure function of its arguments.
  */
 #ifndef VVAE_HIP_H
@@ -296,6 +296,8 @@ int vvae_gemm_nt_stagger(int units);
 int vvae_gemm_nt_persistent(int on);
 /* Test / tuning hook: L2 prefetch distance (k-tiles of 64) of the token panel in vvae_gemm_nt_bf16 (default 3, 0 = off). */
 int vvae_gemm_nt_prefetch(int dist);
+/* Test / tuning hook: bit e set = epilogue kind e of vvae_gemm_nt_bf16 prefetches (default 5: plain and SiLU pair). */
+int vvae_gemm_nt_prefetch_mask(int mask);
 
 /* out[c] = sum_r part[r][c] in fixed order: folds the per-workgroup partial rows of the backward kernels (cols % 4 == 0). */
 int vvae_sum_rows(const float* part, int rows, int cols, float* out, void* stream);

@@ -346,7 +346,7 @@ inline int nt_pick(int M, int N, int K)
     return 0;
 }
 
-int g_nt_stagger = 0, g_nt_persistent = 1, g_nt_prefetch = 3;
+int g_nt_stagger = 0, g_nt_persistent = 1, g_nt_prefetch = 3, g_nt_prefetch_mask = 5;      // plain and SiLU-pair products prefetch; with a residual / silu' operand it lost 0.1 ms per step
 
 template <typename C, int EPI>
 int launch_nt_epi(const void* A, const void* B, void* Cout, const float* bias, const void* res, void* C2, const NtDims& d, hipStream_t s)
@@ -400,6 +400,13 @@ extern "C" int vvae_gemm_nt_prefetch(int dist)
     return 0;
 }
 
+// Test / tuning hook: which epilogue kinds prefetch (bit e = kind e; default all).
+extern "C" int vvae_gemm_nt_prefetch_mask(int mask)
+{
+    g_nt_prefetch_mask = mask & 15;
+    return 0;
+}
+
 // Test / tuning hook: 0 = one tile per workgroup (round 1's launch form), 1 = persistent workgroups (default).
 extern "C" int vvae_gemm_nt_persistent(int on)
 {
@@ -423,7 +430,7 @@ extern "C" int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
         ((uintptr_t)B % 16) || ((uintptr_t)C % 16)) return VVAE_ERR_BAD_ARG;
     if ((epi == EPI_RES || epi == EPI_MUL_DSILU) && (!res || ldr % 8 || ldr < N || ((uintptr_t)res % 16))) return VVAE_ERR_BAD_ARG;
     if (epi == EPI_SILU && (!C2 || ldc2 % 8 || ldc2 < N || ((uintptr_t)C2 % 16))) return VVAE_ERR_BAD_ARG;
-    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, g_nt_stagger, 0, g_nt_prefetch};
+    NtDims d{M, N, K, lda, ldb, ldc, ldr, ldc2, epi, g_nt_stagger, 0, ((g_nt_prefetch_mask >> epi) & 1) ? g_nt_prefetch : 0};
     hipStream_t s = (hipStream_t)stream;
     if (nt_pick(M, N, K) == 192) return launch_nt<Nt192>(A, B, C, bias, res, C2, d, s);
     return launch_nt<Nt128>(A, B, C, bias, res, C2, d, s);
