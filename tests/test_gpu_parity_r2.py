@@ -392,3 +392,15 @@ def test_c5_full_model_bf16_t32(dev):
         mean_t, lv_t, _ = enc._trunk(video[1:2, :24].contiguous(), L.expand_mask(mask[1:2, :24], hw))
     assert_close_scaled(mean_m[:, :24], mean_t, rel=4e-2, what="encoder mean, masked vs truncated")
     assert_close_scaled(lv_m[:, :24], lv_t, rel=4e-2, what="encoder log-variance, masked vs truncated")
+
+
+def test_production_step_survives_unsynchronised_bursts(dev):
+    """The graphed production train step (C3 shape) run the way bench.py's timed region runs it -- tens of replays queued without a host
+    synchronisation -- stays finite and keeps learning; parameters finite at the end.  (Guards the path a one-launch `torch.lerp` latent
+    gate broke in round 2: fine when synchronised every few steps, non-finite after ~40 queued ones.)"""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_bursts.py"), "3", "30"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    mses = [float(line.split("MSE")[1]) for line in r.stdout.splitlines() if line.startswith("burst")]
+    assert len(mses) == 3 and mses[-1] < mses[0], mses
