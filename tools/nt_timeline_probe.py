@@ -14,6 +14,8 @@ res = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
 c = torch.empty(M, N, device=dev, dtype=torch.bfloat16); c2 = torch.empty_like(c)
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 lib = ctypes.CDLL(os.path.abspath("tools/_probe/libnt_stamps.so"))
+if os.environ.get("PREFETCH") is not None:
+    lib.vvae_gemm_nt_prefetch(int(os.environ["PREFETCH"])); lib.vvae_gemm_nt_prefetch_mask(15)
 hip = ctypes.CDLL("libamdhip64.so")
 def run():
     return lib.vvae_gemm_nt_bf16(P(a), K, P(b), K, P(c), N, P(bias), P(res) if epi in (1, 3) else None, N, P(c2) if epi == 2 else None, N, epi, M, N, K,
