@@ -1,7 +1,8 @@
 """Where a persistent NT-GEMM workgroup spends its time: a diagnostic build of gemm_nt.hip (-DNT_STAMPS: wave 0 stamps s_memrealtime at
 the phase boundaries) run on the production shape after a burst of back-to-back launches.
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -fno-vectorize -shared -DNT_STAMPS video_vae_amd/csrc/gemm_nt.hip \
-        -o tools/_probe/libnt_stamps.so"""
+        -o tools/_probe/libnt_stamps.so
+    [PREFETCH=n] python tools/nt_timeline_probe.py [epilogue kind 0..3]"""
 import ctypes, os, sys
 import torch
 dev = "cuda"
@@ -16,7 +17,6 @@ P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 lib = ctypes.CDLL(os.path.abspath("tools/_probe/libnt_stamps.so"))
 if os.environ.get("PREFETCH") is not None:
     lib.vvae_gemm_nt_prefetch(int(os.environ["PREFETCH"])); lib.vvae_gemm_nt_prefetch_mask(15)
-hip = ctypes.CDLL("libamdhip64.so")
 def run():
     return lib.vvae_gemm_nt_bf16(P(a), K, P(b), K, P(c), N, P(bias), P(res) if epi in (1, 3) else None, N, P(c2) if epi == 2 else None, N, epi, M, N, K,
                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
