@@ -93,7 +93,9 @@ int vvae_conv3d_wgrad_bf16_cat2(const void* x, int ldx, const void* x2, int ldx2
                                 float* dbias, int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, void* ws,
                                 size_t ws_bytes, void* stream);
 /* out[c] = sum over V rows of x[v][c] (bias gradients) */
-int vvae_colsum(const void* x, int ld, long V, int C, float* out, int dtype, void* stream);
+int vvae_colsum_blocks(long V);   /* rows of vvae_colsum's partial buffer */
+/* out[c] = sum over V rows of x[v][c]; part: fp32 scratch, vvae_colsum_blocks(V) x C floats; two stages, no atomics: bitwise reproducible */
+int vvae_colsum(const void* x, int ld, long V, int C, float* out, float* part, int dtype, void* stream);
 
 /* ---- 1x1x1 convolutions onto 3 channels as HBM streams (UNet.final_conv train/unet.py:144-153,188; the PatchUnEmbedding
  *      down-projection train/layers.py:60-79).  Reached through vvae_conv3d_{fwd,dgrad,wgrad}; V = voxels, Cin in {12, 16}. ---- */

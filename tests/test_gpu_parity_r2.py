@@ -404,3 +404,14 @@ def test_production_step_survives_unsynchronised_bursts(dev):
     assert r.returncode == 0 and "soak ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     mses = [float(line.split("MSE")[1]) for line in r.stdout.splitlines() if line.startswith("burst")]
     assert len(mses) == 3 and mses[-1] < mses[0], mses
+
+
+def test_graphed_production_step_is_a_pure_function_of_its_inputs(dev):
+    """One graphed production train step replayed from the same parameters / moments / noise after different histories (straight away, after
+    a host pause, after a burst of 17 other steps, after host reads) gives the same loss, gradient buffer and updated parameters BIT FOR
+    BIT (tools/step_determinism.py).  Round 2 found the framework's multi-block reductions -- the bias gradients of the three 96-wide
+    latent-head Linear layers -- history-dependent inside a replayed hipGraph; they now run on vvae_colsum (two stages, no atomics)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "step_determinism.py"), "2"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "differences: 0 of 10" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])

@@ -9,6 +9,11 @@ from video_vae_amd import loss as L, optim
 from video_vae_amd.graph import GraphedTrainStep
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+import os
+for kv in os.environ.get("HOOKS", "").split():                # HOOKS="vvae_gemm_nt_prefetch=0 ..." : tuning hooks set before the capture
+    from video_vae_amd._lib import lib
+    k, v = kv.split("=")
+    assert getattr(lib(), k)(int(v)) == 0
 sys.argv = [sys.argv[0], "--no-cpu-baseline"]
 args = bench.parse()
 dev = torch.device("cuda:0")

@@ -177,6 +177,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     }
 }
 
+// stage 1 of vvae_colsum: part[blockIdx.x][c] = sum of this workgroup's rows (lane-strided, then a fixed tree through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, int ld, long V, int C, float* __restrict__ part,
+                                                          int rows_per_block)
+{
+    __shared__ float red[256];
+    int Cp = 1;
+    while (Cp < C && Cp < 256) Cp <<= 1;
+    const int rows = 256 / Cp;
+    const int cl = threadIdx.x % Cp, rl = threadIdx.x / Cp;
+    const long vbeg = (long)blockIdx.x * rows_per_block;
+    long vend = vbeg + rows_per_block;
+    if (vend > V) vend = V;
+    for (int c0 = 0; c0 < C; c0 += Cp) {
+        const int c = c0 + cl;
+        float s = 0.f;
+        if (c < C)
+            for (long v = vbeg + rl; v < vend; v += rows) s += ldf(x + v * (long)ld + c);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            float t = 0.f;
+            for (int i = 0; i < rows; ++i) t += red[i * Cp + cl];
+            part[(long)blockIdx.x * C + c] = t;
+        }
+        __syncthreads();
+    }
+}
+// stage 2: out[c] = sum_b part[b][c], b in index order
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * C + c];
+    out[c] = s;
+}
+
 template <typename T, bool DGRAD>
 int launch_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, ConvDims d,
                hipStream_t s)
@@ -290,20 +328,30 @@ extern "C" int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy,
     return VVAE_ERR_BAD_ARG;
 }
 
-// out[c] (fp32, overwritten) = sum over V rows of x[v][c]
-extern "C" int vvae_colsum(const void* x, int ld, long V, int C, float* out, int dtype, void* stream)
+// Rows of the fp32 partial buffer vvae_colsum needs: one per workgroup.
+extern "C" int vvae_colsum_blocks(long V)
 {
-    if (!x || !out || V <= 0 || C <= 0 || ld < C) return VVAE_ERR_BAD_ARG;
+    if (V <= 0) return 0;
+    const long b = (V + 255) / 256;                                  // >= 256 rows per workgroup, at most 1024 workgroups
+    return (int)(b < 1024 ? b : 1024);
+}
+
+// out[c] (fp32, overwritten) = sum over V rows of x[v][c].  part: fp32 scratch of vvae_colsum_blocks(V) x C floats.  Two stages, no
+// atomics: every workgroup writes its own partial row, one workgroup folds the rows in index order -- bitwise reproducible.  (The bias
+// gradients of the Linear layers the GEMM kernels do not take -- 96-wide latent heads -- used the framework's multi-block reduction, whose
+// result inside a replayed hipGraph depended on what had run before: tools/step_determinism.py.)
+extern "C" int vvae_colsum(const void* x, int ld, long V, int C, float* out, float* part, int dtype, void* stream)
+{
+    if (!x || !out || !part || V <= 0 || C <= 0 || ld < C || (dtype != VVAE_DT_F32 && dtype != VVAE_DT_BF16)) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = vvae_zero_async(out, sizeof(float) * C, s);
-    if (e != hipSuccess) return (int)e;
-    const int vb = 4096;
+    const int nblk = vvae_colsum_blocks(V);
+    const int vb = (int)((V + nblk - 1) / nblk);
     if (dtype == VVAE_DT_F32)
-        hipLaunchKernelGGL((colsum_kernel<float>), dim3(ceil_div(V, vb)), dim3(256), 0, s, (const float*)x, ld, V, C, out, vb);
-    else if (dtype == VVAE_DT_BF16)
-        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(ceil_div(V, vb)), dim3(256), 0, s, (const bf16_t*)x, ld, V, C, out, vb);
+        hipLaunchKernelGGL((colsum_part_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)x, ld, V, C, part, vb);
     else
-        return VVAE_ERR_BAD_ARG;
+        hipLaunchKernelGGL((colsum_part_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, ld, V, C, part, vb);
+    VVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, part, nblk, C, out);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

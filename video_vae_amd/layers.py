@@ -34,6 +34,15 @@ def _mm_f32(a, b):
 _BMM_F32_OUT = [None]
 
 
+def _colsum_f32(dy2):
+    """Bias gradient dy2.sum(0) in fp32.  On the GPU through the two-stage HIP reduction (vvae_colsum): the framework's multi-block
+    reduction gave history-dependent results inside a replayed hipGraph (tools/step_determinism.py) -- stale partials, occasionally
+    garbage large enough to end a run in NaN."""
+    if dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float32) and dy2.stride(-1) == 1:
+        return ops.colsum_raw(dy2)
+    return dy2.sum(0, dtype=torch.float32)
+
+
 def _dw_f32(x2, dy2):
     """x2^T @ dy2 (K tokens x M, K x N -> M x N fp32) for the Linear layers the HIP weight-gradient kernels do not take
     (M or N not a multiple of 128: patch embedding / un-embedding, the latent heads).  The library picks 64x64 tiles for such
@@ -126,7 +135,7 @@ class _LinearBf16(torch.autograd.Function):
             dw, db = ops.gemm_tn(x2, dy2, ctx.needs_input_grad[2])
         else:
             dw = _dw_f32(x2, dy2) if ctx.needs_input_grad[1] else None
-            db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+            db = _colsum_f32(dy2) if ctx.needs_input_grad[2] else None
         return dx, dw, db, dres, None
 
 
@@ -173,7 +182,7 @@ class _SiluLinearBf16(torch.autograd.Function):
             dw, db = ops.gemm_tn(a, dy2, ctx.needs_input_grad[2])
         else:
             dw = _dw_f32(a, dy2) if ctx.needs_input_grad[1] else None
-            db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+            db = _colsum_f32(dy2) if ctx.needs_input_grad[2] else None
         return dh, dw, db, dres, None
 
 

@@ -722,7 +722,9 @@ def colsum_raw(x):
     x, ld = rows(x)
     c = x.shape[-1]
     out = torch.empty((c,), dtype=torch.float32, device=x.device)
-    check(lib().vvae_colsum(_p(x), ld, x.numel() // c, c, _p(out), _dt(x), _stream()), "vvae_colsum")
+    v = x.numel() // c
+    part = torch.empty((lib().vvae_colsum_blocks(v), c), dtype=torch.float32, device=x.device)
+    check(lib().vvae_colsum(_p(x), ld, v, c, _p(out), _p(part), _dt(x), _stream()), "vvae_colsum")
     return out
 
 
