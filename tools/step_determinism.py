@@ -1,6 +1,7 @@
 """Is one graphed production train step a pure function of its inputs?  The same step (same parameters, moments, noise) is replayed after different
 histories -- straight away, after a host pause, after a burst of 17 other steps (hot clocks, different cache contents) -- and the flat gradient
-buffer and the loss are compared bit for bit with the first replay; a slot that differs names the kernel that wrote it."""
+buffer and the loss are compared bit for bit with the first replay; a slot that differs names the kernel that wrote it.
+    [BENCH_ARGS="--batch 2 --frames 32"] python tools/step_determinism.py [trials] [eager]"""
 import sys, time
 sys.path.insert(0, ".")
 import torch
@@ -10,7 +11,8 @@ from video_vae_amd import loss as L, optim
 from video_vae_amd.graph import GraphedTrainStep
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 eager = len(sys.argv) > 2 and sys.argv[2] == "eager"
-sys.argv = [sys.argv[0], "--no-cpu-baseline"]
+import os
+sys.argv = [sys.argv[0], "--no-cpu-baseline"] + os.environ.get("BENCH_ARGS", "").split()      # e.g. BENCH_ARGS="--batch 2 --frames 32"
 args = bench.parse()
 dev = torch.device("cuda:0")
 model, cfg = bench.build_model(args, dev, torch.bfloat16)
