@@ -323,3 +323,15 @@ def test_library_has_no_packed_fp32_valu_instructions():
     assert res[r"v_mfma_\w+"] > 1000                      # the scan does see the kernels
     assert res[r"v_pk_[a-z0-9]+_f32"] == 0, res
     assert res[r"ds_bpermute_b32"] == 0 and res[r"ds_swizzle_b32"] == 0, res
+
+
+def test_bench_default_protocol_meets_survey_8d(monkeypatch):
+    """>= 20 timed steps behind >= 5 warm-up steps; bench.py's defaults (plus the settle phase that keeps the clock ramp of a cold
+    start out of the timed region) and the N = 1 default the driver relies on."""
+    import sys
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.gpus == 1 and a.steps >= 20 and a.warmup >= 5 and 0 < a.settle_seconds <= 5
+    assert a.batch == 4 and a.frames == 16 and a.size == 256 and a.dtype == "bf16" and a.workload == "vae"      # config C3
