@@ -40,12 +40,13 @@ PROD = dict(height=256, width=256, channels=3, patch_size=16, encoder_depth=9, d
             qkv_features=512, max_temporal_len=64, spatial_compression_rate=8, unembedding_upsample_rate=4)
 
 
-TRAFFIC_FILE = "r02_traffic.json"
+TRAFFIC_FILE = "r03_traffic.json"
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (profiles/r02_traffic.json: separate
-    FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- or None, with the
+def measured_traffic(kernel, key="hbm_bytes_per_launch"):
+    """HBM bytes per launch of ``kernel`` (or, with key="mfma_busy", the busy fraction of the matrix pipes during its launches) from
+    the committed rocprofv3 PMC passes (profiles/r03_traffic.json: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; a third pass with SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE) -- or None, with the
     reason, when there is no figure or the kernel's sources have changed since the passes were taken (the file carries the
     sha256 of the .hip files the kernel is built from: a stale counter figure is refused, not quoted)."""
     import hashlib
@@ -55,8 +56,8 @@ def measured_traffic(kernel):
             rec = json.load(f).get(kernel)
     except (OSError, ValueError):
         return None, f"profiles/{TRAFFIC_FILE} missing"
-    if not rec:
-        return None, f"no PMC figure for {kernel} in profiles/{TRAFFIC_FILE}"
+    if not rec or key not in rec:
+        return None, f"no PMC figure ({key}) for {kernel} in profiles/{TRAFFIC_FILE}"
     h = hashlib.sha256()
     for name in rec.get("source_files", []):
         try:
@@ -66,7 +67,7 @@ def measured_traffic(kernel):
             return None, f"{name} not found"
     if rec.get("source_sha256") != h.hexdigest():
         return None, f"PMC passes predate the current {'/'.join(rec.get('source_files', []))}: re-run tools/pmc_bench_sum.py"
-    return rec.get("hbm_bytes_per_launch"), None
+    return rec.get(key), None
 
 
 def source_sha256(files):
@@ -100,11 +101,14 @@ def parse():
                     help="capture the step as two graphs cut at the encoder's last block even at N = 1 (the N > 1 default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo only to rehearse N > 1 on a one-GPU box")
-    ap.add_argument("--no-graph", action="store_true",
+    ap.add_argument("--no-graph", "--eager", action="store_true", dest="no_graph",
                     help="run the timed steps eagerly (default: forward+backward replayed from a captured hipGraph)")
     ap.add_argument("--with-input-pipeline", action="store_true",
                     help="feed every timed step from the host input pipeline (video_vae_amd/data.py: worker processes -> pinned uint8 "
                          "-> H2D on a side stream) instead of a batch resident in HBM; the line reports the same metric")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the per-launch HIP-event leg (roofline / kernels / conv_stack): for profiler passes over this script, where "
+                         "every extra step is minutes of serialised dispatches")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames per clip of the bounded CPU sample")
     ap.add_argument("--cpu-clips", type=int, default=1, help="clips of the bounded CPU sample")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the CPU baseline leg may take (steps are cut to fit)")
@@ -266,6 +270,9 @@ def self_launch(n):
 
 def main():
     args = parse()
+    # dmabuf IPC: RCCL across processes needs it on this pool (the host driver has no legacy IPC).  Set before the first GPU call of
+    # THIS process too -- under the driver's `torch.distributed.run ... bench.py` form no self-launch parent exists to export it.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -361,8 +368,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # settle: the first ~0.4 s of a process run ~6 % slower (clock ramp from idle); a training job lives in the state behind it.  Every rank
-    # runs the same NUMBER of settle steps (collectives must pair up): rank 0's clock decides.
+    def timed_steps(k):
+        """K steps bracketed by barrier + synchronize; -> (wall seconds of the bracket, per-step HIP-event milliseconds, last loss).  Events
+        sit on the current stream, where the graph replays and the eager update are enqueued: step i = event i -> event i + 1."""
+        barrier()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        t0 = time.perf_counter()
+        last = None
+        for i in range(k):
+            evs[i].record()
+            last = step()
+        evs[k].record()
+        barrier()
+        wall = time.perf_counter() - t0
+        return wall, [evs[i].elapsed_time(evs[i + 1]) for i in range(k)], last
+
+    graphed = "hipgraph" in mode
+    for _ in range(args.warmup):
+        step()
+    # COLD leg: the K steps right behind the W warm-up steps (SURVEY 8d's bare protocol).  From a cold start the chip runs its first ~0.4 s
+    # about 6 % slower (clock ramp from idle, tools/warm_curve.py); a training job lives in the state behind that ramp, so the headline
+    # is the SETTLED leg: untimed steps for --settle-seconds, then K timed steps.  Both are in the line.
+    cold_wall, cold_ms, loss = timed_steps(args.steps)
+    assert torch.isfinite(loss).all(), "non-finite loss in the cold timed region"
+    # Every rank runs the same NUMBER of settle steps (collectives must pair up): rank 0's clock decides.
     settle_steps = 0
     if args.settle_seconds > 0:
         t_s = time.perf_counter()
@@ -375,41 +404,50 @@ def main():
                 dist.broadcast(go_on, 0)
             if not int(go_on.item()):
                 break
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    graphed = "hipgraph" in mode
-    timer = ops.KernelTimer() if rank == 0 else None
-    if not graphed:
-        ops.TIMER = timer                      # eager: per-launch HIP events inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    timer = ops.KernelTimer() if (rank == 0 and not args.no_kernel_timing) else None
+    if not graphed and args.settle_seconds > 0:
+        ops.TIMER = timer                      # eager: per-launch HIP events inside the (settled) timed region
+    if args.settle_seconds > 0:
+        elapsed, step_ms, loss = timed_steps(args.steps)
+    else:
+        elapsed, step_ms = cold_wall, cold_ms
     ops.TIMER = None
-    if graphed:
+    if not graphed and args.settle_seconds <= 0:
+        graphed_like = True                    # no second leg to host the launch events: take them from steps behind the region
+    else:
+        graphed_like = graphed
+    if graphed_like and not args.no_kernel_timing:
         # a replayed graph cannot host event records: time the same kernels (same shapes, same data) in eager steps
         # run right after the timed region, on the same stream.  Every rank runs them (their gradient all-reduces must
         # pair up across ranks); only rank 0 records events.
         ops.TIMER = timer
         for _ in range(3):
-            eager_step()
+            eager_step() if args.workload == "vae" else step()
         torch.cuda.synchronize()
         ops.TIMER = None
     if ddp_on:
         dist.barrier()
+    import statistics
+    med, cold_med = statistics.median(step_ms), statistics.median(cold_ms)
     if ddp_on:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed, med, cold_wall, cold_med], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, med, cold_wall, cold_med = (float(v) for v in tmax.tolist())
     assert torch.isfinite(loss).all(), "non-finite loss in the timed region"
 
     if rank == 0:
         frames = B * T * world * args.steps
+        fps = lambda ms: B * T * world / (ms * 1e-3)
         out = {
-            "metric": "video frames/sec (fwd+bwd) at Bx3x16x256x256", "value": frames / elapsed, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            # frames per step / MEDIAN step time by HIP events (max over ranks), settled leg; the mean over the barrier-bracketed
+            # wall clock of the same K steps and the cold leg (no settle phase) are beside it
+            "metric": "video frames/sec (fwd+bwd) at Bx3x16x256x256", "value": fps(med), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": med,
+            "timing": {"value_from": "median of the K per-step HIP-event times, settled leg, max over ranks",
+                       "settled": {"ms_per_step_median": med, "ms_per_step_wall_mean": 1e3 * elapsed / args.steps, "value_wall_mean": frames / elapsed,
+                                   "ms_min": min(step_ms), "ms_max": max(step_ms)},
+                       "cold": {"ms_per_step_median": cold_med, "ms_per_step_wall_mean": 1e3 * cold_wall / args.steps, "value_median": fps(cold_med),
+                                "value_wall_mean": frames / cold_wall, "what": "the K steps right behind the W warm-up steps, no settle phase"}},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" if not args.with_input_pipeline else
                     "synthetic clips on disk through the host input pipeline (worker processes -> pinned uint8 -> H2D on a side stream)",
@@ -420,11 +458,12 @@ def main():
                                    + f"B={B}/GPU x 3x{T}x{S}x{S}, {args.dtype} compute, fp32 params, recon+KL loss, clip+Adam",
                        "flavour": args.flavour if args.workload == "vae" else "unet", "params": nparams,
                        "global_batch": B * world, "frames_per_clip": T, "parallelism": f"dp{world}", "launch_mode": mode,
-                       "settle": f"{settle_steps} untimed steps ({args.settle_seconds:g} s) ahead of the {args.warmup} warm-up steps"},
+                       "settle": f"{args.warmup} warm-up steps, {args.steps} timed steps (cold leg), {settle_steps} untimed steps "
+                                 f"({args.settle_seconds:g} s), {args.steps} timed steps (settled leg = value)"},
         }
-        summ = timer.summary()
-        nsteps_timed = 3 if graphed else args.steps
-        timed_in = ("eager steps right after the timed region (graph replay cannot host events)" if graphed
+        summ = timer.summary() if timer is not None else {}
+        nsteps_timed = 3 if graphed_like else args.steps
+        timed_in = ("eager steps right after the timed region (graph replay cannot host events)" if graphed_like
                     else "the timed region")
         if summ:
             # the dominant hand-written kernel = the kernel (all its tagged shapes together) with the largest total time per
@@ -443,7 +482,8 @@ def main():
                 mf = bound == "mfma"
                 return {"bound": bound, "achieved": tfs if mf else gbs, "peak": MFMA_PEAK_TFS if mf else HBM_PEAK_GBS,
                         "unit": "TFLOP/s" if mf else "GB/s", "frac": (tfs / MFMA_PEAK_TFS) if mf else (gbs / HBM_PEAK_GBS),
-                        "traffic": measured_traffic(kname)[0], "traffic_note": measured_traffic(kname)[1], "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
+                        "traffic": measured_traffic(kname)[0], "traffic_note": measured_traffic(kname)[1],
+                        "mfma_busy": measured_traffic(kname, "mfma_busy")[0], "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
                         "launches_per_step": top["n"] / nsteps_timed, "alg_bytes_per_launch": b_l, "alg_flops_per_launch": f_l,
                         "alg_GBps": gbs, "alg_TFLOPps": tfs, "frac_mfma": tfs / MFMA_PEAK_TFS,
                         "kernel_ms_per_step": top["ms"] / nsteps_timed, "timed_in": timed_in}

@@ -1,0 +1,149 @@
+"""Round 3: the benchmarked model -- full production depth, bf16, 256 x 256 -- against the CPU oracle END TO END.
+
+What bench.py times is 21 bf16 FactoredAttention blocks -> un-patchify + pad -> the UNet at 256^2 (12-real-channel patch mixer, rolling
+256^2 conv tiles, the 16 + 16 two-tensor decoder level, the one-kernel loss tail) -> recon + KL loss -> backward.  Round 2 compared pieces of
+that (two blocks at production width, a 64^2 UNet, the full depth in fp32 at 128^2); here the whole thing meets ``oracle.model.video_vae``
+(reference train/model.py:119-136, loss legacy/training_loop_adversarial.py:90-124) once run eagerly through ``L.loss_fn_plain`` and once
+as a ``GraphedTrainStep`` REPLAY -- graph vs oracle, not graph vs eager.
+
+Bar (as tests/test_gpu_parity_r2.py): the oracle runs twice on the CPU, in fp32 (``ref``) and with the reference's mixed-precision rules
+emulated (``emu``); the product's error against ``ref`` may not exceed 3 x the emulation's own + 2e-3.
+"""
+import pytest
+import torch
+
+from oracle import loss as OLoss
+from oracle import model as OM
+from test_gpu_parity_r2 import BF16_FACTOR, BF16_FLOOR, PROD, _load, check_bf16, rel_l2
+from util import rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def _case():
+    kw = dict(PROD, height=256, width=256)
+    cfg = OM.VAEConfig(**kw)
+    p = OM.init_video_vae(cfg, seed=3, zero_final=False)                 # final_conv non-zero: the UNet takes part
+    b, t = 1, 16
+    g = torch.Generator().manual_seed(0)
+    video = torch.rand((b, t, 256, 256, 3), generator=g)
+    mask = torch.ones(b, t)
+    mask[0, 13:] = 0                                                      # masked tail
+    # Gumbel uniforms far from the gate's threshold (a last-bit difference in the logits cannot flip a frame, which would be a discrete
+    # O(1) change and not a parity question); frame 0 is kept
+    u = torch.where(torch.rand((b, t, 1), generator=g) < 0.6, torch.full((), 0.9), torch.full((), 0.02))
+    u[:, 0] = 0.9
+    noise = {"gumbel_u": u, "reparam_eps": torch.randn((b, t, cfg.hw, cfg.latent_dim), generator=g)}
+    return kw, cfg, p, video, mask, noise
+
+
+def _oracle(cfg, p, video, mask, noise, dtype):
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    emask = OLoss.expand_mask(mask.bool(), cfg.hw)
+    v = video if dtype == torch.float32 else video.to(dtype).float()      # the driver casts the clip to bf16 (rl_nonadversarial.py:330)
+    loss, aux = OLoss.loss_fn_plain(OM.video_vae(po, cfg, v, emask, noise, dtype=dtype), v, mask)
+    loss.backward()
+    out = {"loss": loss.detach(), "recon": aux["reconstruction"].detach(), "MSE": aux["MSE"].detach(), "kl_loss": aux["kl_loss"].detach(),
+           "selection_loss": aux["selection_loss"].detach(), "density": aux["kept_frame_density"].detach()}
+    return out, {k: v.grad for k, v in po.items()}
+
+
+@pytest.fixture(scope="module")
+def oracle_runs():
+    kw, cfg, p, video, mask, noise = _case()
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    ref = _oracle(cfg, p, video, mask, noise, torch.float32)
+    emu = _oracle(cfg, p, video, mask, noise, torch.bfloat16)
+    return kw, cfg, p, video, mask, noise, ref, emu
+
+
+def _compare(tag, got, grads, ref, emu, names):
+    """got: dict like the oracle's; grads: {name: tensor}.  Scalars within 3 x the emulation's own distance (+ 2e-3 relative)."""
+    (o_ref, g_ref), (o_emu, g_emu) = ref, emu
+    report = []
+    check_bf16(f"{tag} reconstruction", got["recon"], o_emu["recon"], o_ref["recon"], report)
+    for k in ("loss", "MSE", "kl_loss"):
+        a, e, r = float(got[k]), float(o_emu[k]), float(o_ref[k])
+        assert abs(a - r) <= BF16_FACTOR * abs(e - r) + BF16_FLOOR * abs(r), f"{tag} {k}: gpu {a:.6g}, emulated oracle {e:.6g}, fp32 oracle {r:.6g}"
+    assert abs(float(got["density"]) - float(o_ref["density"])) < 1e-6, (tag, "kept_frame_density: a gate flipped")
+    # a spread of >= 60 parameter gradients over the whole depth + every UNet / head / embedding tensor
+    picked = set(names[::max(1, len(names) // 60)]) | {k for k in names if "unet" in k or "layers" not in k}
+    need_more = []
+    for k in sorted(picked):
+        floor = None
+        if k.endswith("conv.bias") and "final_conv" not in k and "patch_mixer" not in k:
+            floor = float(g_ref[k[:-4] + "kernel"].abs().max())             # zero in exact arithmetic (bias in front of a GroupNorm)
+        n0 = len(report)
+        check_bf16(f"{tag} d{k}", grads[k], g_emu[k], g_ref[k], report, floor_scale=floor)
+        if len(report) > n0 and report[-1][1] > 3e-2:
+            need_more.append(report[-1])
+    worst = sorted(report, key=lambda r: -r[1] / (BF16_FACTOR * r[2] + BF16_FLOOR))[:6]
+    print(f"\n[{tag}] {len(report)} tensors checked; worst (name, gpu vs fp32, emulation vs fp32):", [(n, f"{a:.2e}", f"{b:.2e}") for n, a, b in worst])
+    print(f"[{tag}] tensors above 3e-2 relative L2 (all within 3 x the emulation's own error):", [(n, f"{a:.2e}", f"{b:.2e}") for n, a, b in need_more])
+    return report
+
+
+def test_production_model_bf16_256_eager_vs_oracle(dev, oracle_runs):
+    """Eager: L.loss_fn_plain on the full-depth bf16 model at 256^2 (B=1, T=16 -- the production kernels' frame count -- masked tail, injected noise), backward inside
+    ops.deferred_wgrad as train_step runs it."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, ops, optim
+    kw, cfg, p, video, mask, noise, ref, emu = oracle_runs
+    m = _load(V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **kw), p, dev)
+    opt = optim.Optimizer(m, 0.0)
+    rngs = V.Rngs(3)
+    for k, v in noise.items():
+        rngs.inject(k, v)
+    vg, mg = video.to(dev, torch.bfloat16), mask.to(dev)
+    opt.zero_grad()
+    loss, aux = L.loss_fn_plain(m, vg, L.expand_mask(mg, cfg.hw), mg, rngs, L.HPARAMS)
+    with ops.deferred_wgrad(opt):
+        loss.backward()
+    for b in range(len(opt.buckets)):
+        if not opt.landed[b]:
+            opt._land(b)
+    torch.cuda.synchronize()
+    got = {"loss": loss, "recon": aux["reconstruction"], "MSE": aux["MSE"], "kl_loss": aux["kl_loss"], "density": aux["kept_frame_density"]}
+    grads = {n: g.clone() for n, g in zip(opt.names, opt.gviews)}
+    assert set(grads) == set(ref[1])
+    _compare("eager", got, grads, ref, emu, sorted(grads))
+
+
+def test_production_model_bf16_256_graph_replay_vs_oracle(dev, oracle_runs):
+    """The same case through a GraphedTrainStep REPLAY (what bench.py times and train.py runs): the captured forward + backward is replayed
+    with the oracle's noise in its static buffers; loss terms, reconstruction-dependent terms and the gradient buffer it leaves are compared
+    with the oracle (not with the eager pass).  lr = 0: the update that closes the step leaves the parameters where the oracle's are."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, optim
+    from video_vae_amd.graph import GraphedTrainStep
+    kw, cfg, p, video, mask, noise, ref, emu = oracle_runs
+    m = _load(V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **kw), p, dev)
+    opt = optim.Optimizer(m, 0.0)
+    vg, mg = video.to(dev, torch.bfloat16), mask.to(dev)
+    # captured on OTHER inputs (an all-ones mask, another clip): the replay below must depend on what is copied into the static buffers only
+    g = torch.Generator().manual_seed(99)
+    step = GraphedTrainStep(m, opt, torch.rand(video.shape, generator=g).to(dev, torch.bfloat16), torch.ones_like(mg), L.HPARAMS, cfg.hw, V.Rngs(3), warmup=1)
+    step()                                                              # one replay with other inputs and fresh noise first
+    loss, aux = step(vg, mg, noise={k: v.to(dev) for k, v in noise.items()})
+    torch.cuda.synchronize()
+    got = {"loss": loss, "MSE": aux["MSE"], "kl_loss": aux["kl_loss"], "density": aux["kept_frame_density"]}
+    (o_ref, g_ref), (o_emu, g_emu) = ref, emu
+    for k in ("loss", "MSE", "kl_loss"):
+        a, e, r = float(got[k]), float(o_emu[k]), float(o_ref[k])
+        assert abs(a - r) <= BF16_FACTOR * abs(e - r) + BF16_FLOOR * abs(r), f"replay {k}: gpu {a:.6g}, emulated oracle {e:.6g}, fp32 oracle {r:.6g}"
+    assert abs(float(got["density"]) - float(o_ref["density"])) < 1e-6
+    grads = {n: gv.clone() for n, gv in zip(opt.names, opt.gviews)}
+    names = sorted(grads)
+    report = []
+    picked = set(names[::max(1, len(names) // 60)]) | {k for k in names if "unet" in k or "layers" not in k}
+    for k in sorted(picked):
+        floor = None
+        if k.endswith("conv.bias") and "final_conv" not in k and "patch_mixer" not in k:
+            floor = float(g_ref[k[:-4] + "kernel"].abs().max())
+        check_bf16(f"replay d{k}", grads[k], g_emu[k], g_ref[k], report, floor_scale=floor)
+    assert len(report) >= 60
+    worst = sorted(report, key=lambda r: -r[1] / (BF16_FACTOR * r[2] + BF16_FLOOR))[:6]
+    print(f"\n[replay] {len(report)} gradient tensors checked; worst:", [(n, f"{a:.2e}", f"{b:.2e}") for n, a, b in worst])
+    # lr = 0 and the snapshot / restore around capture: the parameters are still the oracle's
+    for k, prm in m.named_parameters():
+        assert torch.equal(prm.detach().cpu(), p[k]), k

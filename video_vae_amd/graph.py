@@ -36,7 +36,7 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None, enc_segments=3):
+    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None, enc_segments=3, debug_dot=None):
         self.model, self.opt, self.hparams, self.hw, self.rngs = model, optimizer, hparams, hw, rngs
         self.split = (optimizer.reducer is not None) if split is None else bool(split)
         enc = model.encoder
@@ -69,6 +69,7 @@ class GraphedTrainStep:
         self.rl = L._is_rl(model)
         self.noise = {}
         self.graph = None
+        self.debug_dot = debug_dot           # path: write the captured graph (hipGraphDebugDotPrint) there, for tools/
         self._capture(warmup)
 
     def _loss(self):
@@ -196,6 +197,8 @@ class GraphedTrainStep:
         gc.collect()
         # 3. capture forward + backward + gradient landing on the same stream
         g = torch.cuda.CUDAGraph()
+        if self.debug_dot:
+            g.enable_debug_mode()
         # With a process group alive its watchdog thread polls events while we capture: only the capturing thread's own calls
         # may invalidate the capture then ("thread_local"); the default mode would let that poll abort it.
         mode = "thread_local" if opt.reducer is not None else "global"
@@ -213,18 +216,28 @@ class GraphedTrainStep:
         if not all(opt.landed):
             raise RuntimeError("a gradient bucket did not land inside the captured backward (parameter without gradient)")
         self.graph = g
+        if self.debug_dot:
+            g.debug_dump(self.debug_dot)
         opt.update()                      # the captured pass produced real gradients and left buckets to reduce: run the eager half once
         with torch.no_grad():             # ... then put the training state back where the caller left it
             opt.p.copy_(snap[0]); opt.m.copy_(snap[1]); opt.v.copy_(snap[2])
         opt.count = snap[3]
         opt.refresh_shadow()
 
-    def __call__(self, video=None, mask=None):
+    def __call__(self, video=None, mask=None, noise=None):
+        """One train step.  ``noise``: {draw name: tensor} to use for this step's stochastic draws instead of fresh ones from the
+        step's generator (the counterpart of ``Rngs.inject`` for the replayed graph: parity tests hand the oracle's noise over)."""
         if video is not None:
             self.video.copy_(video)
         if mask is not None:
             self.mask.copy_(mask)
-        self._refill()
+        if noise is None:
+            self._refill()
+        else:
+            if set(noise) != set(self.noise):
+                raise KeyError(f"noise for {sorted(noise)} given, the captured step draws {sorted(self.noise)}")
+            for name, t in noise.items():
+                self.noise[name][1].copy_(t)
         self.graph.replay()
         for st, gs in enumerate(self.graphs, start=1):
             self._prelaunch(st - 1)                      # buckets the previous stage completed: reduced under this stage

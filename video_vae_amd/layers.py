@@ -1,8 +1,10 @@
 """Transformer-side layers with the reference's class surface (train/layers.py).
 
-Dense Linear / LayerNorm / spatial attention are glue on stock PyTorch-ROCm (hipBLASLt GEMMs, SDPA);
-the temporal attention core (q/k-norm + RoPE + masked softmax + PV over <= 64 frames) is the fused HIP
-kernel ``ops.temporal_attention_core``.
+Everything on the bf16 GPU path is a launch of libvvae_hip.so through ``ops``: LayerNorm (with the residual adds folded in), the
+temporal AND the spatial attention cores (q/k-norm + RoPE + softmax + PV in one kernel each: ``ops.temporal_attention_core``,
+``ops.spatial_attention_core``), fc1 + SiLU and the MLP's input gradient on the own NT GEMM, every weight gradient on the grouped
+TN GEMM.  The remaining forward / input-gradient products of the Linear layers are plain hipBLASLt GEMMs.  The library's
+flash-attention kernel is only the fallback core for spatial shapes the fused kernel does not take (head_dim != 64, S > 256).
 """
 import math
 
@@ -34,11 +36,15 @@ def _mm_f32(a, b):
 _BMM_F32_OUT = [None]
 
 
+FRAMEWORK_COLSUM = [False]     # tools/reduce_history_probe.py only: put the framework's multi-block reduction back to study it
+
+
 def _colsum_f32(dy2):
     """Bias gradient dy2.sum(0) in fp32.  On the GPU through the two-stage HIP reduction (vvae_colsum): the framework's multi-block
-    reduction gave history-dependent results inside a replayed hipGraph (tools/step_determinism.py) -- stale partials, occasionally
-    garbage large enough to end a run in NaN."""
-    if dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float32) and dy2.stride(-1) == 1:
+    reduction gave history-dependent results inside a replayed hipGraph (tools/step_determinism.py, DESIGN.md section 3: its semaphore
+    reset is a hipMemsetAsync, i.e. a memset NODE in the captured graph) -- stale values, occasionally garbage large enough to end a
+    run in NaN."""
+    if dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float32) and dy2.stride(-1) == 1 and not FRAMEWORK_COLSUM[0]:
         return ops.colsum_raw(dy2)
     return dy2.sum(0, dtype=torch.float32)
 
@@ -447,7 +453,8 @@ class Attention(nn.Module):
             o = ops.temporal_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached,
                                             self.ROPE.sin_cached, m8, div, self.num_heads, 1e-6)
         elif mask is None and ops.spatial_attention_supported(qkv, self.num_heads, self.ROPE.cos_cached.shape[0]):
-            # spatial half in bf16: one HIP prep launch each way around the library flash-attention core
+            # spatial half in bf16: the fused HIP kernel (q/k-norm + RoPE + softmax(QK^T)V; head_dim 64, S <= 256), or for other
+            # shapes one HIP prep launch each way around the library flash-attention core (ops.spatial_attention_core decides)
             o = ops.spatial_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
                                            self.num_heads, 1e-6)
         else:

@@ -119,22 +119,9 @@ class VideoVAE(nn.Module):
             self._kl = (mean, log_variance, kl)
         else:
             sampled_latent = mean
-        # (torch.lerp(fill, z, s) would be one launch forward instead of four and is exact for binary s -- but with it the train step of
-        #  bench.py went non-finite after ~40 steps; the sum of products stays)
-        import os
-        v = os.environ.get("GATE", "sum")
-        if v == "lerp":
-            compressed_representation = torch.lerp(self.fill_token, sampled_latent, selection)
-        elif v == "lerp_detach_w":
-            compressed_representation = torch.lerp(self.fill_token, sampled_latent, selection.detach()) + 0 * selection
-        elif v == "lerp_to":
-            rt = torch.promote_types(torch.promote_types(self.fill_token.dtype, selection.dtype), sampled_latent.dtype)
-            compressed_representation = torch.lerp(self.fill_token.to(rt), sampled_latent.to(rt), selection.to(rt))
-        elif v == "manual":
-            compressed_representation = self.fill_token + selection * (sampled_latent - self.fill_token)
-        elif v == "lerp_expand":
-            compressed_representation = torch.lerp(self.fill_token.expand_as(sampled_latent), sampled_latent, selection.expand_as(sampled_latent))
-        else:
-            compressed_representation = self.fill_token * (1 - selection) + sampled_latent * selection
+        # fill * (1 - s) + z * s as the reference writes it (model.py:133).  torch.lerp(fill, z, s) would be one launch instead of four,
+        # but its backward adds a multi-block framework reduction (the gradient of the broadcast fill_token) to the captured step, and
+        # those are kept out of a replayed hipGraph (the reduction's semaphore memset is a graph memset node).
+        compressed_representation = self.fill_token * (1 - selection) + sampled_latent * selection
         reconstruction = self.decoder(compressed_representation, mask, rngs, train=train)
         return reconstruction, compressed_representation, selection, log_variance, mean

@@ -153,18 +153,21 @@ def force_generic_conv(on):
     lib().vvae_conv3d_force_generic(1 if on else 0)
 
 
-def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None, k_real=0):
+def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None, k_real=0, price=None):
     """Shared by fwd (dgrad=0) and dgrad (dgrad=1): bf16 fast path (weights packed here, or already packed for the whole step by
     conv3d_prepack: ``packed``), else the dispatcher.  ``k_real``: how many of the layer's K channels are not zero padding (0 = all):
-    the matrix-core kernels that know the count skip the padded part of the product (the 12-of-16 channel patch mixer)."""
+    the matrix-core kernels that know the count skip the padded part of the product (the 12-of-16 channel patch mixer).
+    ``price``: (Cin, Cout) the layer really has when its tensors are zero-padded to the kernels' 16-channel granule: the algorithmic
+    bytes / FLOPs bench.py quotes are those of the true layer, not of the padded launch."""
     n, t, h, w, cin, cout, kt, kh, kw = dims
     dt = _dt(x)
     ldo = out.stride(-2)
     esz = x.element_size()
     ck, co = (cout, cin) if dgrad else (cin, cout)
     vox = n * t * h * w
-    alg = vox * (ck + co) * esz
-    flops = 2 * vox * kt * kh * kw * cin * cout
+    pci, pco = price if price is not None else (cin, cout)
+    alg = vox * (pci + pco) * esz
+    flops = 2 * vox * kt * kh * kw * pci * pco
     name = "dgrad" if dgrad else "fwd"
     tag = f"conv3d_{name} {ck}->{co} k{kt}{kh}{kw} @{h}x{w}"
     if _bf16_fast(cin, cout, kt, kh, kw, ldx, ldo, 1 if dgrad else 0, dt):
@@ -191,24 +194,24 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None, k_real=0
 
 
 # --------------------------------------------------------------------------------------------- Conv3d
-def conv3d_fwd_raw(x, kernel, bias, out=None, packed=None, k_real=0):
+def conv3d_fwd_raw(x, kernel, bias, out=None, packed=None, k_real=0, price=None):
     x, ldx = rows(x)
     n, t, h, w, cin = x.shape
     kt, kh, kw, cin2, cout = kernel.shape
     assert cin == cin2, (cin, cin2)
     if out is None:
         out = torch.empty((n, t, h, w, cout), dtype=x.dtype, device=x.device)
-    return _conv_fwd_like(x, ldx, kernel, bias, out, (n, t, h, w, cin, cout, kt, kh, kw), 0, packed, k_real)
+    return _conv_fwd_like(x, ldx, kernel, bias, out, (n, t, h, w, cin, cout, kt, kh, kw), 0, packed, k_real, price)
 
 
-def conv3d_dgrad_raw(dy, kernel, out=None, packed=None, k_real=0):
+def conv3d_dgrad_raw(dy, kernel, out=None, packed=None, k_real=0, price=None):
     dy, lddy = rows(dy)
     n, t, h, w, cout = dy.shape
     kt, kh, kw, cin, cout2 = kernel.shape
     assert cout == cout2
     if out is None:
         out = torch.empty((n, t, h, w, cin), dtype=dy.dtype, device=dy.device)
-    return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1, packed, k_real)
+    return _conv_fwd_like(dy, lddy, kernel, None, out, (n, t, h, w, cin, cout, kt, kh, kw), 1, packed, k_real, price)
 
 
 class ConvPack:
@@ -263,7 +266,7 @@ def conv3d_prepack(kernels, reals=None):
     return packs
 
 
-def conv3d_wgrad_raw(x, dy, kshape, want_bias=True, dw_out=None, db_out=None):
+def conv3d_wgrad_raw(x, dy, kshape, want_bias=True, dw_out=None, db_out=None, price=None):
     """-> (dw, db) fp32; dw_out / db_out: contiguous fp32 buffers to overwrite instead of fresh ones (flat-buffer slots)."""
     x, ldx = rows(x)
     dy, lddy = rows(dy)
@@ -276,7 +279,8 @@ def conv3d_wgrad_raw(x, dy, kshape, want_bias=True, dw_out=None, db_out=None):
     ws, wsb = _ws(wsb, x.device)
     vox = n * t * h * w
     tag = f"conv3d_wgrad {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
-    check(_launch(tag, vox * (cin + cout) * x.element_size(), 2 * vox * kt * kh * kw * cin * cout, "conv3d_wgrad",
+    pci, pco = price if price is not None else (cin, cout)
+    check(_launch(tag, vox * (pci + pco) * x.element_size(), 2 * vox * kt * kh * kw * pci * pco, "conv3d_wgrad",
                   lambda: lib().vvae_conv3d_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), _p(db), n, t, h, w, cin, cout, kt, kh, kw, dt,
                                                   _p(ws), wsb, _stream())), "vvae_conv3d_wgrad")
     return dw, db
@@ -291,7 +295,7 @@ def conv3d_gn_blocks(x, kernel, groups):
     return lib().vvae_conv3d_gn_blocks(n, t, h, w, cin, cout, kt, kh, kw, x.stride(-2), cout, groups)
 
 
-def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk, packed=None):
+def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk, packed=None, price=None):
     """conv3d_fwd_raw + the per-(sample, workgroup, group) sums of the rounded outputs: -> (y, part (n, nblk, groups, 2) fp32)."""
     x, ldx = rows(x)
     n, t, h, w, cin = x.shape
@@ -305,7 +309,8 @@ def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk, packed=None):
         ws, wsb = _ws(wsb, x.device)
     vox = n * t * h * w
     tag = f"conv3d_fwd {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
-    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+    pci, pco = price if price is not None else (cin, cout)
+    check(_launch(tag, vox * (pci + pco) * 2, 2 * vox * kt * kh * kw * pci * pco, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
                   lambda: lib().vvae_conv3d_fwd_bf16_gn(_p(x), ldx, _p(kernel), _p(bias), _p(out), cout, n, t, h, w, cin, cout, kt, kh,
                                                         kw, 1 if packed is not None else 0, _p(ws), wsb, _p(part), groups, _stream())),
           "vvae_conv3d_fwd_bf16_gn")
@@ -314,35 +319,37 @@ def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk, packed=None):
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias, gn_groups=0, gn_blocks=0, pack=None, real=None):
+    def forward(ctx, x, kernel, bias, gn_groups=0, gn_blocks=0, pack=None, real=None, price=None):
         k32 = _f32(kernel)
         b32 = _f32(bias) if bias is not None else None
         ctx.save_for_backward(x, k32)
         ctx.real = real                                  # (real Cin, real Cout) of a zero-padded layer, or None
+        ctx.price = price if price is not None else real    # (Cin, Cout) the roofline accounting uses (_conv_fwd_like)
         ctx.has_bias = bias is not None
         ctx.kdtype = kernel.dtype
         ctx.kparam, ctx.bparam = kernel, bias            # for ops.deferred_wgrad: where the gradient may be written directly
         ctx.pack = pack                                  # this step's packed weights (conv3d_prepack), or None: pack per call
         if gn_blocks:
-            y, part = conv3d_fwd_gn_raw(x, k32, b32, gn_groups, gn_blocks, pack.fwd if pack is not None else None)
+            y, part = conv3d_fwd_gn_raw(x, k32, b32, gn_groups, gn_blocks, pack.fwd if pack is not None else None, ctx.price)
             ctx.mark_non_differentiable(part)
             ctx.set_materialize_grads(False)             # no zero-filled gradient tensor for the partials in backward
             ctx.with_part = True
             return y, part
         ctx.with_part = False
-        return conv3d_fwd_raw(x, k32, b32, packed=pack.fwd if pack is not None else None, k_real=real[0] if real is not None else 0)
+        return conv3d_fwd_raw(x, k32, b32, packed=pack.fwd if pack is not None else None, k_real=real[0] if real is not None else 0,
+                              price=ctx.price)
 
     @staticmethod
     def backward(ctx, dy, dpart=None):
         dx, dw, db = _Conv3d._backward(ctx, dy)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
     @staticmethod
     def _backward(ctx, dy):
         x, k32 = ctx.saved_tensors
         dy = dy.to(x.dtype)
         dx = (conv3d_dgrad_raw(dy, k32, packed=ctx.pack.dgrad if ctx.pack is not None else None,
-                               k_real=ctx.real[1] if ctx.real is not None else 0) if ctx.needs_input_grad[0] else None)
+                               k_real=ctx.real[1] if ctx.real is not None else 0, price=ctx.price) if ctx.needs_input_grad[0] else None)
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             q = WGRAD_QUEUE[0]
@@ -354,12 +361,12 @@ class _Conv3d(torch.autograd.Function):
                 # inside ops.deferred_wgrad the slab-reduce kernel overwrites the parameters' slots of the flat gradient buffer
                 # directly: no gradient tensor, no landing copy (and no clone by autograd.grad inside a captured graph)
                 q.claim(kp)
-                conv3d_wgrad_raw(x, dy, tuple(k32.shape), bp is not None, kp.gview, bp.gview if bp is not None else None)
+                conv3d_wgrad_raw(x, dy, tuple(k32.shape), bp is not None, kp.gview, bp.gview if bp is not None else None, ctx.price)
                 q.opt.mark_external(kp)
                 if bp is not None:
                     q.opt.mark_external(bp)
                 return dx, None, None
-            dw, db = conv3d_wgrad_raw(x, dy, tuple(k32.shape), ctx.has_bias)
+            dw, db = conv3d_wgrad_raw(x, dy, tuple(k32.shape), ctx.has_bias, price=ctx.price)
             dw = dw.to(ctx.kdtype)
         return dx, dw, db
 
@@ -492,14 +499,14 @@ def conv3d(x, kernel, bias=None, pack=None, real=None):
     return _Conv3d.apply(x, kernel, bias, 0, 0, pack, real)
 
 
-def conv3d_with_gn_stats(x, kernel, bias, groups, pack=None):
+def conv3d_with_gn_stats(x, kernel, bias, groups, pack=None, price=None):
     """-> (conv3d(x), stats) where stats is None or (partial sums, rows per sample) for group_norm_silu(..., stats=...): on
     the rolling bf16 kernel the conv's epilogue also sums its rounded outputs per GroupNorm group, so the norm behind it
     (reference train/unet.py:13-23) skips its own statistics pass over the tensor."""
     nblk = conv3d_gn_blocks(x, kernel, groups) if bias is not None else 0
     if not nblk:
-        return _Conv3d.apply(x, kernel, bias, 0, 0, pack, None), None
-    y, part = _Conv3d.apply(x, kernel, bias, groups, nblk, pack, None)
+        return _Conv3d.apply(x, kernel, bias, 0, 0, pack, None, price), None
+    y, part = _Conv3d.apply(x, kernel, bias, groups, nblk, pack, None, price)
     return y, (part, nblk)
 
 

@@ -61,6 +61,7 @@ def main():
                          "path of an .npz / .pt with its six tensors (the ImageNet weights are a remote download in the reference)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC for RCCL between the ranks; before the first GPU call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
