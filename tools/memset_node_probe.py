@@ -5,6 +5,8 @@ launch -- inside a stream capture that is a memset NODE.  Round 2 saw history-de
 the replayed 880-node train step; round 1 saw our own hipMemsetAsync-before-accumulate race in ~1 of 3 replays.  This probe isolates the
 node type:
 
+  part 0 (bare): [ hipMemsetAsync(buf, byte) | out = buf + 0 ] and nothing else in the graph, buf pre-filled with 5.0 before every replay:
+         out must be the byte pattern everywhere.  A wrong value here is not an ordering question: the node itself writes the wrong thing.
   part 1 (explicit): R x [ heavy GEMM | K0: buf = 5 | hipMemsetAsync(buf, 0) | K2: buf += 1 | out_i = buf + 0 ]   -> every out_i must be 1
          6 = the memset ran before K0 (or not at all), 0 = it ran after K2, 5/other = it overlapped;  control: the memset as a fill kernel
   part 2 (framework): R x [ heavy GEMM | y_i = x_i.sum(0) over (16384, 96) ] with x_i rewritten between replays, against the fp64 sums;
@@ -35,6 +37,31 @@ def capture(body):
     with torch.cuda.graph(g, stream=s):
         body(s)
     return g
+
+
+def part0(nbytes, byte):
+    n = nbytes // 4
+    buf = torch.empty(n, device=dev)
+    out = torch.empty(n, device=dev)
+
+    def body(s):
+        rc = hip.hipMemsetAsync(buf.data_ptr(), byte, nbytes, s.cuda_stream)
+        assert rc == 0, rc
+        torch.add(buf, 0.0, out=out)
+    g = capture(body)
+    bad, seen = 0, {}
+    for _ in range(replays):
+        buf.fill_(5.0)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        iv = out.view(torch.int32)
+        ok = iv == (byte * 0x01010101 if byte < 0x80 else byte * 0x01010101 - (1 << 32))
+        if not bool(ok.all()):
+            bad += 1
+            for v in torch.unique(iv[~ok])[:4].tolist():
+                seen[hex(v & 0xFFFFFFFF)] = seen.get(hex(v & 0xFFFFFFFF), 0) + 1
+    print(f"part 0, {nbytes:>8d} B, memset byte {byte:#04x} alone in the graph: {bad} of {replays} replays wrong; wrong words seen {dict(list(seen.items())[:6])}", flush=True)
 
 
 def part1(nbytes, memset_node):
@@ -101,6 +128,8 @@ def part2():
           f"previous replay's values at the wrong elements", flush=True)
 
 
+for nbytes, byte in ((64, 0), (4096, 0), (4096, 0x3F), (1 << 22, 0)):
+    part0(nbytes, byte)
 for nbytes in (64, 4096, 1 << 22):
     part1(nbytes, True)
 part1(4096, False)

@@ -36,8 +36,10 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None, enc_segments=3, debug_dot=None):
+    def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None, enc_segments=3, debug_dot=None,
+                 perceptual_loss_fn=None, vgg_params=None):
         self.model, self.opt, self.hparams, self.hw, self.rngs = model, optimizer, hparams, hw, rngs
+        self.ploss, self.vgg_params = perceptual_loss_fn, vgg_params      # rl flavour only (rl_nonadversarial.py:125)
         self.split = (optimizer.reducer is not None) if split is None else bool(split)
         enc = model.encoder
         if not (hasattr(enc, "layers") and hasattr(enc, "patch_embedding") and len(enc.layers) > 0):
@@ -75,7 +77,7 @@ class GraphedTrainStep:
     def _loss(self):
         emask = L.expand_mask(self.mask, self.hw)
         if self.rl:
-            return L.loss_fn(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
+            return L.loss_fn(self.model, self.video, emask, self.mask, self.rngs, self.hparams, self.ploss, self.vgg_params)
         return L.loss_fn_plain(self.model, self.video, emask, self.mask, self.rngs, self.hparams)
 
     # ---- staged form (data parallel): forward + decoder backward | encoder backward in segments -------------------------

@@ -11,11 +11,19 @@ curriculum (:287-295) and log keys (:344-359).  Data: any iterable of {"video": 
 video_vae_amd/data.py (worker processes -> pinned uint8 batches -> H2D on a side stream, per-rank shuffle seed + rank); without
 --data this driver feeds seeded synthetic clips.  One process per GPU; gradients are all-reduced over RCCL overlapped with backward (ddp.py); rank 0 logs;
 SIGTERM/SIGINT flips a flag and the loop checkpoints and exits (distributed_train.py:58-67,489-494).
+
+The step runs on the path bench.py measures: ``StepRunner`` keeps one captured ``GraphedTrainStep`` per (batch, frames) shape of the
+curriculum -- the counterpart of the reference's ``nnx.jit(train_step)`` (rl_nonadversarial.py:276-277,332), which also compiles once
+per shape -- and runs eagerly only until a shape has been seen ``--capture_after`` times (a shape met once is not worth a capture) or
+with ``--eager``.  Every ``--sample_every`` steps the reconstruction and the original of one clip are written with data.batch_to_video
+(rl_nonadversarial.py:337-343); after every epoch ``--eval_steps`` batches go through eval_step (:200-208,362-391).
 """
 import argparse
+import gc
 import math
 import os
 import signal
+import statistics
 import time
 
 import torch
@@ -27,6 +35,7 @@ from video_vae_amd import ddp, loss as L, optim, rl_model
 NUM_EPOCHS, BATCH_SIZE, MAX_FRAMES, RESIZE, SEED = 100, 2, 32, (256, 256), 0
 NEGATIVE_PENALTY_TRAINING_STEPS = 2000
 _SHOULD_STOP = False
+TIMES = []                    # (start event, end event, launch mode) per step, read after the loop
 
 
 def _stop(signum, frame):
@@ -34,13 +43,65 @@ def _stop(signum, frame):
     _SHOULD_STOP = True
 
 
-def synthetic_batches(batch, frames, size, seed, steps, device):
+def synthetic_batches(batch, frames, size, seed, steps, device, pool=4):
+    """Seeded synthetic clips with ragged lengths: a pool of ``pool`` device-resident batches, cycled (generating 12.6 M uniform floats
+    per step on the host costs more than the train step it would feed)."""
     g = torch.Generator().manual_seed(seed)
-    for _ in range(steps):
+    made = []
+    for _ in range(min(pool, steps)):
         video = torch.rand((batch, frames, size[0], size[1], 3), generator=g)
         lens = torch.randint(max(1, frames // 2), frames + 1, (batch,), generator=g)
         mask = (torch.arange(frames)[None, :] < lens[:, None]).float()
-        yield {"video": video.to(device), "mask": mask.to(device)}
+        made.append({"video": video.to(device), "mask": mask.to(device)})
+    for i in range(steps):
+        yield made[i % len(made)]
+
+
+class StepRunner:
+    """train_step(video, mask, hparams) -> (loss, aux), replayed from a captured hipGraph once a shape has been seen often enough.
+
+    One graph per input shape; a change of ``hparams`` (the compression-rate switch at step 2000, :327-328) re-captures that shape's
+    graph, since the loss constants are baked into the captured launches.  Each graph draws its noise from its own ``Rngs`` (a captured
+    step pins the draws of ITS rngs to static buffers; the eager fallback keeps drawing from the driver's)."""
+
+    def __init__(self, model, opt, hw, rngs, perceptual_loss_fn=None, vgg_params=None, use_graph=True, capture_after=1, log=None):
+        self.model, self.opt, self.hw, self.rngs = model, opt, hw, rngs
+        self.ploss, self.vgg_params = perceptual_loss_fn, vgg_params
+        self.use_graph, self.capture_after, self.log = use_graph, capture_after, log or (lambda msg: None)
+        self.graphs, self.seen = {}, {}
+        self.mode = "eager"
+
+    def __call__(self, video, mask, hparams):
+        shape = (tuple(video.shape), video.dtype)
+        hkey = tuple(sorted(hparams.items()))
+        hit = self.graphs.get(shape)
+        if hit is not None and hit[0] == hkey:
+            self.mode = "hipgraph"
+            loss, aux = hit[1](video, mask)
+            return loss, dict(aux)
+        n = self.seen[shape] = self.seen.get(shape, 0) + 1
+        if self.use_graph and n > self.capture_after:
+            from .graph import GraphedTrainStep
+            if hit is not None:                                  # same shape, new loss constants: drop the old graph and its pool first
+                del self.graphs[shape], hit
+                gc.collect()
+                torch.cuda.empty_cache()
+            try:
+                t0 = time.perf_counter()
+                g = GraphedTrainStep(self.model, self.opt, video, mask, dict(hparams), self.hw, V.Rngs(1_000_003 * (self.rngs.seed + 1) + len(self.seen)),
+                                     perceptual_loss_fn=self.ploss, vgg_params=self.vgg_params)
+                self.graphs[shape] = (hkey, g)
+                self.log(f"captured the train step for video {tuple(video.shape)} in {time.perf_counter() - t0:.1f} s "
+                         f"({1 + len(g.graphs)} hipGraph{'s' if g.graphs else ''})")
+                self.mode = "hipgraph"
+                loss, aux = g(video, mask)
+                return loss, dict(aux)
+            except Exception as e:                               # capture is an optimisation, never a requirement
+                self.log(f"hipGraph capture failed ({type(e).__name__}: {e}); this shape stays eager")
+                self.seen[shape] = -(1 << 30)
+        self.mode = "eager"
+        loss, aux = L.train_step(self.model, self.opt, video, mask, hparams, self.hw, self.rngs, self.ploss, self.vgg_params)
+        return loss, aux
 
 
 def main():
@@ -56,6 +117,15 @@ def main():
     ap.add_argument("--small", action="store_true", help="tiny model (depth 1) for smoke runs")
     ap.add_argument("--data", type=str, default=None, help="directory of clips (videos{i}/*.npy|npz|mp4...): the host input pipeline")
     ap.add_argument("--num_workers", type=int, default=4)
+    ap.add_argument("--eager", action="store_true", help="never capture: every step through the eager L.train_step")
+    ap.add_argument("--capture_after", type=int, default=1, help="eager steps of a (batch, frames) shape before its step is captured as a hipGraph")
+    ap.add_argument("--log_every", type=int, default=10)
+    ap.add_argument("--sample_every", type=int, default=0,
+                    help="every N steps write the reconstruction and the original of one clip under --sample_dir (rl_nonadversarial.py:337-343: 500)")
+    ap.add_argument("--sample_dir", type=str, default=None)
+    ap.add_argument("--sample_ext", default="npz", choices=["npz", "npy", "mp4"], help="mp4 needs ffmpeg on PATH (data.batch_to_video)")
+    ap.add_argument("--eval_steps", type=int, default=0, help="batches per epoch through eval_step after the epoch's training (:362-391)")
+    ap.add_argument("--eval_data", type=str, default=None, help="directory of evaluation clips (default: synthetic / --data)")
     ap.add_argument("--vgg", type=str, default=None,
                     help="perceptual loss (rl flavour; rl_nonadversarial.py:125,272-274): 'random' = randomly initialised VGG16 head, or the "
                          "path of an .npz / .pt with its six tensors (the ImageNet weights are a remote download in the reference)")
@@ -100,42 +170,91 @@ def main():
         vgg, vgg_params = perceptual.load_vgg(None if args.vgg == "random" else args.vgg, device=dev)
         ploss = perceptual.get_adversarial_perceptual_loss_fn(vgg)
     rngs = V.Rngs(3 + rank)
+    log = (lambda msg: print(msg, flush=True)) if rank == 0 else (lambda msg: None)
+    runner = StepRunner(model, opt, hw, rngs, ploss, vgg_params, use_graph=not args.eager, capture_after=args.capture_after, log=log)
+    if args.sample_every and not args.sample_dir:
+        ap.error("--sample_every needs --sample_dir")
+
+    def loader(epoch, bsz, frames, directory, salt):
+        if directory:
+            from video_vae_amd import data as D
+            host = D.create_batched_dataloader(directory, batch_size=bsz, max_frames=frames, resize=(size, size), crop_size=size,
+                                               shuffle=True, seed=SEED + epoch, num_workers=args.num_workers, prefetch_size=16,
+                                               drop_remainder=True, rank=rank, num_epochs=1, as_uint8=True)
+            return D.DevicePrefetcher(host, dev, dtype=torch.bfloat16)       # the cast of :330 rides in the H2D side stream
+        return synthetic_batches(bsz, frames, (size, size), SEED + epoch + 1000 * rank + salt, max(args.steps, args.eval_steps), dev)
+
+    def dump(tag, epoch, i, batch, recon, bsz):
+        from video_vae_amd import data as D
+        d = os.path.join(args.sample_dir, f"{tag}/epoch{epoch}")
+        os.makedirs(d, exist_ok=True)
+        D.batch_to_video({"video": recon[:bsz], "mask": batch["mask"]}, os.path.join(d, f"video_{i}_latent.{args.sample_ext}"), fps=30.0)
+        D.batch_to_video(batch, os.path.join(d, f"video_{i}_original.{args.sample_ext}"), fps=30.0)
+
     start, global_step = time.perf_counter(), 0
     for epoch in range(args.epochs):
         max_mult = min(int(math.log2(max(args.per_device_batch_size, 1))), int(math.log2(64 / args.max_frames)) - 1)
         mult = max(0, min(epoch, max_mult))                       # batch <-> frames curriculum, :287-295
         bsz, frames = args.per_device_batch_size // (2 ** mult), args.max_frames * (2 ** mult)
-        if args.data:
-            from video_vae_amd import data as D
-            host = D.create_batched_dataloader(args.data, batch_size=bsz, max_frames=frames, resize=(size, size), crop_size=size,
-                                               shuffle=True, seed=SEED + epoch, num_workers=args.num_workers, prefetch_size=16,
-                                               drop_remainder=True, rank=rank, num_epochs=1, as_uint8=True)
-            batches = D.DevicePrefetcher(host, dev, dtype=torch.float32)
-        else:
-            batches = synthetic_batches(bsz, frames, (size, size), SEED + epoch + 1000 * rank, args.steps, dev)
-        for i, batch in enumerate(batches):
+        for i, batch in enumerate(loader(epoch, bsz, frames, args.data, 0)):
             if _SHOULD_STOP or i >= args.steps:
                 break
             if i > NEGATIVE_PENALTY_TRAINING_STEPS:
                 hparams["max_compression_rate"] = 10000
             video = batch["video"].to(torch.bfloat16)             # :330
-            loss, aux = L.train_step(model, opt, video, batch["mask"], hparams, hw, rngs, ploss, vgg_params)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                                           # step i = this event -> the next step's (bench.py's per-step clock)
+            loss, aux = runner(video, batch["mask"], hparams)
+            TIMES.append((ev, runner.mode))
             global_step += 1
-            if i % 10 == 0 or i == args.steps - 1:
+            if args.sample_every and i % args.sample_every == args.sample_every - 1 and rank == 0:
+                recon = aux.get("reconstruction")
+                if recon is None:                                 # a replayed step keeps no reconstruction: one eval pass on this batch
+                    recon = L.eval_step(model, video, batch["mask"], hparams, hw, rngs, ploss, vgg_params)[1]["reconstruction"]
+                dump("train", epoch, i, batch, recon, bsz)
+            if i % args.log_every == 0 or i == args.steps - 1:
                 keys = [k for k in aux if k != "reconstruction"]
                 vals = [loss] + [aux[k] for k in keys]
                 if world > 1:
                     vals = ddp.all_reduce_mean_scalars(vals)
                 if rank == 0:
                     msg = ", ".join(f"{k} = {float(v):.4f}" for k, v in zip(["Loss"] + keys, vals))
-                    print(f"Epoch {epoch}, Step {i}: {msg}, lr = {opt.last_lr:.3e}, time = {time.perf_counter() - start:.2f}", flush=True)
+                    print(f"Epoch {epoch}, Step {i}: {msg}, lr = {opt.last_lr:.3e}, time = {time.perf_counter() - start:.2f}, "
+                          f"mode = {runner.mode}, effective_batch_size = {bsz}, effective_max_frames = {frames}", flush=True)
         if args.save_dir and rank == 0:
             tag = "checkpoint_sigterm" if _SHOULD_STOP else "checkpoint"
             V.save_checkpoint(model, opt, os.path.join(args.save_dir, f"{tag}_{epoch}"))
+        if args.eval_steps and not _SHOULD_STOP:
+            for i, batch in enumerate(loader(epoch, bsz, frames, args.eval_data or args.data, 500_000)):
+                if _SHOULD_STOP or i >= args.eval_steps:
+                    break
+                video = batch["video"].to(torch.bfloat16)
+                loss, aux = L.eval_step(model, video, batch["mask"], hparams, hw, rngs, ploss, vgg_params)
+                if args.sample_every and i % 100 == 0 and rank == 0:
+                    dump("eval", epoch, i, batch, aux["reconstruction"], bsz)
+                keys = [k for k in aux if k != "reconstruction"]
+                vals = [loss] + [aux[k] for k in keys]
+                if world > 1:
+                    vals = ddp.all_reduce_mean_scalars(vals)
+                if rank == 0:
+                    msg = ", ".join(f"{k} = {float(v):.4f}" for k, v in zip(["Loss"] + keys, vals))
+                    print(f"VALIDATION Epoch {epoch}, Step {i}: {msg}, effective_batch_size = {bsz}, effective_max_frames = {frames}", flush=True)
         if world > 1:
             dist.barrier()
         if _SHOULD_STOP:
             break
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    torch.cuda.synchronize()
+    if rank == 0 and TIMES:
+        by_mode = {}
+        for (a, mode), (b, mode_next) in zip(TIMES, TIMES[1:] + [(end, None)]):
+            if mode_next in (mode, None):                              # a step followed by a capture is not a steady-state step
+                by_mode.setdefault(mode, []).append(a.elapsed_time(b))
+        for mode, ts in by_mode.items():
+            tail = ts[len(ts) // 5:] if len(ts) >= 10 else ts          # the first fifth carries clock ramp and allocator warm-up
+            print(f"train summary: {len(ts)} {mode} steps, median {statistics.median(tail):.2f} ms/step over the last {len(tail)} "
+                  f"(logging every {args.log_every} steps included)", flush=True)
     if world > 1:
         dist.destroy_process_group()
 
