@@ -4,6 +4,9 @@ import torch
 sys.path.insert(0, ".")
 from video_vae_amd import ops
 from video_vae_amd._lib import lib
+import os, video_vae_amd._lib as _L
+if os.environ.get("VVAE_AB_LIB"):        # A/B against another build of the library (tools only)
+    _L.LIB_PATH = os.environ["VVAE_AB_LIB"]
 sys.path.insert(0, "tools")
 from conv_bench_util import tmg
 

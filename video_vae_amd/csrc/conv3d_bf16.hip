@@ -514,8 +514,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int row16_byte
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CIB_, int COB_, int KH_, int KW_, int TH_, int AG_, int RG_, int MINW_, int BPC_>
+template <int CIB_, int COB_, int KH_, int KW_, int TH_, int AG_, int RG_, int MINW_, int BPC_, int PD_ = 1>
 struct WgCfg {
+    static constexpr int PD = PD_;                                           // X planes / dY tiles in flight per workgroup (1 or 2)
     static constexpr int CIB = CIB_, COB = COB_, KT = 3, KH = KH_, KW = KW_, TH = TH_, TW = 32;
     static constexpr int CIT = CIB / 16, COT = COB / 16;
     static constexpr int AG = AG_, AGS = (KH + AG - 1) / AG;                 // kernel rows dy are split into AG groups of AGS rows
@@ -596,10 +597,14 @@ enum { W_REG = 1, W_LDS = 2 };
 // CR_ < CKB_: only the first CR_ of a voxel's CKB_ channels are real (the rest is zero padding in memory): LDS voxels are packed to
 // 2 CR_ bytes, K runs over (dt, dx, ci < CR_) and a lane's 8-element run is read as two 8-byte halves (a half never straddles a
 // frame plane: KW * CR_ is a multiple of 4).
-template <int CKB_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_, int WMODE_, bool PF_, int CR_ = CKB_>
+// PD_: halo planes in flight per workgroup (1 or 2).  2 costs one more plane of staging registers (12-20 VGPRs): the 4-wave configurations
+// have them, the 8-wave ones (256-register cap, 108 of them resident weights) would spill.
+template <int CKB_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_, int WMODE_, bool PF_, int CR_ = CKB_, int PD_ = 1>
 struct RollCfg {
     static constexpr int CKB = CKB_, KT = 3, KH = KH_, KW = KW_, MT_W = MT_W_, NT_W = NT_W_, WM = WM_, WN = WN_, WMODE = WMODE_, CR = CR_;
     static constexpr bool PF = PF_;                          // request the fragments of k-step j+1 before multiplying k-step j
+    static constexpr int PD = PD_;
+    static_assert(PD == 1 || PD == 2, "planes in flight");
     static constexpr int NTHREADS = 64 * WM * WN;
     static constexpr int TH = MT_W * WM, TW = 16, HR = TH + KH - 1, WR = TW + KW - 1;
     static constexpr int PITCH = 2 * CR;
@@ -680,7 +685,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
     sx.store(smem + ((t_beg - 1) & 3) * PLANE, tid);
     sx.fetch(x, ldx, n, t_beg, hx, wx, d.T, d.H, d.W, tid);
     sx.store(smem + (t_beg & 3) * PLANE, tid);
+    // TWO planes in flight per workgroup: plane tt + 1 is parked at the top of step tt, plane tt + 2 is already on its way in the second
+    // register set.  With one plane in flight a step could not be shorter than a memory round trip (a 16 -> 16 step is 0.45 us of matrix
+    // work against 1-2 us of loaded-HBM latency: the 256^2 layers ran at half the HBM rate with the matrix pipes 38 % busy).
+    PlaneStager<C::NTHREADS, HR, WR, CKB / 8, PITCH, C::SWZ> sx2;
     sx.fetch(x, ldx, n, t_beg + 1, hx, wx, d.T, d.H, d.W, tid);
+    if (C::PD == 2 && t_beg + 1 < t_end) sx2.fetch(x, ldx, n, t_beg + 2, hx, wx, d.T, d.H, d.W, tid);
     const int wo = w0 + r;
     const int lin_w = (wm * MT_W) * WR + r;                                // this lane's voxel in the wave's first halo row
     // GroupNorm partials per channel PAIR (a group is an even number of consecutive channels): v_dot2c_f32_bf16 adds the two
@@ -690,10 +700,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
     for (int i = 0; i < (GN ? NT_W : 1); ++i)
 #pragma unroll
         for (int e = 0; e < 2; ++e) { gs[i][e] = 0.f; gss[i][e] = 0.f; }
-    for (int tt = t_beg; tt < t_end; ++tt) {
-        sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
-        __syncthreads();
-        if (tt + 1 < t_end) sx.fetch(x, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
+    auto frame = [&](int tt) {
 
         f32x4 acc[MT_W][NT_W];
 #pragma unroll
@@ -794,6 +801,26 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
                 }
             }
         }
+    };
+    if (C::PD == 2) {
+        for (int tt = t_beg; tt < t_end; tt += 2) {
+            sx.store(smem + ((tt + 1) & 3) * PLANE, tid);                   // waits for plane tt + 1 only: plane tt + 2 stays in flight
+            __syncthreads();
+            if (tt + 2 < t_end) sx.fetch(x, ldx, n, tt + 3, hx, wx, d.T, d.H, d.W, tid);
+            frame(tt);
+            if (tt + 1 >= t_end) break;
+            sx2.store(smem + ((tt + 2) & 3) * PLANE, tid);
+            __syncthreads();
+            if (tt + 3 < t_end) sx2.fetch(x, ldx, n, tt + 4, hx, wx, d.T, d.H, d.W, tid);
+            frame(tt + 1);
+        }
+    } else {
+        for (int tt = t_beg; tt < t_end; ++tt) {
+            sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
+            __syncthreads();
+            if (tt + 1 < t_end) sx.fetch(x, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
+            frame(tt);
+        }
     }
     if (GN) {
         // fold: the 16 voxel lanes of a channel quad (xor-shuffles), then the WM waves that share the channels (LDS), then the
@@ -877,8 +904,8 @@ int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf
 typedef RollCfg<16, 7, 7, 2, 1, 8, 1, W_LDS, true> R377;         // patch mixer: TH 16, 77 KB of weights behind a 61 KB ring
 typedef RollCfg<16, 7, 7, 4, 1, 8, 1, W_LDS, true, 12> R377_12;  // ... with 12 real of its 16 K channels: 8 k-steps instead of 11, and
                                                                  // TH 32: a weight fragment read from LDS feeds 4 output rows
-typedef RollCfg<16, 3, 3, 4, 1, 4, 1, W_REG, false> R16_16;      // TH 16
-typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false> R16_32;      // TH 8, one output-channel tile per wave
+typedef RollCfg<16, 3, 3, 4, 1, 4, 1, W_REG, false, 16, 2> R16_16;   // TH 16, two planes in flight
+typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false, 16, 2> R16_32;   // TH 8, one output-channel tile per wave, two planes in flight
 typedef RollCfg<32, 3, 3, 4, 1, 8, 1, W_REG, false> R32_16;      // TH 32, 8 waves, 157 KB ring (TH 16 with 2 rows per wave read 4 X
                                                                  // fragments per 6 products: 153 -> 129 us at 256^2; taller tiles lose elsewhere)
 typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false> R32_32;      // TH 16, 8 waves, one output-channel tile per wave
@@ -946,6 +973,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
 
     PlaneStager<C::NTHREADS, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx;
     PlaneStager<C::NTHREADS, TH, TW, COB / 8, PY> sy;
+    PlaneStager<C::NTHREADS, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx2;      // PD == 2 only
+    PlaneStager<C::NTHREADS, TH, TW, COB / 8, PY> sy2;
     const bf16_t* xsrc = x + ci0;
     const bf16_t* ysrc = dy + co0;
     if (sp.x2 && ci0 + (int)(threadIdx.x % (WR * (CIB / 8))) % (CIB / 8) * 8 >= sp.xsplit) {   // this thread stages a 16-byte part of x2
@@ -970,14 +999,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
         sx.store(ring, tid);
         sx.fetch(xsrc, ldx, n, 1, hx, wx, d.T, d.H, d.W, tid);
         sy.fetch(ysrc, lddy, n, 0, h0, w0, d.T, d.H, d.W, tid);
-        for (int tt = 0; tt < d.T; ++tt) {
-            sx.store(ring + ((tt + 1) & 3) * C::PLANE, tid);      // plane tt+1 (zeros past the end)
-            sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
-            __syncthreads();
-            if (tt + 1 < d.T) {                                   // next step's operands fly while this step computes
-                sx.fetch(xsrc, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
-                sy.fetch(ysrc, lddy, n, tt + 1, h0, w0, d.T, d.H, d.W, tid);
-            }
+        if (C::PD == 2 && d.T > 1) {                              // second register set: plane 2 and dY tile 1 are on their way too
+            sx2.fetch(xsrc, ldx, n, 2, hx, wx, d.T, d.H, d.W, tid);
+            sy2.fetch(ysrc, lddy, n, 1, h0, w0, d.T, d.H, d.W, tid);
+        }
+        auto step = [&](int tt) {
             const unsigned char* ys = ybuf + (tt & 1) * C::YBYTES + loffy + r0 * (TW * PY);
             // halo rows r0 + a0 + rr, rr = 0 .. THR+AGS-2, meet kernel rows a0 + aa at output rows r0 + h, h = rr - aa
             const unsigned char* xplane = ring + ((tt + dt - 1) & 3) * C::PLANE + (r0 + a0) * (C::WRP * PX) + 8 * pp;
@@ -1001,6 +1027,39 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
                             acc[aa][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[h % AGS], acc[aa][b], 0, 0, 0);
                     }
                 }
+            }
+        };
+        if (C::PD == 2) {
+            // two steps' operands in flight: a step of the 16-channel layers is ~0.5 us of matrix work against 1-2 us of loaded-HBM latency
+            for (int tt = 0; tt < d.T; tt += 2) {
+                sx.store(ring + ((tt + 1) & 3) * C::PLANE, tid);
+                sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
+                __syncthreads();
+                if (tt + 2 < d.T) {
+                    sx.fetch(xsrc, ldx, n, tt + 3, hx, wx, d.T, d.H, d.W, tid);
+                    sy.fetch(ysrc, lddy, n, tt + 2, h0, w0, d.T, d.H, d.W, tid);
+                }
+                step(tt);
+                if (tt + 1 >= d.T) break;
+                sx2.store(ring + ((tt + 2) & 3) * C::PLANE, tid);
+                sy2.store(ybuf + ((tt + 1) & 1) * C::YBYTES, tid);
+                __syncthreads();
+                if (tt + 3 < d.T) {
+                    sx2.fetch(xsrc, ldx, n, tt + 4, hx, wx, d.T, d.H, d.W, tid);
+                    sy2.fetch(ysrc, lddy, n, tt + 3, h0, w0, d.T, d.H, d.W, tid);
+                }
+                step(tt + 1);
+            }
+        } else {
+            for (int tt = 0; tt < d.T; ++tt) {
+                sx.store(ring + ((tt + 1) & 3) * C::PLANE, tid);      // plane tt+1 (zeros past the end)
+                sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
+                __syncthreads();
+                if (tt + 1 < d.T) {                                   // next step's operands fly while this step computes
+                    sx.fetch(xsrc, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
+                    sy.fetch(ysrc, lddy, n, tt + 1, h0, w0, d.T, d.H, d.W, tid);
+                }
+                step(tt);
             }
         }
     }
@@ -1064,10 +1123,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 //            CIB COB KH KW TH AG RG MINW workgroups/CU
-typedef WgCfg<16, 16, 3, 3, 8, 1, 1, 2, 2> W333_16_16;       //  3 waves
+typedef WgCfg<16, 16, 3, 3, 8, 1, 1, 2, 2, 2> W333_16_16;    //  3 waves, two steps' operands in flight
 typedef WgCfg<32, 16, 3, 3, 8, 1, 2, 3, 1> W333_32_16;       // 12 waves: two row groups of an 8-row tile
 typedef WgCfg<32, 32, 3, 3, 4, 1, 1, 3, 1> W333_32_32;       // 12 waves
-typedef WgCfg<16, 16, 7, 7, 4, 4, 1, 3, 1> W377_16_16;       // 12 waves: 3 temporal taps x 4 groups of kernel rows
+typedef WgCfg<16, 16, 7, 7, 4, 4, 1, 3, 1, 2> W377_16_16;    // 12 waves: 3 temporal taps x 4 groups of kernel rows
 
 int g_wg_cob16 = 0;                        // tuning: 1 = 16 output channels per workgroup even where Cin, Cout % 32 == 0
 int g_wg_blocks = 0;                       // tuning: > 0 overrides the persistent grid size

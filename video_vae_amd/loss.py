@@ -134,7 +134,9 @@ def train_step(model, optimizer, video, mask, hparams, hw, rngs, perceptual_loss
     with ops.deferred_wgrad(optimizer):
         loss.backward()
     optimizer.update()
-    return loss.detach(), aux
+    # detached: a caller that keeps the aux of step i while step i + 1 is captured as a hipGraph must not keep step i's autograd graph
+    # (and with it AccumulateGrad nodes pinned to this stream) alive -- graph.GraphedTrainStep captures on a stream of its own
+    return loss.detach(), {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in aux.items()}
 
 
 @torch.no_grad()

@@ -88,6 +88,7 @@ class StepRunner:
                 torch.cuda.empty_cache()
             try:
                 t0 = time.perf_counter()
+                gc.collect()                                     # no autograd graph of an eager step may outlive into the capture
                 g = GraphedTrainStep(self.model, self.opt, video, mask, dict(hparams), self.hw, V.Rngs(1_000_003 * (self.rngs.seed + 1) + len(self.seen)),
                                      perceptual_loss_fn=self.ploss, vgg_params=self.vgg_params)
                 self.graphs[shape] = (hkey, g)
