@@ -22,6 +22,24 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// Buffer-descriptor access (hardware range check): a load whose offset lies outside the descriptor returns zeros, a store there is
+// dropped.  The halo stagers and epilogues below therefore issue EVERY load / store unconditionally, with the offset of an out-of-volume
+// voxel set to OOB: no exec-masked branches in the march loop, so the compiler can COUNT the outstanding memory operations and waits
+// for the halo plane with s_waitcnt vmcnt(stores behind it) instead of vmcnt(0) -- with predicated loads it lost count, and every step
+// of the march waited for the previous step's output stores to drain (and for the second plane in flight) before it parked its plane.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned OOB = 0x80000000u;                         // descriptors span < 2 GiB (checked by the launchers)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, unsigned off, uint2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)off, 0, 0);
+}
+
 template <int CKB_, int KT_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_>
 struct ConvCfg {
     static constexpr int CKB = CKB_, KT = KT_, KH = KH_, KW = KW_, MT_W = MT_W_, NT_W = NT_W_, WM = WM_, WN = WN_;
@@ -38,6 +56,8 @@ struct ConvCfg {
 };
 
 struct BfDims { int N, T, H, W, CK, CO, tiles_h, tiles_w; };
+// bytes a (voxel, channel) tensor with row pitch ld spans from its first element (the extent of its buffer descriptor)
+inline __host__ __device__ long span_bytes(long vox, int ld, int ch) { return ((vox - 1) * ld + ch) * 2; }
 
 // Optional second tensor on either side of a single-chunk layer (the decoder's concat([up, skip]) at 16 + 16 channels, reference
 // train/unet.py:79, without the joint buffer: a producer that writes a 32-byte channel half of 64-byte voxels runs at a third of the
@@ -423,6 +443,8 @@ extern "C" int vvae_conv3d_gn_blocks(int N, int T, int H, int W, int Cin, int Co
 {
     if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || !vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ld_in, ld_out, 0, 0)) return 0;
     if (Cin != chunk_of(Cin)) return 0;
+    const long vox = (long)N * T * H * W;
+    if (span_bytes(vox, ld_in, Cin) >= (1L << 31) || span_bytes(vox, ld_out, Cout) >= (1L << 31)) return 0;    // see launch_roll
     BfDims d{N, T, H, W, Cin, Cout, 0, 0};
     return roll_gn_blocks_any(d, kh, groups);
 }
@@ -560,6 +582,22 @@ struct PlaneStager {
             if (ok0 && hr < HR && (unsigned)hi < (unsigned)H) v[it] = *reinterpret_cast<const uint4*>(col + hi * rowstride);
         }
     }
+    // The same through a buffer descriptor: every load is issued, out-of-volume pieces with an OOB offset (-> zeros).
+    // ``c0``: first channel of the tile within the tensor.
+    __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t r, int ld, int c0, int n, int t, int h0, int w0, int T, int H, int W, int tid) {
+        const int rip = tid / ROW_ITEMS, item = tid - rip * ROW_ITEMS;
+        const int wc = item / PARTS, part = item - wc * PARTS;
+        const int wi = w0 + wc;
+        const bool ok0 = rip < RPP && (unsigned)wi < (unsigned)W && (unsigned)t < (unsigned)T;
+        const unsigned col = (unsigned)((((long)n * T + t) * H * (long)W + wi) * ld + c0 + part * 8) * 2u;
+        const unsigned rowstride = (unsigned)W * (unsigned)ld * 2u;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int hr = rip + it * RPP, hi = h0 + hr;
+            const bool ok = ok0 && hr < HR && (unsigned)hi < (unsigned)H;
+            v[it] = buf_load16(r, ok ? col + (unsigned)hi * rowstride : OOB);
+        }
+    }
     __device__ __forceinline__ void store(unsigned char* __restrict__ lds, int tid) const {
         const int rip = tid / ROW_ITEMS, item = tid - rip * ROW_ITEMS;
         const int wc = item / PARTS, part = item - wc * PARTS;
@@ -621,7 +659,9 @@ struct RollCfg {
 
 // GN: the workgroup also emits, per GroupNorm group, the sum and the sum of squares of the (bf16-rounded) outputs it wrote --
 // one row of the partial buffer gn_stats would have produced by re-reading the whole tensor: part[n][blk][group][2].
-template <class C, bool GN>
+// TWO: a second tensor on one side (Split2): that instantiation keeps per-thread pointers and predicated accesses (a lane's tensor is
+// not wave-uniform, a buffer descriptor is); the one-tensor instantiations go through descriptors and have a branch-free march loop.
+template <class C, bool GN, bool TWO>
 __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wp,
                                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy,
                                                                        BfDims d, int tchunk, float* __restrict__ gn_part, int gn_groups,
@@ -631,7 +671,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
     constexpr int CKB = C::CKB, KT = C::KT, KH = C::KH, KW = C::KW, MT_W = C::MT_W, NT_W = C::NT_W;
     constexpr int HR = C::HR, WR = C::WR, PITCH = C::PITCH, KSTEPS = C::KSTEPS, PLANE = C::PLANE, CO_T = C::CO_T;
     constexpr bool WREG = C::WMODE == W_REG;
-    if (sp.x2 && (int)(threadIdx.x % (WR * (CKB / 8))) % (CKB / 8) * 8 >= sp.xsplit) {     // this thread stages a 16-byte part of x2
+    const long vox_all = (long)d.N * d.T * d.H * d.W;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, TWO ? 0u : (unsigned)span_bytes(vox_all, ldx, d.CK));
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, TWO ? 0u : (unsigned)span_bytes(vox_all, ldy, d.CO));
+    if (TWO && sp.x2 && (int)(threadIdx.x % (WR * (CKB / 8))) % (CKB / 8) * 8 >= sp.xsplit) {     // this thread stages a 16-byte part of x2
         x = sp.x2 - sp.xsplit;
         ldx = sp.ldx2;
     }
@@ -681,16 +724,33 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
 
     PlaneStager<C::NTHREADS, HR, WR, CKB / 8, PITCH, C::SWZ> sx;
     const int hx = h0 - KH / 2, wx = w0 - KW / 2;
-    sx.fetch(x, ldx, n, t_beg - 1, hx, wx, d.T, d.H, d.W, tid);            // out-of-range frames come back as zeros
+#define FETCH(S, T_) do { if (TWO) (S).fetch(x, ldx, n, (T_), hx, wx, d.T, d.H, d.W, tid); else (S).fetch(rx, ldx, 0, n, (T_), hx, wx, d.T, d.H, d.W, tid); } while (0)
+    FETCH(sx, t_beg - 1);                                                  // out-of-range frames come back as zeros
     sx.store(smem + ((t_beg - 1) & 3) * PLANE, tid);
-    sx.fetch(x, ldx, n, t_beg, hx, wx, d.T, d.H, d.W, tid);
+    FETCH(sx, t_beg);
     sx.store(smem + (t_beg & 3) * PLANE, tid);
     // TWO planes in flight per workgroup: plane tt + 1 is parked at the top of step tt, plane tt + 2 is already on its way in the second
     // register set.  With one plane in flight a step could not be shorter than a memory round trip (a 16 -> 16 step is 0.45 us of matrix
     // work against 1-2 us of loaded-HBM latency: the 256^2 layers ran at half the HBM rate with the matrix pipes 38 % busy).
     PlaneStager<C::NTHREADS, HR, WR, CKB / 8, PITCH, C::SWZ> sx2;
-    sx.fetch(x, ldx, n, t_beg + 1, hx, wx, d.T, d.H, d.W, tid);
-    if (C::PD == 2 && t_beg + 1 < t_end) sx2.fetch(x, ldx, n, t_beg + 2, hx, wx, d.T, d.H, d.W, tid);
+    // The march loop below is straight-line code: every fetch and every store is issued in every step (a frame index past the chunk
+    // becomes -1 -> all offsets OOB -> zeros without traffic).  The prologue is made to LOOK like a loop iteration to the compiler's wait
+    // counting -- the same number of (dropped, OOB) stores behind each plane request as a step's epilogue issues -- so that the wait in
+    // front of a plane's LDS store is vmcnt(memory operations issued behind that plane's loads), the same number on the loop's entry and
+    // back edges, instead of the conservative vmcnt(0) a mismatch between the two collapses to.
+    constexpr int STORES = MT_W * NT_W;
+    FETCH(sx, t_beg + 1);
+    if (!TWO) {
+#pragma unroll
+        for (int i = 0; i < STORES; ++i) buf_store8(ry, OOB, make_uint2(0, 0));
+    }
+    if (C::PD == 2) {
+        FETCH(sx2, t_beg + 1 < t_end ? t_beg + 2 : -1);
+        if (!TWO) {
+#pragma unroll
+            for (int i = 0; i < STORES; ++i) buf_store8(ry, OOB, make_uint2(0, 0));
+        }
+    }
     const int wo = w0 + r;
     const int lin_w = (wm * MT_W) * WR + r;                                // this lane's voxel in the wave's first halo row
     // GroupNorm partials per channel PAIR (a group is an even number of consecutive channels): v_dot2c_f32_bf16 adds the two
@@ -782,18 +842,25 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
 #pragma unroll
         for (int m = 0; m < MT_W; ++m) {
             const int ho = h0 + wm * MT_W + m;
-            if (ho >= d.H || wo >= d.W) continue;
+            const bool inside = ho < d.H && wo < d.W;                  // outside: the store is issued with an OOB offset and dropped
             const long v = (((long)n * d.T + tt) * d.H + ho) * d.W + wo;
 #pragma unroll
             for (int i = 0; i < NT_W; ++i) {
                 uint2 o;
                 o.x = (uint32_t)f2bf(acc[m][i][0] + bv[i][0]) | ((uint32_t)f2bf(acc[m][i][1] + bv[i][1]) << 16);
                 o.y = (uint32_t)f2bf(acc[m][i][2] + bv[i][2]) | ((uint32_t)f2bf(acc[m][i][3] + bv[i][3]) << 16);
-                if (sp.y2 && (ct0 + i) * 16 >= sp.ysplit) *reinterpret_cast<uint2*>(sp.y2 + v * sp.ldy2 + (ct0 + i) * 16 - sp.ysplit + 4 * g) = o;
-                else *reinterpret_cast<uint2*>(y + v * ldy + (ct0 + i) * 16 + 4 * g) = o;
+                const int c0 = (ct0 + i) * 16 + 4 * g;
+                if (TWO) {                                         // produced channels >= ysplit live in the second tensor
+                    if (inside) {
+                        if (sp.y2 && c0 >= sp.ysplit) *reinterpret_cast<uint2*>(sp.y2 + v * sp.ldy2 + c0 - sp.ysplit) = o;
+                        else *reinterpret_cast<uint2*>(y + v * ldy + c0) = o;
+                    }
+                } else {
+                    buf_store8(ry, inside ? (unsigned)(v * ldy + c0) * 2u : OOB, o);
+                }
                 if (GN) {                                          // statistics of what GroupNorm will read: the rounded values
                     const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3f803f80u);
-                    const bf16x2 p0 = __builtin_bit_cast(bf16x2, o.x), p1 = __builtin_bit_cast(bf16x2, o.y);
+                    const bf16x2 p0 = __builtin_bit_cast(bf16x2, inside ? o.x : 0u), p1 = __builtin_bit_cast(bf16x2, inside ? o.y : 0u);
                     gs[i][0] = __builtin_amdgcn_fdot2_f32_bf16(p0, ones, gs[i][0], false);
                     gs[i][1] = __builtin_amdgcn_fdot2_f32_bf16(p1, ones, gs[i][1], false);
                     gss[i][0] = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, gss[i][0], false);
@@ -806,22 +873,23 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
         for (int tt = t_beg; tt < t_end; tt += 2) {
             sx.store(smem + ((tt + 1) & 3) * PLANE, tid);                   // waits for plane tt + 1 only: plane tt + 2 stays in flight
             __syncthreads();
-            if (tt + 2 < t_end) sx.fetch(x, ldx, n, tt + 3, hx, wx, d.T, d.H, d.W, tid);
+            FETCH(sx, tt + 2 < t_end ? tt + 3 : -1);
             frame(tt);
             if (tt + 1 >= t_end) break;
             sx2.store(smem + ((tt + 2) & 3) * PLANE, tid);
             __syncthreads();
-            if (tt + 3 < t_end) sx2.fetch(x, ldx, n, tt + 4, hx, wx, d.T, d.H, d.W, tid);
+            FETCH(sx2, tt + 3 < t_end ? tt + 4 : -1);
             frame(tt + 1);
         }
     } else {
         for (int tt = t_beg; tt < t_end; ++tt) {
             sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
             __syncthreads();
-            if (tt + 1 < t_end) sx.fetch(x, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
+            FETCH(sx, tt + 1 < t_end ? tt + 2 : -1);
             frame(tt);
         }
     }
+#undef FETCH
     if (GN) {
         // fold: the 16 voxel lanes of a channel quad (xor-shuffles), then the WM waves that share the channels (LDS), then the
         // channels of each group -- fixed order, no atomics
@@ -887,13 +955,17 @@ int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf
                 float* gn_part, int gn_groups, Split2 sp)
 {
     const int tchunk = roll_tchunk<C>(d);
+    const long vox = (long)d.N * d.T * d.H * d.W, lim = 1L << 31;              // buffer descriptors: 32-bit offsets, OOB = 2^31
+    if (span_bytes(vox, ldx, d.CK) >= lim || span_bytes(vox, ldy, d.CO) >= lim || (sp.x2 && span_bytes(vox, sp.ldx2, d.CK) >= lim) ||
+        (sp.y2 && span_bytes(vox, sp.ldy2, d.CO) >= lim)) return VVAE_ERR_BAD_ARG;
     dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk)), d.CO / C::CO_BLK);
-    auto k = conv3d_bf16_roll_kernel<C, GN>;
-    static bool attr_done = false;
-    if (C::LDS_BYTES > 65536 && !attr_done) {
+    const bool two = sp.x2 || sp.y2;
+    auto k = two ? conv3d_bf16_roll_kernel<C, GN, true> : conv3d_bf16_roll_kernel<C, GN, false>;
+    static bool attr_done[2] = {false, false};
+    if (C::LDS_BYTES > 65536 && !attr_done[two]) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[two] = true;
     }
     hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk, gn_part, gn_groups, sp);
     VVAE_LAUNCH_CHECK();
@@ -938,7 +1010,7 @@ int roll_gn_blocks_any(BfDims d, int kh, int groups)
     return 0;
 }
 
-template <class C>
+template <class C, bool TWO>
 __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx,
                                                                                  const bf16_t* __restrict__ dy, int lddy,
                                                                                  float* __restrict__ slab, WgDims d, Split2 sp)
@@ -975,12 +1047,17 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
     PlaneStager<C::NTHREADS, TH, TW, COB / 8, PY> sy;
     PlaneStager<C::NTHREADS, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx2;      // PD == 2 only
     PlaneStager<C::NTHREADS, TH, TW, COB / 8, PY> sy2;
+    // one input tensor: buffer descriptors (unconditional loads, see make_rsrc); TWO: per-thread pointers as a lane's tensor is not uniform
+    const long vox_all = (long)d.N * d.T * d.H * d.W;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, TWO ? 0u : (unsigned)span_bytes(vox_all, ldx, d.CI));
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (unsigned)span_bytes(vox_all, lddy, d.CO));
     const bf16_t* xsrc = x + ci0;
-    const bf16_t* ysrc = dy + co0;
-    if (sp.x2 && ci0 + (int)(threadIdx.x % (WR * (CIB / 8))) % (CIB / 8) * 8 >= sp.xsplit) {   // this thread stages a 16-byte part of x2
+    if (TWO && sp.x2 && ci0 + (int)(threadIdx.x % (WR * (CIB / 8))) % (CIB / 8) * 8 >= sp.xsplit) {   // this thread stages a 16-byte part of x2
         xsrc = sp.x2 + ci0 - sp.xsplit;
         ldx = sp.ldx2;
     }
+#define FX(S, T_) do { if (TWO) (S).fetch(xsrc, ldx, n, (T_), hx, wx, d.T, d.H, d.W, tid); else (S).fetch(rx, ldx, ci0, n, (T_), hx, wx, d.T, d.H, d.W, tid); } while (0)
+#define FY(S, T_) (S).fetch(rdy, lddy, co0, n, (T_), h0, w0, d.T, d.H, d.W, tid)
 
     // A workgroup walks whole time-columns: for a fixed (n, h-tile, w-tile) it marches t = 0..T-1, so every X plane is
     // fetched from memory once (not KT times) and lives in the LDS ring for the three steps that use it.
@@ -993,15 +1070,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
         const int h0 = th * TH, w0 = tw * TW;
         const int hx = h0 - KH / 2, wx = w0 - KW / 2;
         __syncthreads();                                          // previous column is done with the ring
-        sx.fetch(xsrc, ldx, n, -1, hx, wx, d.T, d.H, d.W, tid);   // plane -1 = zeros
+        FX(sx, -1);   // plane -1 = zeros
         sx.store(ring + 3 * C::PLANE, tid);
-        sx.fetch(xsrc, ldx, n, 0, hx, wx, d.T, d.H, d.W, tid);
+        FX(sx, 0);
         sx.store(ring, tid);
-        sx.fetch(xsrc, ldx, n, 1, hx, wx, d.T, d.H, d.W, tid);
-        sy.fetch(ysrc, lddy, n, 0, h0, w0, d.T, d.H, d.W, tid);
+        FX(sx, 1);
+        FY(sy, 0);
         if (C::PD == 2 && d.T > 1) {                              // second register set: plane 2 and dY tile 1 are on their way too
-            sx2.fetch(xsrc, ldx, n, 2, hx, wx, d.T, d.H, d.W, tid);
-            sy2.fetch(ysrc, lddy, n, 1, h0, w0, d.T, d.H, d.W, tid);
+            FX(sx2, 2);
+            FY(sy2, 1);
         }
         auto step = [&](int tt) {
             const unsigned char* ys = ybuf + (tt & 1) * C::YBYTES + loffy + r0 * (TW * PY);
@@ -1036,8 +1113,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
                 sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
                 __syncthreads();
                 if (tt + 2 < d.T) {
-                    sx.fetch(xsrc, ldx, n, tt + 3, hx, wx, d.T, d.H, d.W, tid);
-                    sy.fetch(ysrc, lddy, n, tt + 2, h0, w0, d.T, d.H, d.W, tid);
+                    FX(sx, tt + 3);
+                    FY(sy, tt + 2);
                 }
                 step(tt);
                 if (tt + 1 >= d.T) break;
@@ -1045,8 +1122,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
                 sy2.store(ybuf + ((tt + 1) & 1) * C::YBYTES, tid);
                 __syncthreads();
                 if (tt + 3 < d.T) {
-                    sx2.fetch(xsrc, ldx, n, tt + 4, hx, wx, d.T, d.H, d.W, tid);
-                    sy2.fetch(ysrc, lddy, n, tt + 3, h0, w0, d.T, d.H, d.W, tid);
+                    FX(sx2, tt + 4);
+                    FY(sy2, tt + 3);
                 }
                 step(tt + 1);
             }
@@ -1056,13 +1133,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
                 sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
                 __syncthreads();
                 if (tt + 1 < d.T) {                                   // next step's operands fly while this step computes
-                    sx.fetch(xsrc, ldx, n, tt + 2, hx, wx, d.T, d.H, d.W, tid);
-                    sy.fetch(ysrc, lddy, n, tt + 1, h0, w0, d.T, d.H, d.W, tid);
+                    FX(sx, tt + 2);
+                    FY(sy, tt + 1);
                 }
                 step(tt);
             }
         }
     }
+#undef FX
+#undef FY
     // ---- write this workgroup's partial sums: slab[block][dt][dy][dx][ci_local][co_local] (+ COB dbias partials) ----
     float* out = slab + (((long)blockIdx.x * C::RG + rgp) * gridDim.y + blockIdx.y) * C::SLAB_FLOATS;
     const int col = lane & 15, rg = lane >> 4;
@@ -1154,6 +1233,8 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
                      int CI, int CO, void* ws, size_t ws_bytes, hipStream_t s, Split2 sp = NO_SPLIT)
 {
     WgDims d{N, T, H, W, CI, CO, ceil_div(H, C::TH), ceil_div(W, C::TW), 0, 0};
+    const long vox = (long)N * T * H * W, lim = 1L << 31;                     // buffer descriptors: 32-bit offsets, OOB = 2^31
+    if (span_bytes(vox, ldx, CI) >= lim || span_bytes(vox, lddy, CO) >= lim || (sp.x2 && span_bytes(vox, sp.ldx2, CI) >= lim)) return VVAE_ERR_BAD_ARG;
     const long ncols = (long)N * d.tiles_h * d.tiles_w;
     const int nsub = (CI / C::CIB) * (CO / C::COB);
     const int nbx = wg_blocks_x<C>(ncols, nsub);
@@ -1161,12 +1242,13 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
     d.cols_per_block = ceil_div(ncols, nbx);
     const int nblk = ceil_div(ncols, d.cols_per_block);        // blocks that own at least one time-column
     if (!ws || ws_bytes < (size_t)nblk * C::RG * nsub * C::SLAB_FLOATS * sizeof(float)) return VVAE_ERR_WORKSPACE;
-    auto k = conv3d_wgrad_bf16_kernel<C>;
-    static bool attr_done = false;                 // once per instantiation: keeps the launch path free of non-stream calls
-    if (C::LDS_BYTES > 65536 && !attr_done) {      // (hipGraph capture of the training step replays only stream work)
+    const bool two = sp.x2 != nullptr;
+    auto k = two ? conv3d_wgrad_bf16_kernel<C, true> : conv3d_wgrad_bf16_kernel<C, false>;
+    static bool attr_done[2] = {false, false};     // once per instantiation: keeps the launch path free of non-stream calls
+    if (C::LDS_BYTES > 65536 && !attr_done[two]) { // (hipGraph capture of the training step replays only stream work)
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[two] = true;
     }
     hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d, sp);
     VVAE_LAUNCH_CHECK();
