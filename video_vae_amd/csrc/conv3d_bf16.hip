@@ -637,12 +637,17 @@ enum { W_REG = 1, W_LDS = 2 };
 // frame plane: KW * CR_ is a multiple of 4).
 // PD_: halo planes in flight per workgroup (1 or 2).  2 costs one more plane of staging registers (12-20 VGPRs): the 4-wave configurations
 // have them, the 8-wave ones (256-register cap, 108 of them resident weights) would spill.
-template <int CKB_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_, int WMODE_, bool PF_, int CR_ = CKB_, int PD_ = 1>
+// LA_ > 0 (register-resident weights only): the X fragments of a step form ONE stream of KSTEPS * (MT_W + KH - 1) LDS reads, kept LA_ reads ahead of
+// the products that consume them in a rotating window of LA_ + 1 fragments.  Left to itself the compiler issued each read right in front of its
+// first product and waited for it (r [lgkmcnt(0)] M M M r [lgkmcnt(0)] ...): 30 exposed LDS round trips per step and wave against 960 cycles of
+// matrix work -- the matrix pipes of the 16-channel layers were 38 % busy.
+template <int CKB_, int KH_, int KW_, int MT_W_, int NT_W_, int WM_, int WN_, int WMODE_, bool PF_, int CR_ = CKB_, int PD_ = 1, int LA_ = 0>
 struct RollCfg {
     static constexpr int CKB = CKB_, KT = 3, KH = KH_, KW = KW_, MT_W = MT_W_, NT_W = NT_W_, WM = WM_, WN = WN_, WMODE = WMODE_, CR = CR_;
     static constexpr bool PF = PF_;                          // request the fragments of k-step j+1 before multiplying k-step j
-    static constexpr int PD = PD_;
+    static constexpr int PD = PD_, LA = LA_;
     static_assert(PD == 1 || PD == 2, "planes in flight");
+    static_assert(LA == 0 || (WMODE_ == W_REG && CR_ == CKB_ && !PF_), "read-ahead window: register weights, whole voxels");
     static constexpr int NTHREADS = 64 * WM * WN;
     static constexpr int TH = MT_W * WM, TW = 16, HR = TH + KH - 1, WR = TW + KW - 1;
     static constexpr int PITCH = 2 * CR;
@@ -734,23 +739,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
     // work against 1-2 us of loaded-HBM latency: the 256^2 layers ran at half the HBM rate with the matrix pipes 38 % busy).
     PlaneStager<C::NTHREADS, HR, WR, CKB / 8, PITCH, C::SWZ> sx2;
     // The march loop below is straight-line code: every fetch and every store is issued in every step (a frame index past the chunk
-    // becomes -1 -> all offsets OOB -> zeros without traffic).  The prologue is made to LOOK like a loop iteration to the compiler's wait
-    // counting -- the same number of (dropped, OOB) stores behind each plane request as a step's epilogue issues -- so that the wait in
-    // front of a plane's LDS store is vmcnt(memory operations issued behind that plane's loads), the same number on the loop's entry and
-    // back edges, instead of the conservative vmcnt(0) a mismatch between the two collapses to.
-    constexpr int STORES = MT_W * NT_W;
+    // becomes -1 -> all offsets OOB -> zeros without traffic; the stores of step tt are issued by step tt + 1, see flush()).
     FETCH(sx, t_beg + 1);
-    if (!TWO) {
-#pragma unroll
-        for (int i = 0; i < STORES; ++i) buf_store8(ry, OOB, make_uint2(0, 0));
-    }
-    if (C::PD == 2) {
-        FETCH(sx2, t_beg + 1 < t_end ? t_beg + 2 : -1);
-        if (!TWO) {
-#pragma unroll
-            for (int i = 0; i < STORES; ++i) buf_store8(ry, OOB, make_uint2(0, 0));
-        }
-    }
+    if (C::PD == 2) FETCH(sx2, t_beg + 1 < t_end ? t_beg + 2 : -1);
     const int wo = w0 + r;
     const int lin_w = (wm * MT_W) * WR + r;                                // this lane's voxel in the wave's first halo row
     // GroupNorm partials per channel PAIR (a group is an even number of consecutive channels): v_dot2c_f32_bf16 adds the two
@@ -760,6 +751,14 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
     for (int i = 0; i < (GN ? NT_W : 1); ++i)
 #pragma unroll
         for (int e = 0; e < 2; ++e) { gs[i][e] = 0.f; gss[i][e] = 0.f; }
+    uint2 held[MT_W][NT_W];
+    unsigned hoff[MT_W];
+#pragma unroll
+    for (int m = 0; m < MT_W; ++m) {
+        hoff[m] = OOB;
+#pragma unroll
+        for (int i = 0; i < NT_W; ++i) held[m][i] = make_uint2(0, 0);
+    }
     auto frame = [&](int tt) {
 
         f32x4 acc[MT_W][NT_W];
@@ -814,6 +813,37 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
                 xo[hr] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pbase + lin * PITCH + p * 16));
             }
         };
+        if (C::LA > 0) {
+            constexpr int LA = C::LA > 0 ? C::LA : 1, NR = KSTEPS * NX;
+            bf16x8 win[LA + 1];
+            auto rd = [&](int idx) {
+                const int j = idx / NX, hr = idx - j * NX;
+                int slot, part;
+                if (CKB == 32) { slot = j < KT * KW ? j : 0; part = g; }
+                else { slot = 2 * j + (g >> 1); if (slot >= KT * KW) slot = 0; part = g & 1; }
+                const int dt = slot / KW, dx = slot - dt * KW;
+                const int lin = lin_w + dx + hr * WR;
+                const int p = C::SWZ ? (part ^ ((lin >> 1) & 2)) : part;
+                return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + ((tt + dt - 1) & 3) * PLANE + lin * PITCH + p * 16));
+            };
+#pragma unroll
+            for (int i = 0; i < LA && i < NR; ++i) win[i % (LA + 1)] = rd(i);
+#pragma unroll
+            for (int idx = 0; idx < NR; ++idx) {
+                if (idx + LA < NR) win[(idx + LA) % (LA + 1)] = rd(idx + LA);
+                const int j = idx / NX, hr = idx - j * NX;
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy) {
+                    const int m = hr - dy;
+                    if (m >= 0 && m < MT_W) {
+#pragma unroll
+                        for (int i = 0; i < NT_W; ++i)
+                            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[WREG ? j : 0][dy][i], win[idx % (LA + 1)], acc[m][i], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         if (C::PF) request(0, xf[0], wf[0]);
 #pragma unroll
         for (int j = 0; j < KSTEPS; ++j) {
@@ -838,12 +868,16 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
             }
             if (C::PF) __builtin_amdgcn_sched_barrier(0);
         }
-        // D[row = co 4g+j][col = voxel r]; lane stores 4 consecutive channels (8 bytes) of one voxel
+        }
+        // D[row = co 4g+j][col = voxel r]; a lane holds 4 consecutive channels (8 bytes) of one voxel.  One tensor: the rounded tile is
+        // PARKED (held[], hoff[]) and stored by flush() behind the NEXT step's barrier, in front of that step's plane request -- so the only
+        // memory operations younger than a plane's loads when the march waits for them are none, and the stores have a whole step to drain.
 #pragma unroll
         for (int m = 0; m < MT_W; ++m) {
             const int ho = h0 + wm * MT_W + m;
             const bool inside = ho < d.H && wo < d.W;                  // outside: the store is issued with an OOB offset and dropped
             const long v = (((long)n * d.T + tt) * d.H + ho) * d.W + wo;
+            if (!TWO) hoff[m] = inside ? (unsigned)(v * ldy + ct0 * 16 + 4 * g) * 2u : OOB;
 #pragma unroll
             for (int i = 0; i < NT_W; ++i) {
                 uint2 o;
@@ -856,7 +890,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
                         else *reinterpret_cast<uint2*>(y + v * ldy + c0) = o;
                     }
                 } else {
-                    buf_store8(ry, inside ? (unsigned)(v * ldy + c0) * 2u : OOB, o);
+                    held[m][i] = o;
                 }
                 if (GN) {                                          // statistics of what GroupNorm will read: the rounded values
                     const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3f803f80u);
@@ -869,15 +903,25 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
             }
         }
     };
+    auto flush = [&]() {                                               // the parked tile of the previous step (OOB offsets before the first)
+        if (!TWO) {
+#pragma unroll
+            for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+                for (int i = 0; i < NT_W; ++i) buf_store8(ry, hoff[m] == OOB ? OOB : hoff[m] + 32u * i, held[m][i]);
+        }
+    };
     if (C::PD == 2) {
         for (int tt = t_beg; tt < t_end; tt += 2) {
             sx.store(smem + ((tt + 1) & 3) * PLANE, tid);                   // waits for plane tt + 1 only: plane tt + 2 stays in flight
             __syncthreads();
+            flush();
             FETCH(sx, tt + 2 < t_end ? tt + 3 : -1);
             frame(tt);
             if (tt + 1 >= t_end) break;
             sx2.store(smem + ((tt + 2) & 3) * PLANE, tid);
             __syncthreads();
+            flush();
             FETCH(sx2, tt + 3 < t_end ? tt + 4 : -1);
             frame(tt + 1);
         }
@@ -885,10 +929,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_bf16_roll_kernel(const bf1
         for (int tt = t_beg; tt < t_end; ++tt) {
             sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
             __syncthreads();
+            flush();
             FETCH(sx, tt + 1 < t_end ? tt + 2 : -1);
             frame(tt);
         }
     }
+    flush();                                                            // the last step's tile
 #undef FETCH
     if (GN) {
         // fold: the 16 voxel lanes of a channel quad (xor-shuffles), then the WM waves that share the channels (LDS), then the
@@ -976,11 +1022,11 @@ int launch_roll(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf
 typedef RollCfg<16, 7, 7, 2, 1, 8, 1, W_LDS, true> R377;         // patch mixer: TH 16, 77 KB of weights behind a 61 KB ring
 typedef RollCfg<16, 7, 7, 4, 1, 8, 1, W_LDS, true, 12> R377_12;  // ... with 12 real of its 16 K channels: 8 k-steps instead of 11, and
                                                                  // TH 32: a weight fragment read from LDS feeds 4 output rows
-typedef RollCfg<16, 3, 3, 4, 1, 4, 1, W_REG, false, 16, 2> R16_16;   // TH 16, two planes in flight
-typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false, 16, 2> R16_32;   // TH 8, one output-channel tile per wave, two planes in flight
-typedef RollCfg<32, 3, 3, 4, 1, 8, 1, W_REG, false> R32_16;      // TH 32, 8 waves, 157 KB ring (TH 16 with 2 rows per wave read 4 X
+typedef RollCfg<16, 3, 3, 4, 1, 4, 1, W_REG, false, 16, 1, 2> R16_16;   // TH 16, two planes in flight
+typedef RollCfg<16, 3, 3, 4, 1, 2, 2, W_REG, false, 16, 1, 2> R16_32;   // TH 8, one output-channel tile per wave, two planes in flight
+typedef RollCfg<32, 3, 3, 4, 1, 8, 1, W_REG, false, 32, 1, 3> R32_16;      // TH 32, 8 waves, 157 KB ring (TH 16 with 2 rows per wave read 4 X
                                                                  // fragments per 6 products: 153 -> 129 us at 256^2; taller tiles lose elsewhere)
-typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false> R32_32;      // TH 16, 8 waves, one output-channel tile per wave
+typedef RollCfg<32, 3, 3, 4, 1, 4, 2, W_REG, false, 32, 1, 3> R32_32;      // TH 16, 8 waves, one output-channel tile per wave
 
 #define ROLL(C) do { if (gn_part) return launch_roll<C, true>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups, sp); \
                      return launch_roll<C, false>(x, ldx, wp, bias, y, ldy, d, s, nullptr, 0, sp); } while (0)
