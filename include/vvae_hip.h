@@ -53,6 +53,7 @@ int vvae_conv3d_dgrad_generic(const void* dy, int lddy, const float* w, void* dx
                               int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
 int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
                               int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
+int vvae_conv3d_deep_config(int on);               /* test/tuning hook: deep (K-split waves) rolling fwd/dgrad kernel on/off (off: per-frame kernel) */
 int vvae_conv3d_roll_config(int on, int tchunk);   /* test/tuning hook: rolling time-column fwd/dgrad kernel on/off, frames per workgroup */
 int vvae_conv3d_wgrad_config(int cob16, int blocks); /* tuning hook: 16 output channels per wgrad workgroup (default 0), persistent grid size (0 = per-config default) */
 int vvae_conv3d_bf16_supported(int Cin, int Cout, int kt, int kh, int kw, int ld_in, int ld_out, int which, int flags);

@@ -414,6 +414,45 @@ def test_conv3d_rolling_kernel_matches_per_frame(dev, case, tchunk):
     assert torch.equal(dx0, dx1)
 
 
+DEEP_CASES = [
+    # cin, cout, (n, t, h, w): the layers the deep rolling kernel owns (K channels in 1 / 2 / 4 chunks of 32 split over the waves), fwd and
+    # dgrad roles, ragged tiles, one frame, volumes smaller than a tile
+    (32, 64, (1, 5, 20, 24)), (64, 32, (2, 3, 9, 33)), (64, 64, (1, 6, 17, 16)), (64, 128, (1, 4, 10, 18)), (128, 64, (1, 3, 7, 30)),
+    (128, 128, (2, 2, 5, 16)), (64, 64, (1, 1, 3, 5)), (128, 128, (1, 7, 1, 1)), (32, 128, (1, 2, 16, 16)),
+]
+
+
+@pytest.mark.parametrize("case", DEEP_CASES)
+def test_conv3d_deep_kernel_matches_per_frame(dev, case):
+    """The deep rolling kernel (waves split the K chunks, partial sums folded through LDS in chunk order) against the per-frame kernel it
+    replaces: the same products; with one K chunk the same summation order (bitwise), with 2 / 4 chunks the fp32 partial sums are
+    associated differently, so a small fraction of the bf16 outputs may sit one rounding step apart.  Deterministic run to run."""
+    from video_vae_amd import ops
+    from video_vae_amd._lib import lib
+    ci, co, (n, t, h, w) = case
+    x = rnd((n, t, h, w, ci), 70, 1.0).to(dev, torch.bfloat16)
+    gy = rnd((n, t, h, w, co), 71, 1.0).to(dev, torch.bfloat16)
+    k = rnd((3, 3, 3, ci, co), 72, (27 * ci) ** -0.5).to(dev)
+    b = rnd((co,), 73, 0.1).to(dev)
+    try:
+        lib().vvae_conv3d_deep_config(0)
+        y0, dx0 = ops.conv3d_fwd_raw(x, k, b), ops.conv3d_dgrad_raw(gy, k)
+        lib().vvae_conv3d_deep_config(1)
+        y1, dx1 = ops.conv3d_fwd_raw(x, k, b), ops.conv3d_dgrad_raw(gy, k)
+        y2, dx2 = ops.conv3d_fwd_raw(x, k, b), ops.conv3d_dgrad_raw(gy, k)
+    finally:
+        lib().vvae_conv3d_deep_config(1)
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2), "not reproducible"
+    for name, a, ref, ck in (("y", y1, y0, ci), ("dx", dx1, dx0, co)):
+        if ck == 32:
+            assert torch.equal(a, ref), f"{name}: one K chunk must be bitwise equal to the per-frame kernel"
+            continue
+        a, ref = a.float(), ref.float()
+        frac = float((a != ref).float().mean())
+        err = float(((a - ref).abs() / ref.abs().clamp_min(0.25)).max())
+        assert frac < 0.05 and err <= 2.0 ** -7, f"{name}: {frac:.3f} of outputs differ, worst relative step {err:.2e}"
+
+
 @pytest.mark.parametrize("case", FAST_CASES)
 def test_conv3d_bf16_fast_path(dev, case):
     """bf16 MFMA fwd/dgrad vs (a) the generic fp32-matrix-core path on the GPU and (b) the CPU oracle.

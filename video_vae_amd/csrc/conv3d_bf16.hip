@@ -325,6 +325,7 @@ int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias
 // for the 3x7x7 mixer with 12 real channels on the rolling kernel; anything else packs and multiplies the padded product.
 inline int real_k(int flags, int kh) { return (kh == 7 && ((flags >> 8) & 0xff) == 12 && roll_enabled()) ? 12 : 0; }
 int roll_gn_blocks_any(BfDims d, int kh, int groups);
+int launch_deep_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s);
 }
 
 // which: 0 fwd (K = Cin, produced = Cout), 1 dgrad (K = Cout, produced = Cin), 2 wgrad (ld_in = ldx, ld_out = lddy).
@@ -425,6 +426,10 @@ extern "C" int vvae_conv3d_fwd_bf16(const void* x, int ldx, const float* w, cons
         if (rc != VVAE_ERR_BAD_ARG) return rc;
     }
     if (kr) return VVAE_ERR_BAD_ARG;                                // packed for the real-channel K order: only the rolling kernel reads it
+    if (kh == 3 && chunk_of(CK) == 32) {                            // deeper layers: time march with the waves splitting the K chunks
+        const int rc = launch_deep_any(xp, ldx, wp, bp, yp, ldy, d, s);
+        if (rc != VVAE_ERR_BAD_ARG) return rc;
+    }
     if (kh == 7) return launch_cfg<C377_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
     if (chunk_of(CK) == 16) {
         if (CO == 16) return launch_cfg<C333_k16_o16>(xp, ldx, wp, bp, yp, ldy, d, s);
@@ -560,7 +565,16 @@ struct WgDims { int N, T, H, W, CI, CO, tiles_h, tiles_w, ncols, cols_per_block;
 
 // One HR x WR halo plane of 16-byte channel parts held in registers between its global fetch and its LDS store, so the
 // fetch of step t+1 can be in flight while step t computes (register-staged software pipeline).
-template <int NTHREADS, int HR, int WR, int PARTS, int PITCH, bool SWZ = false, int WRP = WR>   // WRP: LDS row pitch in voxels
+// 16-byte part index of an LDS voxel, XORed so that every ds_read_b128 lane group of 16 consecutive voxels lands on 16 distinct slots of the
+// 256-byte bank row for any tap shift.  Mode 1: 64-byte voxels (32 channels); 2: 128-byte (64 channels); 3: 256-byte (128 channels) -- found by
+// exhaustive search over XOR-linear maps of the voxel index against the lane groups of MI355X_MICROARCH.md's LDS table.
+template <int MODE> __device__ __forceinline__ int swz_part(int part, int lin) {
+    return MODE == 1 ? (part ^ ((lin >> 1) & 2)) : MODE == 2 ? (part ^ (lin & 6)) : MODE == 3 ? (part ^ ((lin & 7) << 1)) : part;
+}
+// SWCOL: the swizzle is a function of the voxel's COLUMN in the halo row instead of its linear index (conflict freedom only involves the 16
+// consecutive voxels of one row, so either works; with the column a reader's swizzle does not depend on the halo row and the row becomes an
+// immediate offset).
+template <int NTHREADS, int HR, int WR, int PARTS, int PITCH, int SWZ = 0, int WRP = WR, bool SWCOL = false>   // WRP: LDS row pitch in voxels
 struct PlaneStager {
     static constexpr int ROW_ITEMS = WR * PARTS;
     static_assert(ROW_ITEMS <= NTHREADS, "a halo row must fit one pass");
@@ -604,7 +618,7 @@ struct PlaneStager {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int lin = (rip + it * RPP) * WRP + wc;                   // SWZ: part ^= ((voxel >> 2) & 1) << 1 (64-byte voxels)
-            const int p = SWZ ? (part ^ ((lin >> 1) & 2)) : part;
+            const int p = swz_part<SWZ>(part, SWCOL ? wc : lin);
             if (rip < RPP && rip + it * RPP < HR) {
                 if (PITCH % 16 == 0) *reinterpret_cast<uint4*>(lds + lin * PITCH + p * 16) = v[it];
                 else {                                                     // 24-byte voxels (12 real of 16 channels): 8-byte pieces,
@@ -1056,6 +1070,196 @@ int roll_gn_blocks_any(BfDims d, int kh, int groups)
     return 0;
 }
 
+
+// =============================================================================================== deep rolling forward / input gradient
+// The layers whose K channels do not fit one chunk (CK = 64, 128) or that produce >= 64 channels from 32 ran on the per-frame kernel
+// (conv3d_bf16_kernel): stage -> barrier -> multiply with nothing in flight, packed weights re-fetched through the vector L1 for every tile
+// -- 0.6-0.95 PF/s with the matrix pipes 34 % busy.  Same march over time as conv3d_bf16_roll_kernel (ring of four halo planes, one new plane
+// per step fetched while the step multiplies, parked output tile stored behind the next barrier), with the WAVES of a workgroup splitting
+// (K chunk, output-channel tile, row group) so that each wave's weights -- 27 fragments: one 32-channel chunk x one 16-channel tile x
+// 3 x 3 x 3 taps -- stay in registers for the whole march.  The NCH chunk-waves of an output tile each hold a partial sum; at the end
+// of a step every wave parks the rows it does not own in an LDS scratch, one barrier, and the owner of a row adds the NCH - 1 partials in
+// chunk order (fixed order: deterministic), rounds and stores it.
+template <int NCH_, int NCT_, int NRG_, int MT_, int LA_>
+struct DeepCfg {
+    static constexpr int NCH = NCH_, NCT = NCT_, NRG = NRG_, MT = MT_, LA = LA_;
+    static constexpr int CK = 32 * NCH, CO_BLK = 16 * NCT, NW = NCH * NCT * NRG, NTHREADS = 64 * NW;
+    static constexpr int KT = 3, KH = 3, KW = 3, KSTEPS = KT * KW;            // one k-step = the 32 channels of a chunk at one (dt, dx)
+    static constexpr int TH = MT * NRG, TW = 16, HR = TH + KH - 1, WR = TW + KW - 1, NX = MT + KH - 1;
+    static constexpr int PITCH = 2 * CK, SWZ = NCH == 1 ? 1 : NCH == 2 ? 2 : 3;
+    static constexpr int PLANE = HR * WR * PITCH;
+    static constexpr int OWN = MT / NCH;                                     // rows of a wave's MT that it finishes itself
+    static constexpr int SCRATCH = NCH > 1 ? NW * MT * 1024 : 0;             // [wave][row][lane] f32x4
+    static constexpr int LDS_BYTES = 4 * PLANE + SCRATCH;
+    static_assert(NW == 8 && MT % NCH == 0 && (NCH == 1 || NCH == 2 || NCH == 4), "wave grid");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_bf16_deep_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wp,
+                                                                       const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy,
+                                                                       BfDims d, int tchunk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NCH = C::NCH, NCT = C::NCT, MT = C::MT, KH = C::KH, KW = C::KW, KSTEPS = C::KSTEPS, NX = C::NX;
+    constexpr int HR = C::HR, WR = C::WR, PITCH = C::PITCH, PLANE = C::PLANE, OWN = C::OWN;
+    const long vox_all = (long)d.N * d.T * d.H * d.W;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)span_bytes(vox_all, ldx, d.CK));
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, (unsigned)span_bytes(vox_all, ldy, d.CO));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = wave % NCH, wi = (wave / NCH) % NCT, rg = wave / (NCH * NCT);      // K chunk, output-channel tile, row group of this wave
+    const int r = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);       // XCD-aware: neighbours share halo columns and planes
+    const int nch = (d.T + tchunk - 1) / tchunk;
+    const int tc = bid % nch; int q = bid / nch;
+    const int tw = q % d.tiles_w; q /= d.tiles_w;
+    const int th = q % d.tiles_h; const int n = q / d.tiles_h;
+    const int h0 = th * C::TH, w0 = tw * C::TW;
+    const int t_beg = tc * tchunk;
+    int t_end = t_beg + tchunk;
+    if (t_end > d.T) t_end = d.T;
+
+    const int co_tiles = d.CO / 16;
+    const int ct = blockIdx.y * NCT + wi;                                  // this wave's output-channel tile
+    bf16x8 wreg[KSTEPS][KH];
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j)
+#pragma unroll
+        for (int dy = 0; dy < KH; ++dy)
+            wreg[j][dy] = __builtin_bit_cast(bf16x8, wp[((long)((c * KH + dy) * KSTEPS + j) * co_tiles + ct) * 64 + lane]);
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = bias ? bias[ct * 16 + 4 * g + e] : 0.f;
+
+    PlaneStager<C::NTHREADS, HR, WR, C::CK / 8, PITCH, C::SWZ, WR, true> sx;
+    const int hx = h0 - KH / 2, wx = w0 - KW / 2;
+#define FETCH(T_) sx.fetch(rx, ldx, 0, n, (T_), hx, wx, d.T, d.H, d.W, tid)
+    FETCH(t_beg - 1);                                                      // out-of-range frames come back as zeros
+    sx.store(smem + ((t_beg - 1) & 3) * PLANE, tid);
+    FETCH(t_beg);
+    sx.store(smem + (t_beg & 3) * PLANE, tid);
+    FETCH(t_beg + 1);
+    const int wo = w0 + r;
+    const int lin_w = (rg * MT) * WR + r;                                  // this lane's voxel in the wave's first halo row
+    f32x4* scr = reinterpret_cast<f32x4*>(smem + 4 * PLANE);               // [wave][row][lane]
+    uint2 held[OWN];
+    unsigned hoff[OWN];
+#pragma unroll
+    for (int m = 0; m < OWN; ++m) { held[m] = make_uint2(0, 0); hoff[m] = OOB; }
+
+    for (int tt = t_beg; tt < t_end; ++tt) {
+        sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
+        __syncthreads();                                                   // also: every wave has read last step's scratch
+#pragma unroll
+        for (int m = 0; m < OWN; ++m) buf_store8(ry, hoff[m], held[m]);    // the previous step's rows (OOB before the first)
+        FETCH(tt + 1 < t_end ? tt + 2 : -1);
+
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int LA = C::LA, NR = KSTEPS * NX;
+        bf16x8 win[LA + 1];
+        auto rd = [&](int idx) {
+            const int j = idx / NX, hr = idx - j * NX;
+            const int dt = j / KW, dx = j - dt * KW;
+            const int p = swz_part<C::SWZ>(c * 4 + g, r + dx);             // column swizzle: independent of the halo row
+            return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + ((tt + dt - 1) & 3) * PLANE + (lin_w + dx) * PITCH + p * 16
+                                                                                + hr * (WR * PITCH)));
+        };
+#pragma unroll
+        for (int i = 0; i < LA; ++i) win[i % (LA + 1)] = rd(i);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+#pragma unroll
+            for (int hr = 0; hr < NX; ++hr) {
+                const int idx = j * NX + hr;
+                if (idx + LA < NR) win[(idx + LA) % (LA + 1)] = rd(idx + LA);
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy) {
+                    const int m = hr - dy;
+                    if (m >= 0 && m < MT) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][dy], win[idx % (LA + 1)], acc[m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- fold the NCH partial sums of every row: wave c owns rows [c * OWN, (c + 1) * OWN) of its (tile, row group)
+        if (NCH > 1) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m / OWN != c) scr[(wave * MT + m) * 64 + lane] = acc[m];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
+            float sum[4] = {0.f, 0.f, 0.f, 0.f};                           // scalar adds on purpose: no packed fp32 VALU forms (Makefile)
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc) {                             // chunk order, own partial in its place
+                f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mm = 0; mm < MT; ++mm)                            // (static register index: the owned row is c * OWN + o)
+                    if (mm == c * OWN + o) part = acc[mm];
+                if (cc != c) part = scr[((wave - c + cc) * MT + c * OWN + o) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] = cc == 0 ? part[e] : sum[e] + part[e];
+            }
+            const int ho = h0 + rg * MT + c * OWN + o;
+            const bool inside = ho < d.H && wo < d.W;
+            const long v = (((long)n * d.T + tt) * d.H + ho) * d.W + wo;
+            hoff[o] = inside ? (unsigned)(v * ldy + ct * 16 + 4 * g) * 2u : OOB;
+            held[o].x = (uint32_t)f2bf(sum[0] + bv[0]) | ((uint32_t)f2bf(sum[1] + bv[1]) << 16);
+            held[o].y = (uint32_t)f2bf(sum[2] + bv[2]) | ((uint32_t)f2bf(sum[3] + bv[3]) << 16);
+        }
+    }
+#undef FETCH
+#pragma unroll
+    for (int m = 0; m < OWN; ++m) buf_store8(ry, hoff[m], held[m]);        // the last step's rows
+}
+
+int g_deep = 1;
+
+//              NCH NCT NRG MT LA
+typedef DeepCfg<1, 4, 2, 8, 3> D32_64;       // K 32 -> 64 per workgroup: TH 16
+typedef DeepCfg<2, 2, 2, 4, 3> D64_32;       // K 64 -> 32: TH 8
+typedef DeepCfg<2, 4, 1, 8, 3> D64_64;       // K 64 -> 64 per workgroup: TH 8
+typedef DeepCfg<4, 2, 1, 4, 3> D128_32;      // K 128 -> 32 per workgroup: TH 4
+
+template <class C>
+int launch_deep(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s)
+{
+    const long vox = (long)d.N * d.T * d.H * d.W, lim = 1L << 31;
+    if (span_bytes(vox, ldx, d.CK) >= lim || span_bytes(vox, ldy, d.CO) >= lim) return VVAE_ERR_BAD_ARG;
+    d.tiles_h = ceil_div(d.H, C::TH);
+    d.tiles_w = ceil_div(d.W, C::TW);
+    const long cols = (long)d.N * d.tiles_h * d.tiles_w * (d.CO / C::CO_BLK);
+    int tchunk = d.T;                                                      // whole clip per workgroup unless that starves the chip
+    while (tchunk > 2 && cols * ceil_div(d.T, tchunk) < 256) tchunk = (tchunk + 1) / 2;
+    dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk)), d.CO / C::CO_BLK);
+    auto k = conv3d_bf16_deep_kernel<C>;
+    static bool attr_done = false;
+    if (C::LDS_BYTES > 65536 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// 3 x 3 x 3 layers the deep kernel takes; anything else: VVAE_ERR_BAD_ARG (the caller falls back to the per-frame kernel)
+int launch_deep_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s)
+{
+    if (!g_deep) return VVAE_ERR_BAD_ARG;
+    if (d.CK == 32 && d.CO % 64 == 0) return launch_deep<D32_64>(x, ldx, wp, bias, y, ldy, d, s);
+    if (d.CK == 64 && d.CO == 32) return launch_deep<D64_32>(x, ldx, wp, bias, y, ldy, d, s);
+    if (d.CK == 64 && d.CO % 64 == 0) return launch_deep<D64_64>(x, ldx, wp, bias, y, ldy, d, s);
+    if (d.CK == 128 && d.CO % 32 == 0) return launch_deep<D128_32>(x, ldx, wp, bias, y, ldy, d, s);
+    return VVAE_ERR_BAD_ARG;
+}
+
 template <class C, bool TWO>
 __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx,
                                                                                  const bf16_t* __restrict__ dy, int lddy,
@@ -1365,6 +1569,13 @@ extern "C" int vvae_conv3d_wgrad_bf16_cat2(const void* x, int ldx, const void* x
 extern "C" int vvae_conv3d_wgrad_config(int cob16, int blocks)
 {
     g_wg_cob16 = cob16; g_wg_blocks = blocks;
+    return 0;
+}
+
+// Test / tuning hook: on = 0 routes the multi-chunk / wide layers through the per-frame kernel again (vvae_conv3d_deep_config).
+extern "C" int vvae_conv3d_deep_config(int on)
+{
+    g_deep = on;
     return 0;
 }
 

@@ -37,9 +37,10 @@ from . import ops
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, video, mask, hparams, hw, rngs, warmup=3, split=None, enc_segments=3, debug_dot=None,
-                 perceptual_loss_fn=None, vgg_params=None):
+                 perceptual_loss_fn=None, vgg_params=None, stream=None):
         self.model, self.opt, self.hparams, self.hw, self.rngs = model, optimizer, hparams, hw, rngs
         self.ploss, self.vgg_params = perceptual_loss_fn, vgg_params      # rl flavour only (rl_nonadversarial.py:125)
+        self.capture_stream = stream        # capture on this (non-default) stream instead of a fresh one: see _capture
         self.split = (optimizer.reducer is not None) if split is None else bool(split)
         enc = model.encoder
         if not (hasattr(enc, "layers") and hasattr(enc, "patch_embedding") and len(enc.layers) > 0):
@@ -167,7 +168,10 @@ class GraphedTrainStep:
         # to the stream that was current when the node was created; a node left over from an earlier pass on another stream
         # makes the engine insert cross-stream syncs, which corrupts a capture -- so no pass before the capture may run on a
         # different stream, and no autograd graph from an earlier pass may still be alive (gc below).
-        self.stream = torch.cuda.Stream()
+        # A driver that has ALREADY run eager steps (train.py: a shape is met once before it is captured) hands over the stream those steps
+        # ran on: the AccumulateGrad nodes they created are pinned to it, and a capture on any other stream would segfault in the engine's
+        # cross-stream sync.  Such a driver runs everything -- model construction, eager steps, captures, replays -- on that one stream.
+        self.stream = self.capture_stream if self.capture_stream is not None else torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         gc.collect()
         # per-rank noise stream for the static buffers (eager mode draws from Rngs(seed) keys; same distributions here)

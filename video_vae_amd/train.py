@@ -90,7 +90,7 @@ class StepRunner:
                 t0 = time.perf_counter()
                 gc.collect()                                     # no autograd graph of an eager step may outlive into the capture
                 g = GraphedTrainStep(self.model, self.opt, video, mask, dict(hparams), self.hw, V.Rngs(1_000_003 * (self.rngs.seed + 1) + len(self.seen)),
-                                     perceptual_loss_fn=self.ploss, vgg_params=self.vgg_params)
+                                     perceptual_loss_fn=self.ploss, vgg_params=self.vgg_params, stream=torch.cuda.current_stream())
                 self.graphs[shape] = (hkey, g)
                 self.log(f"captured the train step for video {tuple(video.shape)} in {time.perf_counter() - t0:.1f} s "
                          f"({1 + len(g.graphs)} hipGraph{'s' if g.graphs else ''})")
@@ -138,6 +138,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # ONE non-default stream for the whole run: model construction, eager steps, graph captures and replays, the optimizer update and
+    # (through the current-stream edges of ProcessGroupNCCL) the collectives.  Autograd pins every parameter's AccumulateGrad node to the
+    # stream that was current when the node was made; a capture on another stream than the eager steps before it crashes the engine.
+    train_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(train_stream)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     signal.signal(signal.SIGTERM, _stop)
