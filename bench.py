@@ -99,6 +99,12 @@ def parse():
                     help="attach the gradient reducer and a process group even at world size 1 (launch under torch.distributed.run)")
     ap.add_argument("--split-graph", action="store_true",
                     help="capture the step as two graphs cut at the encoder's last block even at N = 1 (the N > 1 default)")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
+                    help="dtype the gradient buckets cross the transport in (bf16: half the xGMI bytes, see video_vae_amd/ddp.py); f32 = the reference")
+    ap.add_argument("--enc-segments", type=int, default=9,
+                    help="data parallel, graph mode: hipGraphs the encoder's backward is cut into (1 + this many graphs per step).  The buckets of a "
+                         "segment are all-reduced under the segments still to come; only the LAST segment's wait for the end of backward: 9 -> one "
+                         "encoder block + the patch embedding = 32 MB of the 683 MB (3 -> 95 MB)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-graph", "--eager", action="store_true", dest="no_graph",
@@ -298,7 +304,7 @@ def main():
     opt = optim.Optimizer(model, optim.reference_schedule(batch_size=args.batch * world))
     reducer = None
     if ddp_on:
-        reducer = ddp.GradReducer(opt)
+        reducer = ddp.GradReducer(opt, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32)
         reducer.broadcast_parameters(0)
     nparams = sum(p.numel() for p in model.parameters())
 
@@ -352,7 +358,8 @@ def main():
         if not args.no_graph:
             try:
                 from video_vae_amd.graph import GraphedTrainStep
-                gstep = GraphedTrainStep(model, opt, video, mask, L.HPARAMS, hw, rngs, split=True if args.split_graph else None)
+                gstep = GraphedTrainStep(model, opt, video, mask, L.HPARAMS, hw, rngs, split=True if args.split_graph else None,
+                                         enc_segments=args.enc_segments)
 
                 def step():
                     loss, _aux = gstep(*batch()) if feed is not None else gstep()
@@ -451,7 +458,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" if not args.with_input_pipeline else
                     "synthetic clips on disk through the host input pipeline (worker processes -> pinned uint8 -> H2D on a side stream)",
-            "rccl_ranks": world if (ddp_on and args.backend == "nccl") else 0,
+            "rccl_ranks": world if (ddp_on and args.backend == "nccl") else 0, "grad_allreduce_dtype": args.grad_dtype if ddp_on else None,
             "config": {"workload": ((("C3" if (B, T, S) == (4, 16, 256) else "C5 per-GPU shape" if (B, T, S) == (2, 32, 256) else "custom shape")
                                      + ": full VideoVAE (enc 9 / dec 12 FactoredAttention + 3D-conv UNet) train step, ")
                                     if args.workload == "vae" else "Conv3d UNet stack alone (diagnostic), ")

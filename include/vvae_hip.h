@@ -51,8 +51,11 @@ int vvae_conv3d_fwd_generic(const void* x, int ldx, const float* w, const float*
                             int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
 int vvae_conv3d_dgrad_generic(const void* dy, int lddy, const float* w, void* dx, int lddx,
                               int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
+/* no atomics: one fp32 partial dW per voxel chunk in ws (vvae_conv3d_wgrad_generic_ws_bytes), folded in index order */
+size_t vvae_conv3d_wgrad_generic_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw);
 int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
-                              int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, void* stream);
+                              int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype,
+                              void* ws, size_t ws_bytes, void* stream);
 int vvae_conv3d_deep_config(int on);               /* test/tuning hook: deep (K-split waves) rolling fwd/dgrad kernel on/off (off: per-frame kernel) */
 int vvae_conv3d_roll_config(int on, int tchunk);   /* test/tuning hook: rolling time-column fwd/dgrad kernel on/off, frames per workgroup */
 int vvae_conv3d_wgrad_config(int cob16, int blocks); /* tuning hook: 16 output channels per wgrad workgroup (default 0), persistent grid size (0 = per-config default) */
@@ -165,8 +168,9 @@ int vvae_convt_1x2x2_fwd(const void* x, int ldx, const float* w, const float* bi
                          int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
 int vvae_convt_1x2x2_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx,
                            int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
+size_t vvae_convt_1x2x2_wgrad_ws_bytes(int NT, int H, int W, int Cin, int Cout);   /* per-chunk fp32 partials, folded in index order (no atomics) */
 int vvae_convt_1x2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw,
-                           int NT, int H, int W, int Cin, int Cout, int dtype, void* stream);
+                           int NT, int H, int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* bf16 MFMA path (weights in registers, no LDS) for the UNet decoder shapes 128->64, 64->32, 32->16:
  * dgrad = 0: x -> y (+bias); dgrad = 1: "x" is dy (2H x 2W, Cout), "y" is dx (H x W, Cin).  ws: packed weights. */
 /* bf16 matrix-core weight + bias gradient of the same layer (128->64, 64->32, 32->16): deterministic slab reduction. */
@@ -185,10 +189,11 @@ int vvae_convt_1x2x2_bf16(const void* x, int ldx, const float* w, const float* b
 int vvae_temporal_attn_fwd(const void* qkv, int ld, void* out, int ldo, const float* q_scale, const float* k_scale,
                            const float* cos_table, const float* sin_table, const uint8_t* mask, int mask_div,
                            int A, int T, int heads, int D, float eps, int dtype, void* stream);
+size_t vvae_temporal_attn_bwd_ws_bytes(int A, int heads, int D);   /* partial rows of the q/k-norm scale gradients (no atomics) */
 int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, void* dqkv, int lddq,
                            const float* q_scale, const float* k_scale, const float* cos_table, const float* sin_table,
                            const uint8_t* mask, int mask_div, float* dq_scale, float* dk_scale,
-                           int A, int T, int heads, int D, float eps, int dtype, void* stream);
+                           int A, int T, int heads, int D, float eps, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* lane-per-frame form of the same core for head_dim D in {8,16,32,64} (the production path): forward also writes the
  * row log-sum-exp `lse` (A*heads, T) fp32; backward consumes (out, lse) and writes per-workgroup partials of the

@@ -1371,3 +1371,45 @@ def test_plain_loss_tail_matches_the_framework_ops(dev, b, t):
     for a, w, what in zip(got, ref_leaves, ("d mse", "d kl", "d selection")):
         assert a.shape == w.grad.shape
         assert_close_scaled(a, w.grad, rel=1e-5, what=what)      # fp32 density - 1/rate against the fp64 reference: absolute, not relative
+
+
+def test_fp32_fallback_paths_are_bitwise_reproducible(dev):
+    """Round 3: the fp32 / odd-shape fallbacks (generic Conv3d and ConvTranspose weight + bias gradients, the any-head-dim temporal
+    attention's q/k-norm scale gradients) accumulated with float atomics -- configs C1-C2 were reproducible to rounding only.  They now
+    write per-workgroup partials folded in index order: two passes over the same inputs are bitwise equal (and still match the oracle:
+    test_conv3d_fwd_bwd / test_conv_transpose / test_temporal_attention cover the values)."""
+    import video_vae_amd as V
+    from video_vae_amd import ops
+    from oracle import unet as OU
+    p = OU.init_unet(12, 16, 2, 3, seed=1, zero_final=False)
+    m = V.UNet(12, 16, 2, 3, V.Rngs(0), dtype=torch.float32)
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k, v in p.items():
+            sd[k].copy_(v)
+    m = m.to(dev)
+    x = rnd((2, 5, 24, 40, 12), 90, 0.5).to(dev)
+    gy = rnd((2, 5, 24, 40, 3), 91).to(dev)
+    runs = []
+    for _ in range(2):
+        for prm in m.parameters():
+            prm.grad = None
+        m(x).backward(gy)
+        runs.append({k: prm.grad.clone() for k, prm in m.named_parameters()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), f"fp32 UNet gradient of {k} differs between two passes"
+    # any-head-dim temporal attention (head_dim 24 is not one of the fast kernels' 8/16/32/64)
+    heads, d, t, a = 2, 24, 7, 37
+    qkv = rnd((a, t, 3 * heads * d), 92).to(dev).requires_grad_(True)
+    qs, ks = (1 + 0.1 * rnd((d,), 93)).to(dev).requires_grad_(True), (1 + 0.1 * rnd((d,), 94)).to(dev).requires_grad_(True)
+    pos = torch.arange(t, dtype=torch.float32)[:, None] / (10000.0 ** (torch.arange(0, d, 2).float() / d))[None, :]
+    cos, sin = torch.cat([pos.cos(), pos.cos()], -1).to(dev), torch.cat([pos.sin(), pos.sin()], -1).to(dev)
+    go = rnd((a, t, heads * d), 95).to(dev)
+    grads = []
+    for _ in range(2):
+        for v in (qkv, qs, ks):
+            v.grad = None
+        ops.temporal_attention_core(qkv, qs, ks, cos, sin, None, 1, heads).backward(go)
+        grads.append((qs.grad.clone(), ks.grad.clone(), qkv.grad.clone()))
+    for g0, g1 in zip(*grads):
+        assert torch.equal(g0, g1)

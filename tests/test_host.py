@@ -135,7 +135,7 @@ def _free_port():
     return port
 
 
-def _ddp_worker(rank, world, port, out):
+def _ddp_worker(rank, world, port, out, grad_dtype="float32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -148,7 +148,7 @@ def _ddp_worker(rank, world, port, out):
                 for p in m.parameters():
                     p.add_(1.0)
         opt = optim.Optimizer(m, 1e-2, bucket_bytes=256, bf16_shadow=False)
-        red = ddp.GradReducer(opt)
+        red = ddp.GradReducer(opt, grad_dtype=getattr(torch, grad_dtype))
         red.broadcast_parameters(0)
         g = torch.Generator().manual_seed(100 + rank)   # per-rank shard: seed + rank
         res = {}
@@ -199,6 +199,28 @@ def test_ddp_gloo_world2(tmp_path):
         assert torch.allclose(r0[f"g{step}"], want, rtol=1e-5, atol=1e-7)
         with torch.no_grad():
             opt.p.add_(want, alpha=-0.05 / 2)
+
+
+def test_ddp_gloo_world2_bf16_gradient_allreduce(tmp_path):
+    """--grad-dtype bf16: buckets cross the transport in bf16 (half the bytes over xGMI).  Replicas still hold bit-identical gradients and
+    parameters after every update; against the fp32 reduction (the reference's arithmetic) the all-reduced gradient is within bf16
+    rounding of the sum of the shard gradients and the 3-step parameter trajectory within that rounding times the step size."""
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path), "bfloat16"), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    (tmp_path / "f32").mkdir()
+    mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path / "f32")), nprocs=2, join=True)
+    f0 = torch.load(tmp_path / "f32" / "r0.pt")
+    for step in range(3):
+        assert torch.equal(r0[f"g{step}"], r1[f"g{step}"]) and torch.equal(r0[f"p{step}"], r1[f"p{step}"])      # replicas identical
+        g, ref = r0[f"g{step}"], f0[f"g{step}"]
+        assert not torch.equal(g, ref), "the bf16 path did not run"
+        assert torch.equal(g, g.to(torch.bfloat16).float()), "all-reduced values are bf16 numbers"
+        # two bf16-rounded addends (2^-9 relative each) and one bf16 sum (2^-9 of the result), measured against the gradient's scale:
+        # (the trajectories differ by then, so the bound is on the first step; later steps only drift by lr x that)
+        if step == 0:
+            assert float((g - ref).abs().max()) <= 3 * 2.0 ** -9 * float(ref.abs().max())
+        assert float((r0[f"p{step}"] - f0[f"p{step}"]).abs().max()) <= (step + 1) * 0.05 * 3 * 2.0 ** -8 * float(f0["g0"].abs().max()) + 1e-6
 
 
 def _adam_standin(opt, lr_fn):

@@ -163,7 +163,7 @@ __device__ __forceinline__ void rope_ln_bwd(float* G, const float* XH, const flo
         }
     }
     int n = 0;
-    for (int dd = lane; dd < D; dd += 64, ++n) atomicAdd(dscale + dd, dsc[n]);
+    for (int dd = lane; dd < D; dd += 64, ++n) dscale[dd] = dsc[n];        // this (sequence, head)'s partial row: folded in index order afterwards
 }
 
 template <typename T_>
@@ -235,8 +235,9 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const T_* __rest
         VV[i * (D + 1) + dd] = u;
     }
     __builtin_amdgcn_wave_barrier();
-    rope_ln_bwd<T_>(DO, XQ, rq, q_scale, cosT, sinT, dg, lddq, dq_scale, T, D, lane);
-    rope_ln_bwd<T_>(VV, XK, rk, k_scale, cosT, sinT, dg + HD, lddq, dk_scale, T, D, lane);
+    // dq_scale here is the partial buffer [item][2 D]: q-norm scale gradients in columns [0, D), k-norm in [D, 2 D) (no atomics)
+    rope_ln_bwd<T_>(DO, XQ, rq, q_scale, cosT, sinT, dg, lddq, dq_scale + item * 2 * D, T, D, lane);
+    rope_ln_bwd<T_>(VV, XK, rk, k_scale, cosT, sinT, dg + HD, lddq, dq_scale + item * 2 * D + D, T, D, lane);
 }
 
 bool attn_ok(const AttnDims& d) {
@@ -284,22 +285,29 @@ extern "C" int vvae_temporal_attn_fwd(const void* qkv, int ld, void* out, int ld
 }
 
 // dq_scale / dk_scale: fp32 [D], overwritten.
+// Scratch of vvae_temporal_attn_bwd: one partial row of 2 D floats per (sequence, head).
+extern "C" size_t vvae_temporal_attn_bwd_ws_bytes(int A, int heads, int D)
+{
+    return (A > 0 && heads > 0 && D > 0) ? (size_t)A * heads * 2 * D * sizeof(float) : 0;
+}
+
+// dq_scale / dk_scale (D floats each) are overwritten: per-(sequence, head) partial rows in ws, folded in index order (no atomics).
 extern "C" int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout, int lddo, void* dqkv, int lddq,
                                       const float* q_scale, const float* k_scale, const float* cos_table, const float* sin_table,
                                       const uint8_t* mask, int mask_div, float* dq_scale, float* dk_scale,
-                                      int A, int T, int heads, int D, float eps, int dtype, void* stream)
+                                      int A, int T, int heads, int D, float eps, int dtype, void* ws, size_t ws_bytes, void* stream)
 {
     AttnDims d{A, T, heads, D, mask_div, eps};
     if (!qkv || !dout || !dqkv || !q_scale || !k_scale || !cos_table || !sin_table || !dq_scale || !dk_scale || !attn_ok(d) ||
         ld < 3 * heads * D || lddq < 3 * heads * D || lddo < heads * D) return VVAE_ERR_BAD_ARG;
+    if (!ws || ws_bytes < vvae_temporal_attn_bwd_ws_bytes(A, heads, D) || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
+    float* part = (float*)ws;
     const size_t per_wave = sizeof(float) * (6 * (size_t)buf_floats(T, D) + (size_t)T * (T + 1) + 2 * (size_t)T);
     int wpb = (int)(65536 / per_wave); if (wpb > 4) wpb = 4;
     size_t lds = per_wave * (wpb > 0 ? wpb : 1);
     if (wpb < 1) { wpb = 1; if (lds > kMaxLds) return VVAE_ERR_BAD_ARG; }
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if ((e = vvae_zero_async(dq_scale, sizeof(float) * D, s)) != hipSuccess) return (int)e;
-    if ((e = vvae_zero_async(dk_scale, sizeof(float) * D, s)) != hipSuccess) return (int)e;
     dim3 grid(ceil_div((long)A * heads, wpb));
     if (dtype == VVAE_DT_F32) {
         auto k = temporal_attn_bwd_kernel<float>;
@@ -309,7 +317,7 @@ extern "C" int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout,
             attr_lds = lds;
         }
         hipLaunchKernelGGL(k, grid, dim3(64 * wpb), lds, s, (const float*)qkv, ld, (const float*)dout, lddo, (float*)dqkv, lddq,
-                           q_scale, k_scale, cos_table, sin_table, mask, dq_scale, dk_scale, d, wpb);
+                           q_scale, k_scale, cos_table, sin_table, mask, part, part, d, wpb);
     } else if (dtype == VVAE_DT_BF16) {
         auto k = temporal_attn_bwd_kernel<bf16_t>;
         static size_t attr_lds = 65536;
@@ -318,8 +326,11 @@ extern "C" int vvae_temporal_attn_bwd(const void* qkv, int ld, const void* dout,
             attr_lds = lds;
         }
         hipLaunchKernelGGL(k, grid, dim3(64 * wpb), lds, s, (const bf16_t*)qkv, ld, (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddq,
-                           q_scale, k_scale, cos_table, sin_table, mask, dq_scale, dk_scale, d, wpb);
+                           q_scale, k_scale, cos_table, sin_table, mask, part, part, d, wpb);
     } else return VVAE_ERR_BAD_ARG;
+    VVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vvae_reduce_rows_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, s, (const float*)part, A * heads, (long)2 * D, 2 * D, dq_scale, D,
+                       dk_scale);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -4,7 +4,8 @@
 extern "C" {
 int vvae_conv3d_fwd_generic(const void*, int, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*);
 int vvae_conv3d_dgrad_generic(const void*, int, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, void*);
-int vvae_conv3d_wgrad_generic(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, int, void*);
+int vvae_conv3d_wgrad_generic(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
+size_t vvae_conv3d_wgrad_generic_ws_bytes(int, int, int, int, int, int, int, int, int);
 int vvae_conv3d_fwd_bf16(const void*, int, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
 int vvae_conv3d_wgrad_bf16(const void*, int, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, void*, size_t, void*);
 size_t vvae_conv3d_bf16_ws_bytes(int, int, int, int, int, int, int, int, int, int);
@@ -30,10 +31,15 @@ extern "C" void vvae_conv3d_force_generic(int on) { g_force_generic = on; }
 // Scratch bytes the caller must provide to fwd / dgrad / wgrad for this shape (0 = none needed).
 extern "C" size_t vvae_conv3d_workspace_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int dtype, int which)
 {
-    if (g_force_generic) return 0;
-    if (pointwise_shape(Cin, Cout, kt, kh, kw)) return which == 2 ? vvae_conv_pointwise_ws_bytes((long)N * T * H * W, Cin, Cout) : 0;
-    if (dtype != VVAE_DT_BF16) return 0;
-    return vvae_conv3d_bf16_ws_bytes(N, T, H, W, Cin, Cout, kt, kh, kw, which);
+    const size_t generic = which == 2 ? vvae_conv3d_wgrad_generic_ws_bytes(N, T, H, W, Cin, Cout, kt, kh, kw) : 0;
+    if (g_force_generic) return generic;
+    if (pointwise_shape(Cin, Cout, kt, kh, kw)) {                     // (vvae_conv3d_wgrad falls back to generic when the pointwise kernels decline)
+        const size_t pw = which == 2 ? vvae_conv_pointwise_ws_bytes((long)N * T * H * W, Cin, Cout) : 0;
+        return pw > generic ? pw : generic;
+    }
+    if (dtype != VVAE_DT_BF16) return generic;
+    const size_t fast = vvae_conv3d_bf16_ws_bytes(N, T, H, W, Cin, Cout, kt, kh, kw, which);
+    return fast > generic ? fast : generic;                           // (the fast path may decline a pitch: the generic path then needs its own)
 }
 
 // y[n,t,h,w,co] = bias[co] + sum_{a,b,c,ci} x[n,t+a-pt,h+b-ph,w+c-pw,ci] * w[a,b,c,ci,co]   (zero padding)
@@ -70,5 +76,5 @@ extern "C" int vvae_conv3d_wgrad(const void* x, int ldx, const void* dy, int ldd
         return vvae_conv_pointwise_wgrad(x, ldx, dy, lddy, dw, dbias, (long)N * T * H * W, Cin, Cout, dtype, ws, ws_bytes, stream);
     if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, lddy, 2, 0))
         return vvae_conv3d_wgrad_bf16(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, ws, ws_bytes, stream);
-    return vvae_conv3d_wgrad_generic(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
+    return vvae_conv3d_wgrad_generic(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, ws, ws_bytes, stream);
 }

@@ -88,11 +88,12 @@ __global__ __launch_bounds__(256) void conv3d_f32mfma_kernel(
     }
 }
 
-// dW[tap][ci][co] += sum_v x[v+off(tap)][ci] * dy[v][co]   (atomic fp32 accumulate; dW pre-zeroed)
+// part[chunk][tap][ci][co] = sum over the chunk's voxels v of x[v+off(tap)][ci] * dy[v][co]: every (chunk, tap, ci tile, co tile) is written by
+// exactly one workgroup (no atomics, no zero fill); vvae_reduce_rows_kernel folds the chunks in index order -> bitwise reproducible.
 // grid: x = voxel chunk, y = tap, z = ci tile.  Each wave strides over 4-voxel k-steps.
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void conv3d_wgrad_f32mfma_kernel(
-    const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, float* __restrict__ dw,
+    const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, float* __restrict__ part,
     ConvDims d, int co_tile_base, int voxels_per_block)
 {
     __shared__ float red[4][NT][64][4];
@@ -143,37 +144,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_f32mfma_kernel(
         const float s = red[0][i][l][j] + red[1][i][l][j] + red[2][i][l][j] + red[3][i][l][j];
         const int row = (l >> 4) * 4 + j, col = l & 15;           // row = ci in tile, col = co in tile
         const int cii = blockIdx.z * 16 + row, co = (co_tile_base + i) * 16 + col;
-        if (cii < d.Cin && co < d.Cout) atomicAdd(dw + ((long)tap * d.Cin + cii) * d.Cout + co, s);
-    }
-}
-
-// out[c] = sum_v x[v][c]  (bias gradients).  grid.x blocks each reduce a voxel range; atomics to out.
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long V, int C,
-                                                     float* __restrict__ out, int voxels_per_block)
-{
-    // thread layout: 256 threads; column c = tid % Cp (Cp = C rounded to pow2 <= 256), row lane = tid / Cp
-    __shared__ float red[256];
-    int Cp = 1;
-    while (Cp < C && Cp < 256) Cp <<= 1;
-    const int rows = 256 / Cp;
-    const int cl = threadIdx.x % Cp, rl = threadIdx.x / Cp;
-    const long vbeg = (long)blockIdx.x * voxels_per_block;
-    long vend = vbeg + voxels_per_block;
-    if (vend > V) vend = V;
-    for (int c0 = 0; c0 < C; c0 += Cp) {
-        const int c = c0 + cl;
-        float s = 0.f;
-        if (c < C)
-            for (long v = vbeg + rl; v < vend; v += rows) s += ldf(x + v * (long)ld + c);
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (rl == 0 && c < C) {
-            float t = 0.f;
-            for (int i = 0; i < rows; ++i) t += red[i * Cp + cl];
-            atomicAdd(out + c, t);
-        }
-        __syncthreads();
+        if (cii < d.Cin && co < d.Cout) part[(((long)blockIdx.x * gridDim.y + tap) * d.Cin + cii) * d.Cout + co] = s;
     }
 }
 
@@ -238,29 +209,44 @@ int launch_fwd(const void* x, int ldx, const float* w, const float* bias, void* 
     return 0;
 }
 
-template <typename T>
-int launch_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, ConvDims d,
-                 hipStream_t s)
+// voxel chunks of the generic weight gradient (= rows of its partial buffer) and the voxels per chunk
+inline long wgrad_chunks(const ConvDims& d, long* vpb_out)
 {
     const long V = (long)d.N * d.T * d.H * d.W;
     const int taps = d.kt * d.kh * d.kw;
-    hipError_t e = vvae_zero_async(dw, sizeof(float) * (size_t)taps * d.Cin * d.Cout, s);
-    if (e != hipSuccess) return (int)e;
-    const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
-    // aim for >= ~2048 blocks in total, chunk a multiple of 16 voxels
-    long blocks_xy = (long)taps * ci_tiles;
-    long want = 4096 / (blocks_xy > 0 ? blocks_xy : 1);
+    const long blocks_xy = (long)taps * ceil_div(d.Cin, 16);
+    long want = 4096 / (blocks_xy > 0 ? blocks_xy : 1);          // aim for >= ~2048 blocks in total, chunk a multiple of 16 voxels
     if (want < 1) want = 1;
     long vpb = (V + want - 1) / want;
     vpb = ((vpb + 15) / 16) * 16;
     if (vpb < 256) vpb = 256;
-    dim3 grid(ceil_div(V, vpb), taps, ci_tiles);
+    if (vpb_out) *vpb_out = vpb;
+    return ceil_div(V, vpb);
+}
+
+inline size_t wgrad_ws_bytes(const ConvDims& d)
+{
+    const long V = (long)d.N * d.T * d.H * d.W;
+    const size_t slab = (size_t)wgrad_chunks(d, nullptr) * d.kt * d.kh * d.kw * d.Cin * d.Cout;
+    const size_t bias = (size_t)((V + 255) / 256 < 1024 ? (V + 255) / 256 : 1024) * d.Cout;
+    return (slab + bias) * sizeof(float);
+}
+
+template <typename T>
+int launch_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, ConvDims d, float* ws, hipStream_t s)
+{
+    const long V = (long)d.N * d.T * d.H * d.W;
+    const int taps = d.kt * d.kh * d.kw;
+    const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
+    long vpb = 0;
+    const long chunks = wgrad_chunks(d, &vpb);
+    dim3 grid((unsigned)chunks, taps, ci_tiles);
     const T* xp = (const T*)x;
     const T* dyp = (const T*)dy;
     for (int base = 0; base < co_tiles;) {
         const int rem = co_tiles - base;
         const int nt = rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
-#define GO(NTV) hipLaunchKernelGGL((conv3d_wgrad_f32mfma_kernel<T, NTV>), grid, dim3(256), 0, s, xp, ldx, dyp, lddy, dw, d, base, (int)vpb)
+#define GO(NTV) hipLaunchKernelGGL((conv3d_wgrad_f32mfma_kernel<T, NTV>), grid, dim3(256), 0, s, xp, ldx, dyp, lddy, ws, d, base, (int)vpb)
         switch (nt) {
             case 8: GO(8); break;
             case 4: GO(4); break;
@@ -271,11 +257,17 @@ int launch_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, fl
         VVAE_LAUNCH_CHECK();
         base += nt;
     }
-    if (dbias) {
-        e = vvae_zero_async(dbias, sizeof(float) * d.Cout, s);
-        if (e != hipSuccess) return (int)e;
-        const int vb = 4096;
-        hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(V, vb)), dim3(256), 0, s, dyp, lddy, V, d.Cout, dbias, vb);
+    const long ncols = (long)taps * d.Cin * d.Cout;
+    hipLaunchKernelGGL(vvae_reduce_rows_kernel, dim3((unsigned)ceil_div(ncols, 32L)), dim3(256), 0, s, (const float*)ws, (int)chunks, ncols, (int)ncols,
+                       dw, (int)ncols, (float*)nullptr);
+    VVAE_LAUNCH_CHECK();
+    if (dbias) {                                                  // two-stage column sum (vvae_colsum's kernels), partial rows behind the slab
+        float* part = ws + chunks * ncols;
+        const long nb = (V + 255) / 256 < 1024 ? (V + 255) / 256 : 1024;
+        const int vb = (int)((V + nb - 1) / nb);
+        hipLaunchKernelGGL((colsum_part_kernel<T>), dim3((unsigned)nb), dim3(256), 0, s, dyp, lddy, V, d.Cout, part, vb);
+        VVAE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(d.Cout, 256)), dim3(256), 0, s, (const float*)part, (int)nb, d.Cout, dbias);
         VVAE_LAUNCH_CHECK();
     }
     return 0;
@@ -316,15 +308,25 @@ extern "C" int vvae_conv3d_dgrad_generic(const void* dy, int lddy, const float* 
     return VVAE_ERR_BAD_ARG;
 }
 
+// Scratch bytes of vvae_conv3d_wgrad_generic: one fp32 partial dW per voxel chunk + the partial rows of the bias column sum.
+extern "C" size_t vvae_conv3d_wgrad_generic_ws_bytes(int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw)
+{
+    ConvDims d{N, T, H, W, Cin, Cout, kt, kh, kw};
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return wgrad_ws_bytes(d);
+}
+
+// dw / dbias overwritten; ws: vvae_conv3d_wgrad_generic_ws_bytes(...) bytes, 16-byte aligned.  No atomics: per-chunk partials folded in index order.
 extern "C" int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
                                          int N, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
-                                         int dtype, void* stream)
+                                         int dtype, void* ws, size_t ws_bytes, void* stream)
 {
     ConvDims d{N, T, H, W, Cin, Cout, kt, kh, kw};
     if (!x || !dy || !dw || !dims_ok(d, ldx, lddy, false)) return VVAE_ERR_BAD_ARG;
+    if (!ws || ws_bytes < wgrad_ws_bytes(d) || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == VVAE_DT_F32) return launch_wgrad<float>(x, ldx, dy, lddy, dw, dbias, d, s);
-    if (dtype == VVAE_DT_BF16) return launch_wgrad<bf16_t>(x, ldx, dy, lddy, dw, dbias, d, s);
+    if (dtype == VVAE_DT_F32) return launch_wgrad<float>(x, ldx, dy, lddy, dw, dbias, d, (float*)ws, s);
+    if (dtype == VVAE_DT_BF16) return launch_wgrad<bf16_t>(x, ldx, dy, lddy, dw, dbias, d, (float*)ws, s);
     return VVAE_ERR_BAD_ARG;
 }
 

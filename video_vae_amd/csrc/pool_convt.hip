@@ -131,10 +131,11 @@ __global__ __launch_bounds__(256) void convt_f32mfma_kernel(const T* __restrict_
     }
 }
 
-// dK[1-a][1-b][ci][co] += sum_v x[v][ci] * dy[up(v,a,b)][co]   grid: x = voxel chunk, y = ab, z = ci tile
+// part[chunk][1-a][1-b][ci][co] = sum over the chunk's voxels of x[v][ci] * dy[up(v,a,b)][co]; every element written by one workgroup, the chunks
+// folded in index order afterwards (no atomics).   grid: x = voxel chunk, y = ab, z = ci tile
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void convt_wgrad_f32mfma_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
-                                                                  float* __restrict__ dw, CtDims d, int co_tile_base, int voxels_per_block)
+                                                                  float* __restrict__ part, CtDims d, int co_tile_base, int voxels_per_block)
 {
     __shared__ float red[4][NT][64][4];
     const long V = (long)d.NT * d.H * d.W;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void convt_wgrad_f32mfma_kernel(const T* __res
         const int i = e >> 8, l = (e >> 2) & 63, j = e & 3;
         const float s = red[0][i][l][j] + red[1][i][l][j] + red[2][i][l][j] + red[3][i][l][j];
         const int cii = blockIdx.z * 16 + (l >> 4) * 4 + j, co = (co_tile_base + i) * 16 + (l & 15);
-        if (cii < d.Cin && co < d.Cout) atomicAdd(dw + ((long)tap * d.Cin + cii) * d.Cout + co, s);
+        if (cii < d.Cin && co < d.Cout) part[(((long)blockIdx.x * 4 + tap) * d.Cin + cii) * d.Cout + co] = s;
     }
 }
 
@@ -192,25 +193,35 @@ int launch_convt(const void* in, int ldin, const float* w, const float* bias, vo
     return 0;
 }
 
-template <typename T>
-int launch_convt_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, CtDims d, hipStream_t s)
+inline long convt_wgrad_chunks(const CtDims& d, long* vpb_out)
 {
     const long V = (long)d.NT * d.H * d.W;
-    hipError_t e = vvae_zero_async(dw, sizeof(float) * 4 * (size_t)d.Cin * d.Cout, s);
-    if (e != hipSuccess) return (int)e;
-    const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
-    long want = 2048 / (4L * ci_tiles); if (want < 1) want = 1;
+    long want = 2048 / (4L * ceil_div(d.Cin, 16)); if (want < 1) want = 1;
     long vpb = (V + want - 1) / want; vpb = ((vpb + 15) / 16) * 16; if (vpb < 256) vpb = 256;
-    dim3 grid(ceil_div(V, vpb), 4, ci_tiles);
+    if (vpb_out) *vpb_out = vpb;
+    return ceil_div(V, vpb);
+}
+
+template <typename T>
+int launch_convt_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, CtDims d, float* ws, hipStream_t s)
+{
+    const int ci_tiles = ceil_div(d.Cin, 16), co_tiles = ceil_div(d.Cout, 16);
+    long vpb = 0;
+    const long chunks = convt_wgrad_chunks(d, &vpb);
+    dim3 grid((unsigned)chunks, 4, ci_tiles);
     for (int base = 0; base < co_tiles;) {
         const int rem = co_tiles - base;
         const int nt = rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
-#define GO(NTV) hipLaunchKernelGGL((convt_wgrad_f32mfma_kernel<T, NTV>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy, dw, d, base, (int)vpb)
+#define GO(NTV) hipLaunchKernelGGL((convt_wgrad_f32mfma_kernel<T, NTV>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy, ws, d, base, (int)vpb)
         switch (nt) { case 8: GO(8); break; case 4: GO(4); break; case 2: GO(2); break; default: GO(1); break; }
 #undef GO
         VVAE_LAUNCH_CHECK();
         base += nt;
     }
+    const long ncols = 4L * d.Cin * d.Cout;
+    hipLaunchKernelGGL(vvae_reduce_rows_kernel, dim3((unsigned)ceil_div(ncols, 32L)), dim3(256), 0, s, (const float*)ws, (int)chunks, ncols, (int)ncols,
+                       dw, (int)ncols, (float*)nullptr);
+    VVAE_LAUNCH_CHECK();
     return 0;
 }
 
@@ -285,13 +296,23 @@ extern "C" int vvae_convt_1x2x2_dgrad(const void* dy, int lddy, const float* w, 
 }
 
 // dw (1,2,2,Cin,Cout) fp32 overwritten.  (dbias = vvae_colsum(dy).)
+// Scratch bytes of vvae_convt_1x2x2_wgrad: one fp32 partial dK per voxel chunk.
+extern "C" size_t vvae_convt_1x2x2_wgrad_ws_bytes(int NT, int H, int W, int Cin, int Cout)
+{
+    if (NT <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    CtDims d{NT, H, W, Cin, Cout};
+    return (size_t)convt_wgrad_chunks(d, nullptr) * 4 * Cin * Cout * sizeof(float);
+}
+
+// dw (1,2,2,Cin,Cout) fp32 overwritten; ws: vvae_convt_1x2x2_wgrad_ws_bytes(...) bytes.  No atomics: per-chunk partials folded in index order.
 extern "C" int vvae_convt_1x2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw,
-                                      int NT, int H, int W, int Cin, int Cout, int dtype, void* stream)
+                                      int NT, int H, int W, int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, void* stream)
 {
     if (!x || !dy || !dw || NT <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || lddy < Cout) return VVAE_ERR_BAD_ARG;
+    if (!ws || ws_bytes < vvae_convt_1x2x2_wgrad_ws_bytes(NT, H, W, Cin, Cout) || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
     CtDims d{NT, H, W, Cin, Cout};
-    if (dtype == VVAE_DT_F32) return launch_convt_wgrad<float>(x, ldx, dy, lddy, dw, d, (hipStream_t)stream);
-    if (dtype == VVAE_DT_BF16) return launch_convt_wgrad<bf16_t>(x, ldx, dy, lddy, dw, d, (hipStream_t)stream);
+    if (dtype == VVAE_DT_F32) return launch_convt_wgrad<float>(x, ldx, dy, lddy, dw, d, (float*)ws, (hipStream_t)stream);
+    if (dtype == VVAE_DT_BF16) return launch_convt_wgrad<bf16_t>(x, ldx, dy, lddy, dw, d, (float*)ws, (hipStream_t)stream);
     return VVAE_ERR_BAD_ARG;
 }
 

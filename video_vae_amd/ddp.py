@@ -15,13 +15,22 @@ only the transport -- bucketing and overlap are owned here and in optim.Optimize
 
 Replicas stay bit-identical: every rank applies the same update to the same all-reduced buffer
 (the property the reference checks at claude_distributed/test_distributed.py:159-163).
+
+``grad_dtype=torch.bfloat16`` (train.py / bench.py ``--grad-dtype bf16``) halves what crosses xGMI: a landed bucket is rounded to bf16
+(one cast launch), all-reduced in bf16 and widened back into the fp32 buffer behind the wait.  A ring all-reduce moves
+2 (N - 1) / N x 683 MB per GPU in fp32 over point-to-point links of ~153 GB/s each; at N = 2 and 4, where one or three links carry it,
+that is the part of the step the backward cannot hide.  The price is the gradient's mantissa (8 bits per addend, the sum kept in
+bf16 by the transport); replicas still hold identical values.  Default fp32 = the reference's arithmetic.
 """
 import torch
 import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, optimizer, process_group=None):
+    def __init__(self, optimizer, process_group=None, grad_dtype=torch.float32):
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype is torch.float32 or torch.bfloat16")
+        self.grad_dtype = grad_dtype
         self.opt = optimizer
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
@@ -36,14 +45,24 @@ class GradReducer:
         s, e = self.opt.buckets[b]
         if self.fence:
             torch.cuda.synchronize()
-        self.handles.append(dist.all_reduce(self.opt.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.grad_dtype == torch.float32:
+            self.handles.append((dist.all_reduce(self.opt.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, s, e))
+        else:
+            low = self.opt.g[s:e].to(self.grad_dtype)                  # rounded once on this rank; the transport sums in bf16
+            if self.fence:
+                torch.cuda.synchronize()
+            self.handles.append((dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True), low, s, e))
 
     def reset(self):
         self.handles = []
 
     def finish(self):
-        for h in self.handles:
+        for h, low, s, e in self.handles:
             h.wait()
+            if low is not None:
+                if self.fence:
+                    torch.cuda.synchronize()
+                self.opt.g[s:e].copy_(low)                             # widened back behind the wait, on the current stream
         if self.fence and self.handles:
             torch.cuda.synchronize()
         self.handles = []

@@ -699,7 +699,8 @@ def convt_wgrad_raw(x, dy, kshape):
     n, t, h, w, cin = x.shape
     cout = kshape[-1]
     dw = torch.empty(kshape, dtype=torch.float32, device=x.device)
-    check(lib().vvae_convt_1x2x2_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), n * t, h, w, cin, cout, _dt(x), _stream()),
+    ws, wsb = _ws(lib().vvae_convt_1x2x2_wgrad_ws_bytes(n * t, h, w, cin, cout), x.device)
+    check(lib().vvae_convt_1x2x2_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), n * t, h, w, cin, cout, _dt(x), _p(ws), wsb, _stream()),
           "vvae_convt_1x2x2_wgrad")
     return dw
 
@@ -861,8 +862,9 @@ class _TemporalAttn(torch.autograd.Function):
         else:
             dqs = torch.empty((d,), dtype=torch.float32, device=qkv.device)
             dks = torch.empty((d,), dtype=torch.float32, device=qkv.device)
+            ws, wsb = _ws(lib().vvae_temporal_attn_bwd_ws_bytes(a, heads, d), qkv.device)
             check(lib().vvae_temporal_attn_bwd(_p(qkv), ld, _p(do), lddo, _p(dqkv), c3, _p(qs), _p(ks), _p(cos), _p(sin), _p(mask),
-                                               mask_div, _p(dqs), _p(dks), a, t, heads, d, eps, dt, _stream()),
+                                               mask_div, _p(dqs), _p(dks), a, t, heads, d, eps, dt, _p(ws), wsb, _stream()),
                   "vvae_temporal_attn_bwd")
         return dqkv, dqs.to(pdtype), dks.to(pdtype), None, None, None, None, None, None, None
 

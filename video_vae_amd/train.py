@@ -64,11 +64,12 @@ class StepRunner:
     graph, since the loss constants are baked into the captured launches.  Each graph draws its noise from its own ``Rngs`` (a captured
     step pins the draws of ITS rngs to static buffers; the eager fallback keeps drawing from the driver's)."""
 
-    def __init__(self, model, opt, hw, rngs, perceptual_loss_fn=None, vgg_params=None, use_graph=True, capture_after=1, log=None):
+    def __init__(self, model, opt, hw, rngs, perceptual_loss_fn=None, vgg_params=None, use_graph=True, capture_after=1, log=None, enc_segments=9):
         self.model, self.opt, self.hw, self.rngs = model, opt, hw, rngs
         self.ploss, self.vgg_params = perceptual_loss_fn, vgg_params
         self.use_graph, self.capture_after, self.log = use_graph, capture_after, log or (lambda msg: None)
         self.graphs, self.seen = {}, {}
+        self.enc_segments = enc_segments
         self.mode = "eager"
 
     def __call__(self, video, mask, hparams):
@@ -90,7 +91,8 @@ class StepRunner:
                 t0 = time.perf_counter()
                 gc.collect()                                     # no autograd graph of an eager step may outlive into the capture
                 g = GraphedTrainStep(self.model, self.opt, video, mask, dict(hparams), self.hw, V.Rngs(1_000_003 * (self.rngs.seed + 1) + len(self.seen)),
-                                     perceptual_loss_fn=self.ploss, vgg_params=self.vgg_params, stream=torch.cuda.current_stream())
+                                     perceptual_loss_fn=self.ploss, vgg_params=self.vgg_params, stream=torch.cuda.current_stream(),
+                                     enc_segments=self.enc_segments)
                 self.graphs[shape] = (hkey, g)
                 self.log(f"captured the train step for video {tuple(video.shape)} in {time.perf_counter() - t0:.1f} s "
                          f"({1 + len(g.graphs)} hipGraph{'s' if g.graphs else ''})")
@@ -118,6 +120,8 @@ def main():
     ap.add_argument("--small", action="store_true", help="tiny model (depth 1) for smoke runs")
     ap.add_argument("--data", type=str, default=None, help="directory of clips (videos{i}/*.npy|npz|mp4...): the host input pipeline")
     ap.add_argument("--num_workers", type=int, default=4)
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="dtype of the gradient all-reduce (ddp.GradReducer)")
+    ap.add_argument("--enc-segments", type=int, default=9, help="data parallel: hipGraphs the encoder's backward is cut into (graph.py)")
     ap.add_argument("--eager", action="store_true", help="never capture: every step through the eager L.train_step")
     ap.add_argument("--capture_after", type=int, default=1, help="eager steps of a (batch, frames) shape before its step is captured as a hipGraph")
     ap.add_argument("--log_every", type=int, default=10)
@@ -157,7 +161,7 @@ def main():
     cls = rl_model.VideoVAE if args.flavour == "rl" else V.VideoVAE
     model = cls(rngs=V.Rngs(2), **cfg).to(dev)
     opt = optim.Optimizer(model, optim.reference_schedule(batch_size=args.per_device_batch_size * world))
-    red = ddp.GradReducer(opt) if world > 1 else None
+    red = ddp.GradReducer(opt, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32) if world > 1 else None
     hparams = dict(L.HPARAMS)
     if args.model_path:
         if rank == 0 or world == 1:
@@ -177,7 +181,8 @@ def main():
         ploss = perceptual.get_adversarial_perceptual_loss_fn(vgg)
     rngs = V.Rngs(3 + rank)
     log = (lambda msg: print(msg, flush=True)) if rank == 0 else (lambda msg: None)
-    runner = StepRunner(model, opt, hw, rngs, ploss, vgg_params, use_graph=not args.eager, capture_after=args.capture_after, log=log)
+    runner = StepRunner(model, opt, hw, rngs, ploss, vgg_params, use_graph=not args.eager, capture_after=args.capture_after, log=log,
+                        enc_segments=args.enc_segments)
     if args.sample_every and not args.sample_dir:
         ap.error("--sample_every needs --sample_dir")
 
