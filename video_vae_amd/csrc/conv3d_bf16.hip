@@ -1452,7 +1452,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 //            CIB COB KH KW TH AG RG MINW workgroups/CU
-typedef WgCfg<16, 16, 3, 3, 8, 1, 1, 2, 2, 2> W333_16_16;    //  3 waves, two steps' operands in flight
+typedef WgCfg<16, 16, 3, 3, 8, 1, 2, 3, 2, 1> W333_16_16;    //  6 waves: two row groups of an 8-row tile, 2 workgroups per CU
 typedef WgCfg<32, 16, 3, 3, 8, 1, 2, 3, 1> W333_32_16;       // 12 waves: two row groups of an 8-row tile
 typedef WgCfg<32, 32, 3, 3, 4, 1, 1, 3, 1> W333_32_32;       // 12 waves
 typedef WgCfg<16, 16, 7, 7, 4, 4, 1, 3, 1, 2> W377_16_16;    // 12 waves: 3 temporal taps x 4 groups of kernel rows
