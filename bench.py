@@ -101,10 +101,12 @@ def parse():
                     help="capture the step as two graphs cut at the encoder's last block even at N = 1 (the N > 1 default)")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="dtype the gradient buckets cross the transport in (bf16: half the xGMI bytes, see video_vae_amd/ddp.py); f32 = the reference")
-    ap.add_argument("--enc-segments", type=int, default=9,
+    ap.add_argument("--enc-segments", type=int, default=3,
                     help="data parallel, graph mode: hipGraphs the encoder's backward is cut into (1 + this many graphs per step).  The buckets of a "
-                         "segment are all-reduced under the segments still to come; only the LAST segment's wait for the end of backward: 9 -> one "
-                         "encoder block + the patch embedding = 32 MB of the 683 MB (3 -> 95 MB)")
+                         "segment are all-reduced under the segments still to come; only the LAST segment's wait for the end of backward: 3 -> 95 MB "
+                         "of the 683 MB, 9 -> one encoder block + the patch embedding = 32 MB.  Every cut costs ~0.2 ms of step time at N = 1 "
+                         "(profiles/r03_bench_force_ddp_line.json: 9 segments 37.0 ms, 3 segments 35.7, one graph 34.9), more than a ring moves 63 MB "
+                         "in: the default stays 3")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-graph", "--eager", action="store_true", dest="no_graph",
@@ -495,7 +497,7 @@ def main():
                         "alg_GBps": gbs, "alg_TFLOPps": tfs, "frac_mfma": tfs / MFMA_PEAK_TFS,
                         "kernel_ms_per_step": top["ms"] / nsteps_timed, "timed_in": timed_in}
 
-            # `roofline`: the north-star kernel -- Conv3d forward + input gradient (conv3d_bf16_roll_kernel / conv3d_bf16_kernel, every UNet layer) --
+            # `roofline`: the north-star kernel -- Conv3d forward + input gradient (conv3d_bf16_roll_kernel / conv3d_bf16_deep_kernel, every UNet layer) --
             # priced against HBM as BASELINE.json's north_star fixes it (V*(Cin+Cout)*e bytes per launch), with its
             # matrix-core rate beside it.  `roofline_step_dominant`: the hand-written kernel with the largest total time per step
             # (all its shapes together), bound set by arithmetic intensity against the machine balance (312 FLOP/B).

@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # bench.py kernel tag -> (kernel families of the PMC table, source files)
 KERNELS = {
-    "conv3d_bf16_roll_kernel|conv3d_bf16_kernel": (["conv3d_bf16_roll_kernel", "conv3d_bf16_kernel"], ["conv3d_bf16.hip", "common.hpp"]),
+    "conv3d_bf16_roll_kernel|conv3d_bf16_deep_kernel": (["conv3d_bf16_roll_kernel", "conv3d_bf16_deep_kernel", "conv3d_bf16_kernel"], ["conv3d_bf16.hip", "common.hpp"]),
     "conv3d_wgrad": (["conv3d_wgrad_bf16_kernel", "wgrad_reduce_kernel"], ["conv3d_bf16.hip", "common.hpp"]),
     "gemm_tn256_grouped_kernel": (["gemm_tn256_grouped_kernel"], ["gemm_tn256.hip", "common.hpp"]),
     "tattn_fwd_fast": (["tattn16_fwd_mfma"], ["attn_temporal_mfma.hip", "common.hpp"]),

@@ -179,7 +179,7 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None, k_real=0
             ws, wsb = _ws(wsb, x.device)
             check(lib().vvae_conv3d_pack_bf16(_p(kernel), _p(ws), wsb, cin, cout, kt, kh, kw, flags, _stream()),
                   "vvae_conv3d_pack_bf16")
-        check(_launch(tag, alg, flops, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+        check(_launch(tag, alg, flops, "conv3d_bf16_roll_kernel|conv3d_bf16_deep_kernel",
                       lambda: lib().vvae_conv3d_fwd_bf16(_p(x), ldx, None, _p(bias), _p(out), ldo, n, t, h, w, cin, cout, kt, kh,
                                                          kw, flags, 1, _p(ws), wsb, _stream())),
               "vvae_conv3d_fwd_bf16")
@@ -310,7 +310,7 @@ def conv3d_fwd_gn_raw(x, kernel, bias, groups, nblk, packed=None, price=None):
     vox = n * t * h * w
     tag = f"conv3d_fwd {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
     pci, pco = price if price is not None else (cin, cout)
-    check(_launch(tag, vox * (pci + pco) * 2, 2 * vox * kt * kh * kw * pci * pco, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+    check(_launch(tag, vox * (pci + pco) * 2, 2 * vox * kt * kh * kw * pci * pco, "conv3d_bf16_roll_kernel|conv3d_bf16_deep_kernel",
                   lambda: lib().vvae_conv3d_fwd_bf16_gn(_p(x), ldx, _p(kernel), _p(bias), _p(out), cout, n, t, h, w, cin, cout, kt, kh,
                                                         kw, 1 if packed is not None else 0, _p(ws), wsb, _p(part), groups, _stream())),
           "vvae_conv3d_fwd_bf16_gn")
@@ -400,7 +400,7 @@ def conv3d_cat2_fwd_raw(xa, xb, kernel, bias, groups=0, nblk=0, packed=None):
     part = torch.empty((n, nblk, groups, 2), dtype=torch.float32, device=xa.device) if nblk else None
     vox = n * t * h * w
     tag = f"conv3d_fwd {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
-    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_deep_kernel",
                   lambda: lib().vvae_conv3d_fwd_bf16_cat2(_p(xa), lda, _p(xb), ldb, _p(bias), _p(out), cout, None, 0, ca, n, t, h, w, cin, cout,
                                                           kt, kh, kw, 0, _p(ws), ws.numel(), _p(part), groups, _stream())),
           "vvae_conv3d_fwd_bf16_cat2")
@@ -418,7 +418,7 @@ def conv3d_cat2_dgrad_raw(dy, kernel, ca, packed=None):
     dxb = torch.empty((n, t, h, w, cin - ca), dtype=dy.dtype, device=dy.device)
     vox = n * t * h * w
     tag = f"conv3d_dgrad {cout}->{cin} k{kt}{kh}{kw} @{h}x{w}"
-    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_kernel",
+    check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_bf16_roll_kernel|conv3d_bf16_deep_kernel",
                   lambda: lib().vvae_conv3d_fwd_bf16_cat2(_p(dy), lddy, None, 0, None, _p(dxa), ca, _p(dxb), cin - ca, ca, n, t, h, w, cin, cout,
                                                           kt, kh, kw, 1, _p(ws), ws.numel(), None, 0, _stream())),
           "vvae_conv3d_fwd_bf16_cat2")

@@ -64,7 +64,7 @@ class StepRunner:
     graph, since the loss constants are baked into the captured launches.  Each graph draws its noise from its own ``Rngs`` (a captured
     step pins the draws of ITS rngs to static buffers; the eager fallback keeps drawing from the driver's)."""
 
-    def __init__(self, model, opt, hw, rngs, perceptual_loss_fn=None, vgg_params=None, use_graph=True, capture_after=1, log=None, enc_segments=9):
+    def __init__(self, model, opt, hw, rngs, perceptual_loss_fn=None, vgg_params=None, use_graph=True, capture_after=1, log=None, enc_segments=3):
         self.model, self.opt, self.hw, self.rngs = model, opt, hw, rngs
         self.ploss, self.vgg_params = perceptual_loss_fn, vgg_params
         self.use_graph, self.capture_after, self.log = use_graph, capture_after, log or (lambda msg: None)
@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--data", type=str, default=None, help="directory of clips (videos{i}/*.npy|npz|mp4...): the host input pipeline")
     ap.add_argument("--num_workers", type=int, default=4)
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="dtype of the gradient all-reduce (ddp.GradReducer)")
-    ap.add_argument("--enc-segments", type=int, default=9, help="data parallel: hipGraphs the encoder's backward is cut into (graph.py)")
+    ap.add_argument("--enc-segments", type=int, default=3, help="data parallel: hipGraphs the encoder's backward is cut into (graph.py)")
     ap.add_argument("--eager", action="store_true", help="never capture: every step through the eager L.train_step")
     ap.add_argument("--capture_after", type=int, default=1, help="eager steps of a (batch, frames) shape before its step is captured as a hipGraph")
     ap.add_argument("--log_every", type=int, default=10)
