@@ -67,6 +67,9 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // d/dx silu(x) = s (1 + x (1 - s)), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
 
+#ifndef NT_EXP            // tools/nt_epilogue_probe.py builds timing-only variants: 1 = no global stores in the epilogue, 2 = no epilogue at all
+#define NT_EXP 0
+#endif
 #ifdef NT_STAMPS
 // diagnostic build (tools/nt_timeline_probe.py): wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries of its tiles
 __device__ unsigned long long g_nt_stamps[256 * 16];
@@ -243,6 +246,12 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         __syncthreads();                          // every wave is done with the operand buffers
         NT_STAMP(stamp); ++stamp;                 // main loop done
 
+        if (NT_EXP == 2) {                        // timing-only: the accumulators stay live through a store no launch takes
+            if (d.M < 0) { for (int i = 0; i < NB16; ++i) for (int j = 0; j < MB16; ++j) Cout[i * MB16 + j] = (bf16_t)acc[i][j][0]; }
+            if (!more) break;
+            tb = nb; m0 = nm0; n0 = nn0; first = false;
+            continue;
+        }
         // ---- acc (+bias) -> packed bf16, in registers (48 instead of 96: the half of the waves that parks second holds them through the
         //      first half's stores).  acc[i][j][r]: channel 16 i + 4 kg + r, token 16 j + fr
         uint2 pk[NB16][MB16];
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
                     for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
                     float y[8];
                     if (EPI == EPI_SILU) {
-                        *reinterpret_cast<uint4*>(C2 + gm * d.ldc2 + gn) = v[it];     // pre-activation, kept for backward
+                        if (NT_EXP != 1 || d.M < 0) *reinterpret_cast<uint4*>(C2 + gm * d.ldc2 + gn) = v[it];     // pre-activation, kept for backward
 #pragma unroll
                         for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
                     } else {
@@ -321,9 +330,9 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
                             for (int e = 0; e < 8; ++e) y[e] = x[e] * dsilu_f(r[e]);
                         }
                     }
-                    VecIO<bf16_t, 8>::store(Cout + gm * d.ldc + gn, y);
+                    if (NT_EXP != 1 || d.M < 0) VecIO<bf16_t, 8>::store(Cout + gm * d.ldc + gn, y);
                 } else {
-                    *reinterpret_cast<uint4*>(Cout + gm * d.ldc + gn) = v[it];
+                    if (NT_EXP != 1 || d.M < 0) *reinterpret_cast<uint4*>(Cout + gm * d.ldc + gn) = v[it];
                 }
             }
             if (h == 0) __syncthreads();          // the image is read before the second half overwrites it
