@@ -502,3 +502,35 @@ def test_sigterm_checkpoints_and_exits(dev, tmp_path):
     opt = optim.Optimizer(m, 1e-3)
     V.load_checkpoint(m, opt, str(ck))
     assert opt.count >= 10 and float(opt.m.abs().max()) > 0 and torch.isfinite(opt.p).all()
+
+
+def test_captured_step_holds_no_memset_node_and_the_census_sees_one(dev):
+    """Round 3 root cause of the history-dependent replay: a hipGraph MEMSET node replays garbage on ROCm 7.2, and the
+    framework's multi-block reduction zeroes its semaphores with one.  GraphedTrainStep counts the node types of what it captured
+    (hipGraphGetNodes / hipGraphNodeGetType) and refuses a graph with a memset node; here: (a) the captured VAE step has kernels, no
+    memset; (b) the census does see the memset node of a captured framework reduction with a global reduce (the detector is not blind)."""
+    import video_vae_amd as V
+    from video_vae_amd import optim, loss as L
+    from video_vae_amd.graph import GraphedTrainStep, graph_node_census
+    m = V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **TINY).to(dev)
+    opt = optim.Optimizer(m, 1e-3)
+    video = torch.rand((2, 8, 32, 32, 3), device=dev).to(torch.bfloat16)
+    mask = torch.ones(2, 8, device=dev)
+    gstep = GraphedTrainStep(m, opt, video, mask, L.HPARAMS, 16, V.Rngs(3), warmup=1)
+    c = gstep.census[0]
+    assert c is not None, "this build hands out no raw graph: the memset guard is blind"
+    assert c.get("kernel", 0) > 50 and c.get("memset", 0) == 0, c
+    loss, _ = gstep()
+    assert torch.isfinite(loss)
+    # (b) a reduction over 16 384 rows x 96 columns splits the rows over workgroups: staging buffer + semaphore + hipMemsetAsync
+    x = torch.randn(16384, 96, device=dev, dtype=torch.bfloat16)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        x.sum(0, dtype=torch.float32)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g, stream=s):
+        y = x.sum(0, dtype=torch.float32)
+    c2 = graph_node_census(g)
+    assert c2 is not None and c2.get("memset", 0) >= 1, c2

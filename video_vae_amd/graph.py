@@ -27,12 +27,48 @@ What the capture needs and how it gets it:
     moments and update count are snapshotted before and restored after, so constructing a GraphedTrainStep does not advance
     training: step 0 of the run starts from the weights the caller built (or resumed) and schedule(count) is unchanged.
 """
+import ctypes
 import gc
 
 import torch
 
 from . import loss as L
 from . import ops
+
+
+_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record"}
+_HIP = [None]
+
+
+def graph_node_census(graph):
+    """{node type: count} of a captured ``torch.cuda.CUDAGraph(keep_graph=True)`` (hipGraphGetNodes / hipGraphNodeGetType), or None when
+    this build cannot hand out the raw graph.  Exists for ONE check: a captured step must hold no MEMSET node -- on ROCm 7.2 a replayed
+    memset node fills its buffer with garbage (the node's element count, the low word of an address: tools/memset_node_probe.py), which is
+    how the framework's multi-block reductions (semaphores zeroed by hipMemsetAsync) returned stale results inside the replayed step."""
+    raw = getattr(graph, "raw_cuda_graph", None)
+    if raw is None:
+        return None
+    try:
+        handle = raw()
+        if _HIP[0] is None:
+            _HIP[0] = ctypes.CDLL("libamdhip64.so")
+        hip = _HIP[0]
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(ctypes.c_void_p(handle), None, ctypes.byref(n)) != 0:
+            return None
+        nodes = (ctypes.c_void_p * max(1, n.value))()
+        if hip.hipGraphGetNodes(ctypes.c_void_p(handle), nodes, ctypes.byref(n)) != 0:
+            return None
+        census = {}
+        for i in range(n.value):
+            t = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+                return None
+            name = _NODE_TYPES.get(t.value, f"type{t.value}")
+            census[name] = census.get(name, 0) + 1
+        return census
+    except Exception:
+        return None
 
 
 class GraphedTrainStep:
@@ -202,7 +238,10 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         gc.collect()
         # 3. capture forward + backward + gradient landing on the same stream
-        g = torch.cuda.CUDAGraph()
+        try:
+            g = torch.cuda.CUDAGraph(keep_graph=True)        # keeps the hipGraph_t: its nodes are counted below
+        except TypeError:
+            g = torch.cuda.CUDAGraph()
         if self.debug_dot:
             g.enable_debug_mode()
         # With a process group alive its watchdog thread polls events while we capture: only the capturing thread's own calls
@@ -212,7 +251,10 @@ class GraphedTrainStep:
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
                 self.loss, self.aux = self._stage0()
             for st in range(1, self.nstages):
-                gs = torch.cuda.CUDAGraph()
+                try:
+                    gs = torch.cuda.CUDAGraph(keep_graph=True)
+                except TypeError:
+                    gs = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gs, stream=self.stream, pool=g.pool(), capture_error_mode=mode):
                     self._stage(st)
                 self.graphs.append(gs)
@@ -221,6 +263,13 @@ class GraphedTrainStep:
                 self.loss, self.aux = self._fwd_bwd()
         if not all(opt.landed):
             raise RuntimeError("a gradient bucket did not land inside the captured backward (parameter without gradient)")
+        # what was captured: node types per graph.  A memset node must not be there (see graph_node_census): fail loudly, not staly.
+        self.census = [graph_node_census(x) for x in [g] + self.graphs]
+        for c in self.census:
+            if c and c.get("memset", 0):
+                raise RuntimeError(f"the captured train step holds {c['memset']} hipGraph memset node(s) ({c}): on ROCm 7.2 a replayed memset node writes "
+                                   "garbage, and whatever it was meant to zero (e.g. the semaphore of a multi-block framework reduction) misbehaves on "
+                                   "replay.  Replace the op that issued hipMemsetAsync (DESIGN.md section 3, tools/memset_node_probe.py).")
         self.graph = g
         if self.debug_dot:
             g.debug_dump(self.debug_dot)
