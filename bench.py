@@ -356,7 +356,7 @@ def main():
             loss, _aux = L.train_step(model, opt, v, m, L.HPARAMS, hw, rngs)
             return loss
 
-        step, mode = eager_step, "eager"
+        step, mode, graph_nodes = eager_step, "eager", None
         if not args.no_graph:
             try:
                 from video_vae_amd.graph import GraphedTrainStep
@@ -366,6 +366,7 @@ def main():
                 def step():
                     loss, _aux = gstep(*batch()) if feed is not None else gstep()
                     return loss
+                graph_nodes = gstep.census
                 mode = (f"{1 + len(gstep.graphs)} hipgraphs (fwd + decoder bwd | encoder bwd in {len(gstep.graphs)} segments), each stage's "
                         "all-reduce under the next" if gstep.graphs else "hipgraph(fwd+bwd)") + " + eager all-reduce/clip/Adam"
             except Exception as e:                       # capture is an optimisation, never a requirement
@@ -467,6 +468,8 @@ def main():
                                    + f"B={B}/GPU x 3x{T}x{S}x{S}, {args.dtype} compute, fp32 params, recon+KL loss, clip+Adam",
                        "flavour": args.flavour if args.workload == "vae" else "unet", "params": nparams,
                        "global_batch": B * world, "frames_per_clip": T, "parallelism": f"dp{world}", "launch_mode": mode,
+                       # node types of the captured graph(s) (hipGraphGetNodes): kernels per replayed step; memset nodes must be 0
+                       "graph_nodes": graph_nodes if args.workload == "vae" else None,
                        "settle": f"{args.warmup} warm-up steps, {args.steps} timed steps (cold leg), {settle_steps} untimed steps "
                                  f"({args.settle_seconds:g} s), {args.steps} timed steps (settled leg = value)"},
         }

@@ -1005,10 +1005,12 @@ def test_unpatch_pad_matches_rearrange_then_pad(dev):
 
 
 @pytest.mark.parametrize("ci,co,shape", [(16, 16, (2, 5, 20, 24)), (16, 32, (1, 4, 9, 33)), (32, 16, (2, 3, 17, 16)), (32, 32, (1, 6, 18, 30)),
-                                         (64, 32, (1, 2, 8, 16))])
+                                         (64, 32, (1, 2, 8, 16)), (32, 64, (2, 3, 12, 20)), (64, 64, (1, 5, 9, 17)), (64, 128, (1, 2, 8, 16)),
+                                         (128, 128, (2, 3, 6, 16)), (128, 64, (1, 4, 10, 18)), (48, 16, (1, 2, 8, 16))])
 def test_conv_block_gn_statistics_from_conv_epilogue(dev, ci, co, shape):
-    """ConvBlock3D where the rolling conv kernel sums its own rounded outputs per GroupNorm group (no statistics pass over the
-    tensor) == the two-kernel form (vvae_gn_stats); (64, 32) is not eligible and must take the two-kernel form itself.
+    """ConvBlock3D where the conv kernel (rolling; round 3: also the deep rolling kernel of the 64 / 128-channel layers, whose workgroups cover
+    whole GroupNorm groups of their channel block) sums its own rounded outputs per GroupNorm group (no statistics pass over the tensor)
+    == the two-kernel form (vvae_gn_stats); (48, 16) is not eligible and must take the two-kernel form itself.
     Reference train/unet.py:13-30."""
     import video_vae_amd as V
     from video_vae_amd import ops, unet as U
@@ -1020,7 +1022,7 @@ def test_conv_block_gn_statistics_from_conv_epilogue(dev, ci, co, shape):
     x = rnd((n, t, h, w, ci), 100).to(dev, torch.bfloat16)
     gy = rnd((n, t, h, w, co), 101).to(dev, torch.bfloat16)
     eligible = ops.conv3d_gn_blocks(x, blk.conv.kernel, blk.norm.num_groups)
-    assert (eligible > 0) == (ci <= 32)
+    assert (eligible > 0) == (ci != 48)
     # the fused partial sums against a direct fp64 reduction of the conv output
     if eligible:
         yc, part = ops.conv3d_fwd_gn_raw(x, blk.conv.kernel.detach(), blk.conv.bias.detach(), blk.norm.num_groups, eligible)
@@ -1032,6 +1034,7 @@ def test_conv_block_gn_statistics_from_conv_epilogue(dev, ci, co, shape):
     for fused in (True, False):
         try:
             lib().vvae_conv3d_roll_config(1 if fused else 0, 0)
+            lib().vvae_conv3d_deep_config(1 if fused else 0)
             xx = x.clone().requires_grad_(True)
             blk.zero_grad()
             y = blk(xx)
@@ -1039,6 +1042,7 @@ def test_conv_block_gn_statistics_from_conv_epilogue(dev, ci, co, shape):
             res.append([y.detach(), xx.grad] + [p.grad.clone() for p in blk.parameters()])
         finally:
             lib().vvae_conv3d_roll_config(1, 0)
+            lib().vvae_conv3d_deep_config(1)
     for k, (a, b) in enumerate(zip(*res)):
         assert_close_scaled(a, b, rel=2e-2 if k < 2 else 1e-3, what=f"tensor {k}")
     assert float((res[0][0] != res[1][0]).float().mean()) < 0.02          # the statistics differ in fp32 summation order only

@@ -325,7 +325,9 @@ int launch_roll_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias
 // for the 3x7x7 mixer with 12 real channels on the rolling kernel; anything else packs and multiplies the padded product.
 inline int real_k(int flags, int kh) { return (kh == 7 && ((flags >> 8) & 0xff) == 12 && roll_enabled()) ? 12 : 0; }
 int roll_gn_blocks_any(BfDims d, int kh, int groups);
-int launch_deep_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s);
+int launch_deep_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s, float* gn_part = nullptr,
+                    int gn_groups = 0);
+int deep_gn_blocks_any(BfDims d, int kh, int groups);
 }
 
 // which: 0 fwd (K = Cin, produced = Cout), 1 dgrad (K = Cout, produced = Cin), 2 wgrad (ld_in = ldx, ld_out = lddy).
@@ -447,11 +449,14 @@ extern "C" int vvae_conv3d_gn_blocks(int N, int T, int H, int W, int Cin, int Co
                                      int groups)
 {
     if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || !vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ld_in, ld_out, 0, 0)) return 0;
-    if (Cin != chunk_of(Cin)) return 0;
     const long vox = (long)N * T * H * W;
     if (span_bytes(vox, ld_in, Cin) >= (1L << 31) || span_bytes(vox, ld_out, Cout) >= (1L << 31)) return 0;    // see launch_roll
     BfDims d{N, T, H, W, Cin, Cout, 0, 0};
-    return roll_gn_blocks_any(d, kh, groups);
+    if (Cin == chunk_of(Cin)) {
+        const int nb = roll_gn_blocks_any(d, kh, groups);
+        if (nb > 0) return nb;
+    }
+    return chunk_of(Cin) == 32 ? deep_gn_blocks_any(d, kh, groups) : 0;   // 64 / 128-channel layers, 32 -> >= 64: the deep rolling kernel
 }
 
 // vvae_conv3d_fwd_bf16 (forward only) that also emits the per-group sums of the rounded outputs, so the GroupNorm behind the
@@ -471,7 +476,9 @@ extern "C" int vvae_conv3d_fwd_bf16_gn(const void* x, int ldx, const float* w, c
         if (rc) return rc;
     }
     BfDims d{N, T, H, W, Cin, Cout, 0, 0};
-    return launch_roll_any((const bf16_t*)x, ldx, (const uint4*)ws, bias, (bf16_t*)y, ldy, d, kh, (hipStream_t)stream, gn_part, groups);
+    if (Cin == chunk_of(Cin) && roll_gn_blocks_any(d, kh, groups) > 0)
+        return launch_roll_any((const bf16_t*)x, ldx, (const uint4*)ws, bias, (bf16_t*)y, ldy, d, kh, (hipStream_t)stream, gn_part, groups);
+    return launch_deep_any((const bf16_t*)x, ldx, (const uint4*)ws, bias, (bf16_t*)y, ldy, d, (hipStream_t)stream, gn_part, groups);
 }
 
 // Single-chunk layers with a second tensor on one side (Split2 above): which = 0 forward over concat([x, x2], channels) -- x holds the
@@ -1095,10 +1102,13 @@ struct DeepCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <class C>
+// GN: as conv3d_bf16_roll_kernel<.., GN>: the workgroup also emits, per GroupNorm group it covers, the sum and the sum of squares of the
+// rounded outputs it wrote -- part[n][blk][group][2], blk = (h tile, w tile, time chunk); a workgroup of CO_BLK < CO channels writes the
+// groups of its channel block only (whole groups per block: deep_gn_blocks checks it).
+template <class C, bool GN>
 __global__ __launch_bounds__(C::NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_bf16_deep_kernel(const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wp,
                                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy,
-                                                                       BfDims d, int tchunk)
+                                                                       BfDims d, int tchunk, float* __restrict__ gn_part, int gn_groups)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NCH = C::NCH, NCT = C::NCT, MT = C::MT, KH = C::KH, KW = C::KW, KSTEPS = C::KSTEPS, NX = C::NX;
@@ -1149,6 +1159,7 @@ __global__ __launch_bounds__(C::NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 
     unsigned hoff[OWN];
 #pragma unroll
     for (int m = 0; m < OWN; ++m) { held[m] = make_uint2(0, 0); hoff[m] = OOB; }
+    float gs[2] = {0.f, 0.f}, gss[2] = {0.f, 0.f};                         // GN: this lane's two channel pairs over its rows and frames
 
     for (int tt = t_beg; tt < t_end; ++tt) {
         sx.store(smem + ((tt + 1) & 3) * PLANE, tid);
@@ -1211,11 +1222,46 @@ __global__ __launch_bounds__(C::NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 
             hoff[o] = inside ? (unsigned)(v * ldy + ct * 16 + 4 * g) * 2u : OOB;
             held[o].x = (uint32_t)f2bf(sum[0] + bv[0]) | ((uint32_t)f2bf(sum[1] + bv[1]) << 16);
             held[o].y = (uint32_t)f2bf(sum[2] + bv[2]) | ((uint32_t)f2bf(sum[3] + bv[3]) << 16);
+            if (GN) {                                                      // statistics of what GroupNorm will read: the rounded values
+                const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+                const bf16x2 p0 = __builtin_bit_cast(bf16x2, inside ? held[o].x : 0u), p1 = __builtin_bit_cast(bf16x2, inside ? held[o].y : 0u);
+                gs[0] = __builtin_amdgcn_fdot2_f32_bf16(p0, ones, gs[0], false);
+                gs[1] = __builtin_amdgcn_fdot2_f32_bf16(p1, ones, gs[1], false);
+                gss[0] = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, gss[0], false);
+                gss[1] = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, gss[1], false);
+            }
         }
     }
 #undef FETCH
 #pragma unroll
     for (int m = 0; m < OWN; ++m) buf_store8(ry, hoff[m], held[m]);        // the last step's rows
+    if (GN) {
+        // fold: the 16 voxel lanes of a channel quad (DPP), then the waves that share the output-channel tile (LDS, wave order), then the
+        // channel pairs of each group -- fixed order, no atomics
+        __syncthreads();                                                   // every wave is done with the ring and the scratch
+        float* red = reinterpret_cast<float*>(smem);                       // [wave][pair 0..7][2]
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float a = butterfly_sum<8, 1>(gs[e]), b = butterfly_sum<8, 1>(gss[e]);
+            if (r == 0) { red[(wave * 8 + 2 * g + e) * 2] = a; red[(wave * 8 + 2 * g + e) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        const int gpb = gn_groups * C::CO_BLK / d.CO;                      // groups this workgroup's channel block covers
+        if (tid < gpb) {
+            constexpr int CP = C::CO_BLK / 2;                              // channel pairs of the block: pair cp lives in tile cp / 8
+            const int ppg = CP / gpb;
+            float a = 0.f, b = 0.f;
+            for (int cp = tid * ppg; cp < (tid + 1) * ppg; ++cp) {
+                const int t8 = cp >> 3, q8 = cp & 7;
+                for (int w2 = 0; w2 < C::NW; ++w2)
+                    if ((w2 / NCH) % NCT == t8) { a += red[(w2 * 8 + q8) * 2]; b += red[(w2 * 8 + q8) * 2 + 1]; }
+            }
+            const long nblk = (long)d.tiles_h * d.tiles_w * nch;
+            const long blk = ((long)th * d.tiles_w + tw) * nch + tc;
+            float* pp = gn_part + ((n * nblk + blk) * gn_groups + blockIdx.y * gpb + tid) * 2;
+            pp[0] = a; pp[1] = b;
+        }
+    }
 }
 
 int g_deep = 1;
@@ -1227,37 +1273,66 @@ typedef DeepCfg<2, 4, 1, 8, 3> D64_64;       // K 64 -> 64 per workgroup: TH 8
 typedef DeepCfg<4, 2, 1, 4, 3> D128_32;      // K 128 -> 32 per workgroup: TH 4
 
 template <class C>
-int launch_deep(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s)
+int deep_tchunk(BfDims& d)
 {
-    const long vox = (long)d.N * d.T * d.H * d.W, lim = 1L << 31;
-    if (span_bytes(vox, ldx, d.CK) >= lim || span_bytes(vox, ldy, d.CO) >= lim) return VVAE_ERR_BAD_ARG;
     d.tiles_h = ceil_div(d.H, C::TH);
     d.tiles_w = ceil_div(d.W, C::TW);
     const long cols = (long)d.N * d.tiles_h * d.tiles_w * (d.CO / C::CO_BLK);
     int tchunk = d.T;                                                      // whole clip per workgroup unless that starves the chip
     while (tchunk > 2 && cols * ceil_div(d.T, tchunk) < 256) tchunk = (tchunk + 1) / 2;
+    return tchunk;
+}
+
+// workgroups per sample and channel block = rows per sample of the GroupNorm partial buffer (0: this configuration cannot emit them)
+template <class C>
+int deep_gn_blocks(BfDims d, int groups)
+{
+    if (groups <= 0 || d.CO % (2 * groups) || (groups * C::CO_BLK) % d.CO || groups * C::CO_BLK / d.CO > C::NTHREADS) return 0;
+    const int tchunk = deep_tchunk<C>(d);
+    return d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk);
+}
+
+template <class C>
+int launch_deep(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s, float* gn_part, int gn_groups)
+{
+    const long vox = (long)d.N * d.T * d.H * d.W, lim = 1L << 31;
+    if (span_bytes(vox, ldx, d.CK) >= lim || span_bytes(vox, ldy, d.CO) >= lim) return VVAE_ERR_BAD_ARG;
+    if (gn_part && deep_gn_blocks<C>(d, gn_groups) <= 0) return VVAE_ERR_BAD_ARG;
+    const int tchunk = deep_tchunk<C>(d);
     dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk)), d.CO / C::CO_BLK);
-    auto k = conv3d_bf16_deep_kernel<C>;
-    static bool attr_done = false;
-    if (C::LDS_BYTES > 65536 && !attr_done) {
+    const bool gn = gn_part != nullptr;
+    auto k = gn ? conv3d_bf16_deep_kernel<C, true> : conv3d_bf16_deep_kernel<C, false>;
+    static bool attr_done[2] = {false, false};
+    if (C::LDS_BYTES > 65536 && !attr_done[gn]) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[gn] = true;
     }
-    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk);
+    hipLaunchKernelGGL(k, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, wp, bias, y, ldy, d, tchunk, gn_part, gn_groups);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
 
 // 3 x 3 x 3 layers the deep kernel takes; anything else: VVAE_ERR_BAD_ARG (the caller falls back to the per-frame kernel)
-int launch_deep_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s)
+int launch_deep_any(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf16_t* y, int ldy, BfDims d, hipStream_t s, float* gn_part,
+                    int gn_groups)
 {
     if (!g_deep) return VVAE_ERR_BAD_ARG;
-    if (d.CK == 32 && d.CO % 64 == 0) return launch_deep<D32_64>(x, ldx, wp, bias, y, ldy, d, s);
-    if (d.CK == 64 && d.CO == 32) return launch_deep<D64_32>(x, ldx, wp, bias, y, ldy, d, s);
-    if (d.CK == 64 && d.CO % 64 == 0) return launch_deep<D64_64>(x, ldx, wp, bias, y, ldy, d, s);
-    if (d.CK == 128 && d.CO % 32 == 0) return launch_deep<D128_32>(x, ldx, wp, bias, y, ldy, d, s);
+    if (d.CK == 32 && d.CO % 64 == 0) return launch_deep<D32_64>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups);
+    if (d.CK == 64 && d.CO == 32) return launch_deep<D64_32>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups);
+    if (d.CK == 64 && d.CO % 64 == 0) return launch_deep<D64_64>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups);
+    if (d.CK == 128 && d.CO % 32 == 0) return launch_deep<D128_32>(x, ldx, wp, bias, y, ldy, d, s, gn_part, gn_groups);
     return VVAE_ERR_BAD_ARG;
+}
+
+int deep_gn_blocks_any(BfDims d, int kh, int groups)
+{
+    if (kh != 3 || !g_deep) return 0;
+    if (d.CK == 32 && d.CO % 64 == 0) return deep_gn_blocks<D32_64>(d, groups);
+    if (d.CK == 64 && d.CO == 32) return deep_gn_blocks<D64_32>(d, groups);
+    if (d.CK == 64 && d.CO % 64 == 0) return deep_gn_blocks<D64_64>(d, groups);
+    if (d.CK == 128 && d.CO % 32 == 0) return deep_gn_blocks<D128_32>(d, groups);
+    return 0;
 }
 
 template <class C, bool TWO>
