@@ -56,6 +56,15 @@ struct ConvCfg {
 };
 
 struct BfDims { int N, T, H, W, CK, CO, tiles_h, tiles_w; };
+// 1-D launch of nblk x nsub workgroups where the nsub workgroups of a block index share operand tiles (the channel blocks of one spatial
+// tile re-read the same X planes): blockIdx round-robins over the 8 XCDs, so the nsub mates get CONSECUTIVE slots of ONE XCD -- dispatched
+// together, behind one private L2 -- instead of being nblk slots apart (then the shared planes came from HBM once per channel block).
+__device__ __forceinline__ void block_and_sub(int nblk, int nsub, int& blk, int& sub)
+{
+    const int L = blockIdx.x;
+    if ((nblk & 7) == 0) { const int j = L >> 3; blk = (j / nsub) * 8 + (L & 7); sub = j % nsub; }
+    else { blk = L / nsub; sub = L % nsub; }
+}
 // bytes a (voxel, channel) tensor with row pitch ld spans from its first element (the extent of its buffer descriptor)
 inline __host__ __device__ long span_bytes(long vox, int ld, int ch) { return ((vox - 1) * ld + ch) * 2; }
 
@@ -1120,8 +1129,10 @@ __global__ __launch_bounds__(C::NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 
     const int c = wave % NCH, wi = (wave / NCH) % NCT, rg = wave / (NCH * NCT);      // K chunk, output-channel tile, row group of this wave
     const int r = lane & 15, g = lane >> 4;
 
-    int bid = blockIdx.x;
-    const int nblk = gridDim.x;
+    const int nsub = d.CO / C::CO_BLK;
+    const int nblk = gridDim.x / nsub;
+    int bid, yb;
+    block_and_sub(nblk, nsub, bid, yb);                                    // the channel blocks of a tile: neighbours on one XCD
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);       // XCD-aware: neighbours share halo columns and planes
     const int nch = (d.T + tchunk - 1) / tchunk;
     const int tc = bid % nch; int q = bid / nch;
@@ -1133,7 +1144,7 @@ __global__ __launch_bounds__(C::NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 
     if (t_end > d.T) t_end = d.T;
 
     const int co_tiles = d.CO / 16;
-    const int ct = blockIdx.y * NCT + wi;                                  // this wave's output-channel tile
+    const int ct = yb * NCT + wi;                                          // this wave's output-channel tile
     bf16x8 wreg[KSTEPS][KH];
 #pragma unroll
     for (int j = 0; j < KSTEPS; ++j)
@@ -1256,9 +1267,9 @@ __global__ __launch_bounds__(C::NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 
                 for (int w2 = 0; w2 < C::NW; ++w2)
                     if ((w2 / NCH) % NCT == t8) { a += red[(w2 * 8 + q8) * 2]; b += red[(w2 * 8 + q8) * 2 + 1]; }
             }
-            const long nblk = (long)d.tiles_h * d.tiles_w * nch;
+            const long nblk_s = (long)d.tiles_h * d.tiles_w * nch;
             const long blk = ((long)th * d.tiles_w + tw) * nch + tc;
-            float* pp = gn_part + ((n * nblk + blk) * gn_groups + blockIdx.y * gpb + tid) * 2;
+            float* pp = gn_part + ((n * nblk_s + blk) * gn_groups + yb * gpb + tid) * 2;
             pp[0] = a; pp[1] = b;
         }
     }
@@ -1299,7 +1310,7 @@ int launch_deep(const bf16_t* x, int ldx, const uint4* wp, const float* bias, bf
     if (span_bytes(vox, ldx, d.CK) >= lim || span_bytes(vox, ldy, d.CO) >= lim) return VVAE_ERR_BAD_ARG;
     if (gn_part && deep_gn_blocks<C>(d, gn_groups) <= 0) return VVAE_ERR_BAD_ARG;
     const int tchunk = deep_tchunk<C>(d);
-    dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk)), d.CO / C::CO_BLK);
+    dim3 grid((unsigned)((long)d.N * d.tiles_h * d.tiles_w * ceil_div(d.T, tchunk) * (d.CO / C::CO_BLK)));      // 1-D: block_and_sub
     const bool gn = gn_part != nullptr;
     auto k = gn ? conv3d_bf16_deep_kernel<C, true> : conv3d_bf16_deep_kernel<C, false>;
     static bool attr_done[2] = {false, false};
@@ -1353,8 +1364,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
     const int wi = wr / (COT * C::AG), wj = (wr / C::AG) % COT, a0 = (wr % C::AG) * AGS;
     const int r0 = rgp * C::THR;                                             // first output row of this wave
     const bool bias_wave = dt == 0 && wi == 0 && a0 == 0;
-    const int co_subs = d.CO / COB;
-    const int ci0 = (blockIdx.y / co_subs) * CIB, co0 = (blockIdx.y % co_subs) * COB;
+    const int co_subs = d.CO / COB, nsub = (d.CI / CIB) * co_subs;
+    const int nbx = gridDim.x / nsub;
+    int bx, by;
+    block_and_sub(nbx, nsub, bx, by);                                        // the (ci, co) sub-blocks of a column run: neighbours on one XCD
+    const int ci0 = (by / co_subs) * CIB, co0 = (by % co_subs) * COB;
     // transposed-read lane offsets: lane (g = l>>4, q = (l>>2)&3, p = l&3) addresses voxel row 4g+q, channels 4p..4p+3
     const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
     const int lvox = 4 * g + qq, loffy = (4 * g + qq) * PY + 8 * pp + wj * 32;
@@ -1386,7 +1400,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
 
     // A workgroup walks whole time-columns: for a fixed (n, h-tile, w-tile) it marches t = 0..T-1, so every X plane is
     // fetched from memory once (not KT times) and lives in the LDS ring for the three steps that use it.
-    const int col_beg = blockIdx.x * d.cols_per_block;
+    const int col_beg = bx * d.cols_per_block;
     int col_end = col_beg + d.cols_per_block;
     if (col_end > d.ncols) col_end = d.ncols;
     for (int colidx = col_beg; colidx < col_end; ++colidx) {
@@ -1468,7 +1482,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
 #undef FX
 #undef FY
     // ---- write this workgroup's partial sums: slab[block][dt][dy][dx][ci_local][co_local] (+ COB dbias partials) ----
-    float* out = slab + (((long)blockIdx.x * C::RG + rgp) * gridDim.y + blockIdx.y) * C::SLAB_FLOATS;
+    float* out = slab + (((long)bx * C::RG + rgp) * nsub + by) * C::SLAB_FLOATS;
     const int col = lane & 15, rg = lane >> 4;
 #pragma unroll
     for (int aa = 0; aa < AGS; ++aa) {
@@ -1575,7 +1589,7 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
         if (e != hipSuccess) return (int)e;
         attr_done[two] = true;
     }
-    hipLaunchKernelGGL(k, dim3(nblk, nsub), dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d, sp);
+    hipLaunchKernelGGL(k, dim3(nblk * nsub), dim3(C::NTHREADS), C::LDS_BYTES, s, x, ldx, dy, lddy, (float*)ws, d, sp);   // 1-D: block_and_sub
     VVAE_LAUNCH_CHECK();
     const int taps = C::KT * C::KH * C::KW;
     const long total = (long)taps * CI * CO + CO;
