@@ -1543,8 +1543,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //            CIB COB KH KW TH AG RG MINW workgroups/CU
 typedef WgCfg<16, 16, 3, 3, 8, 1, 2, 3, 2, 1> W333_16_16;    //  6 waves: two row groups of an 8-row tile, 2 workgroups per CU
 typedef WgCfg<32, 16, 3, 3, 8, 1, 2, 3, 1> W333_32_16;       // 12 waves: two row groups of an 8-row tile
-typedef WgCfg<32, 32, 3, 3, 4, 1, 1, 3, 1> W333_32_32;       // 12 waves
-typedef WgCfg<16, 16, 7, 7, 4, 4, 1, 3, 1, 2> W377_16_16;    // 12 waves: 3 temporal taps x 4 groups of kernel rows
+typedef WgCfg<32, 32, 3, 3, 8, 1, 1, 3, 1> W333_32_32;       // 12 waves, 8-row tiles: twice the products per barrier and staged plane (64->64 @64^2 70.8 -> 63.1 us,
+                                                             // 64->32 @128^2 127 -> 116) -- where they still fill the chip (wg32_tall)
+typedef WgCfg<32, 32, 3, 3, 4, 1, 1, 3, 1> W333_32_32_T4;    // 12 waves, 4-row tiles (32->64 @64^2: 8-row tiles leave 128 workgroups for 256 CUs, 41 -> 53 us)
+typedef WgCfg<16, 16, 7, 7, 8, 4, 1, 3, 1, 2> W377_16_16;    // 12 waves: 3 temporal taps x 4 groups of kernel rows
 
 int g_wg_cob16 = 0;                        // tuning: 1 = 16 output channels per workgroup even where Cin, Cout % 32 == 0
 int g_wg_blocks = 0;                       // tuning: > 0 overrides the persistent grid size
@@ -1599,6 +1601,13 @@ int launch_wgrad_cfg(const bf16_t* x, int ldx, const bf16_t* dy, int lddy, float
     return 0;
 }
 
+// 8-row tiles for the 32 x 32 configuration where the time columns of 8 x 32 tiles x (ci, co) sub-blocks still give every CU a workgroup
+inline bool wg32_tall(int N, int H, int W, int CI, int CO)
+{
+    const long cols = (long)N * ceil_div(H, W333_32_32::TH) * ceil_div(W, W333_32_32::TW);
+    return cols * (CI / 32) * (CO / 32) >= 256;
+}
+
 inline bool wgrad_shape_ok(int Cin, int Cout, int kt, int kh, int kw)
 {
     if (Cin % 16 || Cout % 16) return false;
@@ -1613,7 +1622,7 @@ extern "C" size_t vvae_conv3d_wgrad_bf16_ws_bytes(int N, int T, int H, int W, in
     if (!wgrad_shape_ok(Cin, Cout, kt, kh, kw)) return 0;
     if (kh == 7) return wg_ws_bytes<W377_16_16>(N, T, H, W, Cin, Cout);
     const bool i32 = Cin % 32 == 0, o32 = i32 && Cout % 32 == 0 && !g_wg_cob16;
-    if (i32 && o32) return wg_ws_bytes<W333_32_32>(N, T, H, W, Cin, Cout);
+    if (i32 && o32) return wg32_tall(N, H, W, Cin, Cout) ? wg_ws_bytes<W333_32_32>(N, T, H, W, Cin, Cout) : wg_ws_bytes<W333_32_32_T4>(N, T, H, W, Cin, Cout);
     if (i32) return wg_ws_bytes<W333_32_16>(N, T, H, W, Cin, Cout);
     return wg_ws_bytes<W333_16_16>(N, T, H, W, Cin, Cout);
 }
@@ -1630,7 +1639,8 @@ extern "C" int vvae_conv3d_wgrad_bf16(const void* x, int ldx, const void* dy, in
     const bf16_t* dyp = (const bf16_t*)dy;
     if (kh == 7) return launch_wgrad_cfg<W377_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     const bool i32 = Cin % 32 == 0, o32 = i32 && Cout % 32 == 0 && !g_wg_cob16;
-    if (i32 && o32) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+    if (i32 && o32 && wg32_tall(N, H, W, Cin, Cout)) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
+    if (i32 && o32) return launch_wgrad_cfg<W333_32_32_T4>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     if (i32) return launch_wgrad_cfg<W333_32_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
     return launch_wgrad_cfg<W333_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s);
 }
@@ -1649,7 +1659,8 @@ extern "C" int vvae_conv3d_wgrad_bf16_cat2(const void* x, int ldx, const void* x
     const bf16_t* dyp = (const bf16_t*)dy;
     const Split2 sp{(const bf16_t*)x2, ldx2, c_split, nullptr, 0, 0};
     const bool i32 = Cin % 32 == 0, o32 = i32 && Cout % 32 == 0 && !g_wg_cob16;
-    if (i32 && o32) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
+    if (i32 && o32 && wg32_tall(N, H, W, Cin, Cout)) return launch_wgrad_cfg<W333_32_32>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
+    if (i32 && o32) return launch_wgrad_cfg<W333_32_32_T4>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
     if (i32) return launch_wgrad_cfg<W333_32_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
     return launch_wgrad_cfg<W333_16_16>(xp, ldx, dyp, lddy, dw, dbias, N, T, H, W, Cin, Cout, ws, ws_bytes, s, sp);
 }
