@@ -154,3 +154,57 @@ def test_production_model_bf16_256_graph_replay_vs_oracle(dev, oracle_runs):
     # lr = 0 and the snapshot / restore around capture: the parameters are still the oracle's
     for k, prm in m.named_parameters():
         assert torch.equal(prm.detach().cpu(), p[k]), k
+
+
+def test_production_model_bf16_256_rl_flavour_vs_oracle(dev):
+    """The flavour the training driver runs by default (rl_model.VideoVAE + the pair / REINFORCE loss, reference train/rl_model.py:119-147,
+    train/rl_nonadversarial.py:100-186) at full production depth, bf16, 256 x 256, T = 16 with a masked tail: every logged loss term and the
+    same spread of parameter gradients against ``oracle.model.video_vae_rl`` + ``oracle.loss.loss_fn_rl`` (fp32 and bf16-emulated)."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, ops, optim, rl_model
+    kw, cfg, p, video, mask, _ = _case()
+    b, t = video.shape[:2]
+    g = torch.Generator().manual_seed(7)
+    keep = torch.rand((2 * b, t, 1, 1), generator=g) < 0.6
+    keep[0::2, 0] = True                       # the two members of a pair always differ in frame 0: their losses differ by a real amount,
+    keep[1::2, 0] = False                      # so (loss - mean) / (std + 1e-6) is well conditioned (one pair: +-1)
+    noise = {"reparam_eps": torch.randn((b, t, cfg.hw, cfg.latent_dim), generator=g),
+             "bernoulli_u": torch.where(keep, torch.full((), 0.01), torch.full((), 0.995))}      # far from any selection probability
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+
+    def oracle(dtype):
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        emask = OLoss.expand_mask(mask.bool(), cfg.hw)
+        v = video if dtype == torch.float32 else video.to(dtype).float()
+        loss, aux = OLoss.loss_fn_rl(OM.video_vae_rl(po, cfg, v, emask, noise, dtype=dtype), v, mask)
+        loss.backward()
+        return ({k: (aux[k].detach() if k != "reconstruction" else aux[k].detach()) for k in aux} | {"loss": loss.detach()},
+                {k: v.grad for k, v in po.items()})
+    ref, emu = oracle(torch.float32), oracle(torch.bfloat16)
+    m = _load(rl_model.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **kw), p, dev)
+    opt = optim.Optimizer(m, 0.0)
+    rngs = V.Rngs(3)
+    for k, v in noise.items():
+        rngs.inject(k, v)
+    vg, mg = video.to(dev, torch.bfloat16), mask.to(dev)
+    opt.zero_grad()
+    loss, aux = L.loss_fn(m, vg, L.expand_mask(mg, cfg.hw), mg, rngs, L.HPARAMS)
+    with ops.deferred_wgrad(opt):
+        loss.backward()
+    for bk in range(len(opt.buckets)):
+        if not opt.landed[bk]:
+            opt._land(bk)
+    torch.cuda.synchronize()
+    (o_ref, g_ref), (o_emu, g_emu) = ref, emu
+    report, failures = [], []
+    check_bf16("rl reconstruction", aux["reconstruction"], o_emu["reconstruction"], o_ref["reconstruction"], report)
+    got = dict(aux, loss=loss)
+    for k in ("loss", "MSE", "kl_loss", "per_sample_MAE", "selection_loss", "rl_loss", "mean_trajectory_prob"):
+        a, e, r = float(got[k]), float(o_emu[k]), float(o_ref[k])
+        if not abs(a - r) <= BF16_FACTOR * abs(e - r) + BF16_FLOOR * max(abs(r), 1e-3):
+            failures.append(f"rl {k}: gpu {a:.6g}, emulated oracle {e:.6g}, fp32 oracle {r:.6g}")
+    assert abs(float(got["kept_frame_density"]) - float(o_ref["kept_frame_density"])) < 1e-6
+    grads = {n: gv.clone() for n, gv in zip(opt.names, opt.gviews)}
+    assert set(grads) == set(g_ref)
+    failures += _check_grads("rl", grads, g_ref, g_emu, sorted(grads), report)
+    assert len(report) >= 60 and not failures, "\n".join(failures)
