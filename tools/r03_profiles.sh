@@ -33,7 +33,7 @@ echo "== eager line"; timeout -k 10 300 python bench.py --no-cpu-baseline --eage
 echo "== train.py on the same shape"; timeout -k 10 400 python -m video_vae_amd.train --per_device_batch_size 4 --max_frames 16 --flavour model --steps 90 --log_every 30 > $O/train_prod.log 2>&1 || echo FAILED
 echo "== input pipeline"; timeout -k 10 300 python bench.py --no-cpu-baseline --with-input-pipeline > $O/bench_input_pipeline_line.json 2> $O/bench_input_pipeline.err || echo FAILED
 echo "== C5 shape"; timeout -k 10 300 python bench.py --no-cpu-baseline --batch 2 --frames 32 > $O/bench_c5_b2_t32_line.json 2> $O/bench_c5.err || echo FAILED
-echo "== single-rank RCCL rehearsal, 1 + 9 graphs"; timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-ddp --no-cpu-baseline > $O/bench_force_ddp_line.json 2> $O/bench_force_ddp.err || echo FAILED
+echo "== single-rank RCCL rehearsal, 1 + 9 graphs"; timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-ddp --enc-segments 9 --no-cpu-baseline > $O/bench_force_ddp_line.json 2> $O/bench_force_ddp.err || echo FAILED
 echo "== single-rank RCCL rehearsal, 1 + 3 graphs"; timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --force-ddp --enc-segments 3 --no-cpu-baseline > $O/bench_force_ddp_seg3_line.json 2> $O/bench_force_ddp_seg3.err || echo FAILED
 echo "== single-rank RCCL rehearsal, bf16 gradient all-reduce"; timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 1 --force-ddp --grad-dtype bf16 --no-cpu-baseline > $O/bench_force_ddp_bf16_line.json 2> $O/bench_force_ddp_bf16.err || echo FAILED
 echo "== memset node probe"; timeout -k 10 300 python tools/memset_node_probe.py 40 2>&1 | grep -v amdgpu > $O/memset_node_probe.txt || echo FAILED
