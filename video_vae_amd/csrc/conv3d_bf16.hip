@@ -1,20 +1,28 @@
-// bf16 MFMA fast path for NDHWC Conv3d (SAME, stride 1): forward and data-grad.   gfx950 / CDNA4 only.
+// bf16 MFMA fast path for NDHWC Conv3d (SAME, stride 1): forward, data-grad and weight-grad.   gfx950 / CDNA4 only.
 //
 // Replaces the XLA lowering of nnx.Conv at /root/reference/train/unet.py:13-21 (3x3x3) and :111-113 (3x7x7).
 //
-// Shape of the problem: tiny channel counts (16..128) at huge spatial extent, so the GEMM N dimension is 1..8
-// MFMA tiles wide and a naive implicit GEMM is bound by LDS operand reads, not by the matrix cores.  Design:
-//   * one workgroup (4 waves) = one (n, t) x TH x 16 output tile for a block of output channels; the input halo
-//     tile (KT x (TH+KH-1) x (16+KW-1) voxels x CKB channels) is staged ONCE in LDS, zero-filled at the borders;
-//     the voxel pitch is padded to 32 / 96 bytes (= 2 / 6 sixteen-byte slots, both = 2 mod 4) which makes every
-//     ds_read_b128 operand read conflict-free for any tap shift;
-//   * K is ordered (dy | dt, dx, ci): for a fixed kernel row dy the operand fragment read for halo row r serves
-//     the KH output rows r-dy that the wave owns, so each LDS fragment read feeds up to KH*NT_W MFMAs instead of 1;
-//   * v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand and the voxels as B: the accumulator then holds
-//     4 consecutive output channels of one voxel per lane -> 8-byte bf16 stores, contiguous per voxel;
-//   * weights are pre-packed (pack kernel below, ~KB..MB, once per call) into fragment order so a wave's B^T
-//     fragment is one coalesced 1-KiB load that stays L1/L2 resident across workgroups;
-//   * dgrad is the same kernel on weights packed with flipped taps and swapped channel roles.
+// Shape of the problem: tiny channel counts (12..128) at huge spatial extent, so the GEMM N dimension is 1..8 MFMA tiles wide and a
+// naive implicit GEMM is bound by operand staging, not by the matrix cores.  Three forward / input-gradient kernels share one packed
+// weight layout and one K order:
+//   * conv3d_bf16_roll_kernel  -- layers whose K channels fit one chunk (16 / 32: every 256^2 / 128^2 layer, the patch mixer): a
+//     workgroup owns a spatial tile and MARCHES over time with the halo planes of frames t-1, t, t+1 in a ring of four LDS slots, one
+//     new plane fetched per step; weights resident in registers (or, for the mixer, in LDS);
+//   * conv3d_bf16_deep_kernel  -- K = 64 / 128 channels or >= 64 output channels: the same march, the waves of a workgroup splitting
+//     (K chunk, output-channel tile, row group), partial sums folded through LDS in chunk order (round 3);
+//   * conv3d_bf16_kernel       -- the per-frame form both grew out of (one (n, t) x TH x 16 tile per workgroup, halo staged once per
+//     tile, weights re-fetched through L1): kept as the fallback for shapes / extents the marches decline and as the reference the
+//     tests compare them with bit for bit (vvae_conv3d_roll_config / vvae_conv3d_deep_config).
+// Common to all:
+//   * K is ordered (dy | dt, dx, ci): for a fixed kernel row dy the operand fragment read for halo row r serves the KH output rows
+//     r-dy that the wave owns, so each LDS fragment read feeds up to KH*NT_W MFMAs instead of 1;
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand and the voxels as B: the accumulator then holds 4 consecutive output
+//     channels of one voxel per lane -> 8-byte bf16 stores, contiguous per voxel;
+//   * weights are pre-packed once per optimizer step (pack kernels below) into fragment order: a wave's fragment is one coalesced 1-KiB load;
+//   * dgrad is the same kernel on weights packed with flipped taps and swapped channel roles;
+//   * the marches address global memory through buffer descriptors (out-of-volume = out-of-range offset: zeros / dropped store), so
+//     their loops are branch-free and the compiler's s_waitcnt are counted ones (round 3).
+// The weight gradient (conv3d_wgrad_bf16_kernel) is described at its definition.
 #include "common.hpp"
 
 namespace {
