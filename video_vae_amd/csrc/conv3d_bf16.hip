@@ -1018,7 +1018,8 @@ int roll_tchunk(BfDims& d)
     d.tiles_h = ceil_div(d.H, C::TH);
     d.tiles_w = ceil_div(d.W, C::TW);
     const long cols = (long)d.N * d.tiles_h * d.tiles_w * (d.CO / C::CO_BLK);
-    const long want = C::LDS_BYTES > 80 * 1024 ? 512 : 2048;             // ~2 workgroups per CU slot
+    const long want = C::LDS_BYTES > 80 * 1024 ? 256 : 2048;             // one workgroup per CU (big rings): ONE full round of whole clips beats two
+                                                                           // rounds of half clips (32->32 @128^2: 62 -> 58.5 us); small rings: ~2.7 rounds over 3 slots per CU
     int tchunk = d.T;                                                      // whole clip per workgroup unless that starves the chip
     while (tchunk > 2 && cols * ceil_div(d.T, tchunk) < want) tchunk = (tchunk + 1) / 2;
     if (g_roll_tchunk > 0) tchunk = g_roll_tchunk;
