@@ -118,11 +118,30 @@ int vvae_transpose_grouped_bf16(const void* const* src, void* const* dst, const 
 
 /* The scalar end of the recon + KL loss, value and gradients in one launch (reference train/legacy/training_loop_adversarial.py:100-124:
  * selection density against 1 / max_compression_rate with magnified negatives, MSE + gamma1 selection + gamma2 KL).
- * mse_ps, kl_ps fp32 [B]; selection, mask fp32 (B, T) contiguous.  out fp32 [5] = loss, MSE, selection_loss, kl_loss, mean kept-frame
- * density.  grads fp32 [2 B + B T] = d loss / d mse_ps | d loss / d kl_ps | d loss / d selection.  B <= 1024. */
-int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, const float* selection, const float* mask, int B, int T,
+ * mse_ps fp32 [B]; kl_ps fp32 (B, kl_cols): the per-sample KL term as kl_cols >= 1 partial sums (summed here in index order: the per-frame
+ * partials of vvae_encoder_head_fwd, or kl_cols = 1); selection, mask fp32 (B, T) contiguous.  out fp32 [5] = loss, MSE, selection_loss,
+ * kl_loss, mean kept-frame density.  grads fp32 [2 B + B T] = d loss / d mse_ps | d loss / d (per-sample KL) | d loss / d selection.  B <= 1024. */
+int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, int kl_cols, const float* selection, const float* mask, int B, int T,
                          float max_compression_rate, float magnify_negatives_rate, float gamma1, float gamma2, float* out,
                          float* grads, void* stream);
+
+/* ---- The encoder's heads and the latent gate of the model.py flavour in train mode, one launch each way (reference train/model.py:53-59,
+ *      121-133; train/layers.py:226-252): log_var = log(softplus(v)), selection logits = Linear(hw -> 1)(Linear(ld -> 1)(mean)) + 1,
+ *      sel = round(sigmoid(logits + log(u / (1 - u)))) with the straight-through gradient, z = mean + eps exp(log_var / 2),
+ *      comp = fill (1 - sel) + z sel, and the per-frame share of the KL term.  One workgroup per frame; bf16 tensors, fp32 parameters.
+ *      mean, v bf16 (B, T, HW, LD) contiguous; w1 (LD), b1 (1), w2 (HW), b2 (1), fill (LD) fp32; u fp32 (B T); eps fp32 (B, T, HW, LD);
+ *      mask fp32 rows of T, mask_pitch elements apart per sample.  fwd -> logvar, comp bf16; sel, y (noisy logit) fp32 (B T); s1 fp32 (B T, HW);
+ *      kl_frame fp32 (B T).  bwd: dcomp bf16 / dsel fp32 (B T) / gkl fp32 at [b gkl_pitch_b + t gkl_pitch_t] / dlv_ext bf16, each may be NULL
+ *      -> dmean, dv bf16; one partial row per frame of part1 (B T, LD) = dW1, part2 (B T, HW) = dW2, part3 (B T, LD) = d fill and
+ *      partb (2, B T, 4) = [db1 0 0 0] rows, then [db2 0 0 0] rows.  HW % 4 == 0, LD % 8 == 0; mask_pitch 0 = one mask row for all samples. ---- */
+int vvae_encoder_head_ok(int B, int T, int HW, int LD);
+int vvae_encoder_head_fwd(const void* mean, const void* v, const float* w1, const float* b1, const float* w2, const float* b2,
+                          const float* u, const float* eps, const float* mask, long mask_pitch, const float* fill, void* logvar,
+                          void* comp, float* sel, float* y, float* s1, float* kl_frame, int B, int T, int HW, int LD, void* stream);
+int vvae_encoder_head_bwd(const void* mean, const void* v, const float* eps, const float* mask, long mask_pitch, const float* fill,
+                          const float* w1, const float* w2, const float* y, const float* s1, const float* sel, const void* dcomp,
+                          const float* dsel, const float* gkl, long gkl_pitch_b, long gkl_pitch_t, const void* dlv_ext, void* dmean, void* dv,
+                          float* part1, float* part2, float* part3, float* partb, int B, int T, int HW, int LD, void* stream);
 
 /* ---- y = silu(x) over a contiguous bf16 tensor of n elements (n % 8 == 0): the activation between the MLP's two Linear layers
  *      (train/layers.py:186-189). ---- */

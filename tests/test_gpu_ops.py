@@ -1377,6 +1377,101 @@ def test_plain_loss_tail_matches_the_framework_ops(dev, b, t):
         assert_close_scaled(a, w.grad, rel=1e-5, what=what)      # fp32 density - 1/rate against the fp64 reference: absolute, not relative
 
 
+def test_plain_loss_tail_sums_kl_partials(dev):
+    """kl_ps as (b, k) partial sums of the per-sample term (one per frame from ops.encoder_head): same loss and kl_loss as their row
+    sums, and every partial receives its sample's gradient."""
+    from video_vae_amd import ops
+    from video_vae_amd.loss import HPARAMS
+    b, t, k = 3, 6, 6
+    g = torch.Generator().manual_seed(9)
+    mask = (torch.rand(b, t, generator=g) < 0.8).float().to(dev)
+    sel = torch.rand(b, t, 1, 1, generator=g).to(dev)
+    mse = torch.rand(b, generator=g).to(dev)
+    klp = (torch.rand(b, k, generator=g) * 10).to(dev).requires_grad_(True)
+    kls = klp.detach().sum(1).requires_grad_(True)
+    assert ops.plain_loss_tail_ok(mse, klp, sel, mask)
+    l2, aux2 = ops.plain_loss_tail(mse, klp, sel, mask, HPARAMS)
+    l1, aux1 = ops.plain_loss_tail(mse, kls, sel, mask, HPARAMS)
+    l2.backward(); l1.backward()
+    assert_close(l2, l1.detach(), rtol=1e-6, atol=1e-7, what="loss")
+    assert_close(aux2[2], aux1[2].detach(), rtol=1e-6, atol=1e-7, what="kl_loss")
+    assert klp.grad.shape == (b, k)
+    assert torch.equal(klp.grad, kls.grad[:, None].expand(b, k))
+
+
+def _heads_reference(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):
+    """The unfused framework path of model.Encoder._trunk / GumbelSigmoidSTE / VideoVAE.forward on the same leaves (bf16 compute)."""
+    import torch.nn.functional as F
+    from video_vae_amd import ops
+    from video_vae_amd.layers import round_ste
+    bf = torch.bfloat16
+    lv = torch.log(F.softplus(v))
+    b, t, hw, ld = mean.shape
+    s1 = torch.addmm(b1.to(bf), mean.reshape(-1, ld), w1.to(bf)).view(b, t, hw)          # layers._LinearBf16.forward
+    logits = torch.addmm(b2.to(bf), s1.reshape(-1, hw), w2.to(bf)).view(b, t, 1) + 1
+    y = logits.float() + torch.logit(u, eps=1e-20)
+    sel = round_ste(torch.sigmoid(y))[..., None]                    # (b, t, 1, 1)
+    z, kl = ops.reparameterise_kl(mean, lv, eps, mask_bt)
+    comp = fill * (1 - sel) + z * sel
+    return lv, comp, sel, kl
+
+
+@pytest.mark.parametrize("b,t,hw,ld", [(2, 3, 16, 96), (1, 4, 256, 96), (2, 2, 40, 8), (1, 2, 100, 200)])
+def test_encoder_head_matches_the_framework_ops(dev, b, t, hw, ld):
+    """ops.encoder_head (the model.py flavour's heads + Gumbel STE + reparameterisation + KL + latent gate, one launch each way) against the
+    framework ops it replaces, on the same leaves: identical selection, outputs and every gradient within bf16 rounding.  Frames on both
+    sides of the gate, a masked frame, gradients arriving at comp, selection, the KL term and log_variance."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(100 + hw)
+    bf = torch.bfloat16
+    mean = (torch.randn(b, t, hw, ld, generator=g) * 0.5).to(dev, bf)
+    v = (torch.randn(b, t, hw, ld, generator=g) * 1.5).to(dev, bf)
+    w1 = (torch.randn(ld, 1, generator=g) * ld ** -0.5).to(dev)
+    b1 = (torch.randn(1, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(hw, 1, generator=g) * hw ** -0.5).to(dev)
+    b2 = (torch.randn(1, generator=g) * 0.1).to(dev)
+    fill = (torch.randn(1, 1, 1, ld, generator=g) * 0.02).to(dev)
+    # Gumbel noise well away from the decision boundary (logits are 1 + O(0.3)): u < 0.1 drops the frame, u > 0.9 keeps it, so that a
+    # last-bit difference in the bf16 logits cannot flip a frame between the two paths
+    r = torch.rand(b, t, 1, generator=g)
+    u = torch.where(torch.rand(b, t, 1, generator=g) < 0.5, 0.02 + 0.08 * r, 0.9 + 0.08 * r)
+    u.view(-1)[0], u.view(-1)[-1] = 0.02, 0.98
+    u = u.to(dev)
+    eps = torch.randn(b, t, hw, ld, generator=g).to(dev)
+    mask = torch.ones(b, t); mask[0, -1] = 0.0
+    mask_x = mask[:, None, :].expand(b, hw, t).reshape(b * hw, 1, 1, t).to(dev)          # as train_step expands it
+    from video_vae_amd.model import frame_mask
+    mbt = frame_mask(mask_x, b, t)
+    gcomp = torch.randn(b, t, hw, ld, generator=g).to(dev, bf)
+    gsel = torch.randn(b, t, 1, 1, generator=g).to(dev)
+    gkl = torch.randn(b, generator=g).to(dev)
+    glv = (torch.randn(b, t, hw, ld, generator=g) * 0.1).to(dev, bf)
+    assert ops.encoder_head_ok(mean, v, w1, b1, w2, b2, fill)
+
+    def run(fused):
+        leaves = [x.clone().requires_grad_(True) for x in (mean, v, w1, b1, w2, b2, fill)]
+        if fused:
+            lv, comp, sel, kl = ops.encoder_head(*leaves, u, eps, mbt)
+            kl = kl.sum(1)
+        else:
+            lv, comp, sel, kl = _heads_reference(*leaves, u, eps, mbt)
+        tot = (comp.float() * gcomp.float()).sum() + (sel * gsel).sum() + (kl * gkl).sum() + (lv.float() * glv.float()).sum()
+        tot.backward()
+        return (lv, comp, sel, kl), [x.grad for x in leaves]
+
+    (lv1, c1, s1, k1), g1 = run(True)
+    (lv0, c0, s0, k0), g0 = run(False)
+    assert c1.dtype == bf and lv1.dtype == bf and s1.shape == (b, t, 1, 1) and s1.dtype == torch.float32
+    assert torch.equal(s1, s0), (s1.flatten(), s0.flatten())
+    assert 0 < float(s1.sum()) < b * t                             # both sides of the gate are exercised
+    assert_close(lv1.float(), lv0.float(), rtol=8e-3, atol=1e-6, what="log_variance")      # the same roundings: at most a bf16 ulp apart
+    assert_close_scaled(c1.float(), c0.float(), rel=1e-2, what="comp")
+    assert_close(k1, k0.detach(), rtol=1e-4, atol=1e-6, what="kl")
+    for a, w, what in zip(g1, g0, ("d mean", "d v", "d w1", "d b1", "d w2", "d b2", "d fill")):
+        assert a is not None and a.shape == w.shape and a.dtype == w.dtype, what
+        assert_close_scaled(a.float(), w.float(), rel=2e-2, what=what)
+
+
 def test_fp32_fallback_paths_are_bitwise_reproducible(dev):
     """Round 3: the fp32 / odd-shape fallbacks (generic Conv3d and ConvTranspose weight + bias gradients, the any-head-dim temporal
     attention's q/k-norm scale gradients) accumulated with float atomics -- configs C1-C2 were reproducible to rounding only.  They now

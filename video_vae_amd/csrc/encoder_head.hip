@@ -1,0 +1,315 @@
+// The encoder's heads and the latent gate of the model.py flavour, train mode, as ONE launch forward and ONE backward.
+//
+//   log_var  = log(softplus(v))                                   /root/reference/train/model.py:54-55   (v = variance_estimator(x))
+//   s1       = selection_layer1(mean)   (ld -> 1, per token)      model.py:56-57
+//   logits   = selection_layer2(s1) + 1 (hw -> 1, per frame)      model.py:58
+//   sel      = round(sigmoid(logits + log(u / (1 - u))))          /root/reference/train/layers.py:238-252 (temperature 1, round_ste :226-236)
+//   z        = mean + eps * exp(log_var / 2)                      model.py:124-128
+//   KL       = mean_{t,hw,c}[0.5 (e^lv - 1 - lv + mu^2) m_t / len]  /root/reference/train/rl_nonadversarial.py:146-147 (per frame here)
+//   comp     = fill * (1 - sel) + z * sel                         model.py:133
+//
+// As framework ops this is ~17 launches forward and ~28 backward over 6 MB tensors and (b, t) scalars; every launch of a replayed
+// hipGraph costs ~5 us however little it does.  One workgroup per frame: the selection of a frame needs all of its tokens (phase A),
+// the gate of every token needs the selection (phase B); the frame (48 KB per operand at hw = 256, ld = 96) is re-read from L2.
+// The rounding points of the unfused path are kept (bf16 Linear outputs, bf16 softplus / log results) so that the discrete selection
+// and the values downstream agree with it; gradients are accumulated in fp32 and rounded once.
+// Parameter gradients leave as one partial row per frame (folded by the caller's grouped fold): no atomics, fixed order.
+#include "common.hpp"
+
+namespace {
+
+constexpr int EH_MAX_THREADS = 1024;
+constexpr int EH_MAX_HW = 4096;              // w2 / s1 rows in LDS
+constexpr int EH_MAX_LD = 1024;
+
+struct EhDims { int T, HW, LD, CG, TY; long mask_pitch; };
+
+__device__ __forceinline__ float bfr(float v) { return bf2f(f2bf(v)); }
+
+// softplus as the framework computes it (beta 1, threshold 20), in the compute dtype: result rounded to bf16
+__device__ __forceinline__ float softplus_bf(float v) { return bfr(v > 20.f ? v : log1pf(expf(v))); }
+
+// sum over the workgroup in fixed order (lanes by butterfly, waves by index) -> every thread gets the total
+__device__ __forceinline__ float block_total(float v, float* red, float* out_slot)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) t += red[i];
+        *out_slot = t;
+    }
+    __syncthreads();
+    return *out_slot;
+}
+
+__device__ __forceinline__ float seq_len(const float* __restrict__ mrow, int T)
+{
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += mrow[t];
+    return fmaxf(s, 1.0f);
+}
+
+// LDS: w2b[HW] | s1s[HW] | pt[HW * CG] | red[16] | slot[4]
+__global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
+    const bf16_t* __restrict__ mean, const bf16_t* __restrict__ v, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u, const float* __restrict__ eps,
+    const float* __restrict__ mask, const float* __restrict__ fill, bf16_t* __restrict__ logvar, bf16_t* __restrict__ comp,
+    float* __restrict__ sel_out, float* __restrict__ y_out, float* __restrict__ s1_out, float* __restrict__ kl_frame, EhDims d)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w2b = lds;
+    float* s1s = w2b + d.HW;
+    float* pt = s1s + d.HW;
+    float* red = pt + (long)d.HW * d.CG;
+    float* slot = red + 16;
+    const int f = blockIdx.x, b = f / d.T, t = f % d.T;
+    const int tid = threadIdx.x, cg = tid % d.CG, ty = tid / d.CG;
+    const bool active = ty < d.TY;
+    const long base = (long)f * d.HW * d.LD + cg * 8;
+
+    for (int j = tid; j < d.HW; j += blockDim.x) w2b[j] = bfr(w2[j]);
+    float w1r[8], fr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { w1r[e] = bfr(w1[cg * 8 + e]); fr[e] = bfr(fill[cg * 8 + e]); }
+
+    // ---- phase A: per-token dot with w1 (partial per channel group, summed per token in channel order) ----
+    if (active)
+        for (int j = ty; j < d.HW; j += d.TY) {
+            float m[8];
+            VecIO<bf16_t, 8>::load(mean + base + (long)j * d.LD, m);
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += m[e] * w1r[e];
+            pt[j * d.CG + cg] = a;
+        }
+    __syncthreads();
+    const float b1b = bfr(b1[0]);
+    float acc = 0.f;
+    for (int j = tid; j < d.HW; j += blockDim.x) {
+        float a = 0.f;
+        for (int c = 0; c < d.CG; ++c) a += pt[j * d.CG + c];
+        const float s = bfr(a + b1b);
+        s1s[j] = s;
+        s1_out[(long)f * d.HW + j] = s;
+        acc += s * w2b[j];
+    }
+    const float dot2 = block_total(acc, red, slot);
+    const float logits = bfr(bfr(dot2 + bfr(b2[0])) + 1.f);
+    float uc = u[f];
+    uc = uc < 1e-20f ? 1e-20f : (uc > 1.f - 1e-20f ? 1.f - 1e-20f : uc);
+    const float y = logits + logf(uc / (1.f - uc));
+    const float sel = rintf(1.f / (1.f + expf(-y)));
+    if (tid == 0) { sel_out[f] = sel; y_out[f] = y; }
+
+    // ---- phase B: log-variance, reparameterisation, gate, KL ----
+    float kl = 0.f;
+    if (active)
+        for (int j = ty; j < d.HW; j += d.TY) {
+            const long g = base + (long)j * d.LD;
+            float m[8], vv[8], lv[8], o[8];
+            VecIO<bf16_t, 8>::load(mean + g, m);
+            VecIO<bf16_t, 8>::load(v + g, vv);
+            const float4 e0 = *reinterpret_cast<const float4*>(eps + g), e1 = *reinterpret_cast<const float4*>(eps + g + 4);
+            const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                lv[e] = bfr(logf(softplus_bf(vv[e])));
+                const float z = m[e] + ee[e] * __expf(0.5f * lv[e]);
+                o[e] = sel != 0.f ? z : fr[e];
+                kl += 0.5f * (__expf(lv[e]) - 1.f - lv[e] + m[e] * m[e]);
+            }
+            VecIO<bf16_t, 8>::store(logvar + g, lv);
+            VecIO<bf16_t, 8>::store(comp + g, o);
+        }
+    const float klt = block_total(kl, red, slot);
+    if (tid == 0) {
+        const float* mrow = mask + (long)b * d.mask_pitch;
+        kl_frame[f] = klt * mrow[t] / (seq_len(mrow, d.T) * (float)d.T * (float)d.HW * (float)d.LD);
+    }
+}
+
+// LDS: w2b[HW] | colred[TY * LD] | red[16] | slot[4]
+// part1 (F, LD) = dW1, part2 (F, HW) = dW2, part3 (F, LD) = d fill, partb (2, F, 4) = [db1 0 0 0] then [db2 0 0 0]: this frame's row of each
+// (row widths are multiples of four floats: what the caller's fold kernels take).
+__global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
+    const bf16_t* __restrict__ mean, const bf16_t* __restrict__ v, const float* __restrict__ eps, const float* __restrict__ mask,
+    const float* __restrict__ fill, const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ y_in,
+    const float* __restrict__ s1_in, const float* __restrict__ sel_in, const bf16_t* __restrict__ dcomp, const float* __restrict__ dsel,
+    const float* __restrict__ gkl, long gkl_pitch_b, long gkl_pitch_t, const bf16_t* __restrict__ dlv_ext, bf16_t* __restrict__ dmean, bf16_t* __restrict__ dv,
+    float* __restrict__ part1, float* __restrict__ part2, float* __restrict__ part3, float* __restrict__ partb, EhDims d)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w2b = lds;
+    float* colred = w2b + d.HW;
+    float* red = colred + (long)d.TY * d.LD;
+    float* slot = red + 16;
+    const int f = blockIdx.x, b = f / d.T, t = f % d.T;
+    const int tid = threadIdx.x, cg = tid % d.CG, ty = tid / d.CG;
+    const bool active = ty < d.TY;
+    const long base = (long)f * d.HW * d.LD + cg * 8;
+    const float sel = sel_in[f];
+    const bool keep = sel != 0.f;
+
+    for (int j = tid; j < d.HW; j += blockDim.x) w2b[j] = bfr(w2[j]);
+    float w1r[8], fr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { w1r[e] = bfr(w1[cg * 8 + e]); fr[e] = bfr(fill[cg * 8 + e]); }
+
+    // ---- phase 1: d sel through the gate = sum dcomp * (z - fill); d fill = sum_tokens dcomp * (1 - sel) ----
+    float ds = 0.f, dfa[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dfa[e] = 0.f;
+    if (active && dcomp)
+        for (int j = ty; j < d.HW; j += d.TY) {
+            const long g = base + (long)j * d.LD;
+            float m[8], vv[8], dc[8];
+            VecIO<bf16_t, 8>::load(mean + g, m);
+            VecIO<bf16_t, 8>::load(v + g, vv);
+            VecIO<bf16_t, 8>::load(dcomp + g, dc);
+            const float4 e0 = *reinterpret_cast<const float4*>(eps + g), e1 = *reinterpret_cast<const float4*>(eps + g + 4);
+            const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float lv = bfr(logf(softplus_bf(vv[e])));
+                const float z = m[e] + ee[e] * __expf(0.5f * lv);
+                ds += dc[e] * (z - fr[e]);
+                if (!keep) dfa[e] += dc[e];
+            }
+        }
+    const float dsg = block_total(ds, red, slot);
+    // round_ste: identity; sigmoid'; the .float() of the logits casts the gradient back to the compute dtype
+    const float yy = y_in[f];
+    const float sg = 1.f / (1.f + expf(-yy));
+    const float dl = bfr((dsg + (dsel ? dsel[f] : 0.f)) * sg * (1.f - sg));
+
+    // ---- phase 2: token / element gradients ----
+    const float* mrow = mask + (long)b * d.mask_pitch;
+    float kscale = 0.f;
+    if (gkl) kscale = gkl[(long)b * gkl_pitch_b + (long)t * gkl_pitch_t] * mrow[t] / (seq_len(mrow, d.T) * (float)d.T * (float)d.HW * (float)d.LD);
+    float dw1[8], db1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dw1[e] = 0.f;
+    if (active)
+        for (int j = ty; j < d.HW; j += d.TY) {
+            const long g = base + (long)j * d.LD;
+            const float dsi = bfr(dl * w2b[j]);
+            float m[8], vv[8], dc[8], dm[8], dvv[8], dx[8];
+            VecIO<bf16_t, 8>::load(mean + g, m);
+            VecIO<bf16_t, 8>::load(v + g, vv);
+            if (dcomp && keep) VecIO<bf16_t, 8>::load(dcomp + g, dc);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dc[e] = 0.f;
+            }
+            if (dlv_ext) VecIO<bf16_t, 8>::load(dlv_ext + g, dx);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dx[e] = 0.f;
+            }
+            const float4 e0 = *reinterpret_cast<const float4*>(eps + g), e1 = *reinterpret_cast<const float4*>(eps + g + 4);
+            const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float var = softplus_bf(vv[e]);
+                const float lv = bfr(logf(var));
+                const float elv = __expf(lv);
+                dm[e] = dc[e] + kscale * m[e] + dsi * w1r[e];
+                const float dlv = dc[e] * ee[e] * 0.5f * __expf(0.5f * lv) + kscale * 0.5f * (elv - 1.f) + dx[e];
+                const float dsp = vv[e] > 20.f ? 1.f : 1.f / (1.f + expf(-vv[e]));          // softplus'
+                dvv[e] = dlv / var * dsp;
+                dw1[e] += m[e] * dsi;
+            }
+            VecIO<bf16_t, 8>::store(dmean + g, dm);
+            VecIO<bf16_t, 8>::store(dv + g, dvv);
+            if (cg == 0) {
+                db1 += dsi;
+                part2[(long)f * d.HW + j] = s1_in[(long)f * d.HW + j] * dl;
+            }
+        }
+    const float db1t = block_total(db1, red, slot);
+    if (tid < 8) {
+        const long F = gridDim.x;
+        partb[(tid < 4 ? 0 : F * 4) + (long)f * 4 + (tid & 3)] = (tid & 3) ? 0.f : (tid < 4 ? db1t : dl);
+    }
+    // per-channel sums over the token lanes, fixed order: dW1 then d fill through the same LDS image
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) colred[ty * d.LD + cg * 8 + e] = pass ? dfa[e] : dw1[e];
+        }
+        __syncthreads();
+        for (int c = tid; c < d.LD; c += blockDim.x) {
+            float a = 0.f;
+            for (int r = 0; r < d.TY; ++r) a += colred[r * d.LD + c];
+            if (pass) part3[(long)f * d.LD + c] = a;
+            else part1[(long)f * d.LD + c] = a;
+        }
+        __syncthreads();
+    }
+}
+
+bool eh_dims(int B, int T, int HW, int LD, long mask_pitch, EhDims& d, int& threads)
+{
+    if (B <= 0 || T <= 0 || HW <= 0 || HW > EH_MAX_HW || HW % 4 || LD <= 0 || LD > EH_MAX_LD || LD % 8 || (mask_pitch != 0 && mask_pitch < T)) return false;
+    d.T = T; d.HW = HW; d.LD = LD; d.CG = LD / 8; d.mask_pitch = mask_pitch;
+    d.TY = EH_MAX_THREADS / d.CG;
+    if (d.TY > HW) d.TY = HW;
+    threads = ((d.CG * d.TY + 63) / 64) * 64;
+    return true;
+}
+
+}  // namespace
+
+// 1 when the fused heads cover the shape (bf16 operands are the caller's business), else 0.
+extern "C" int vvae_encoder_head_ok(int B, int T, int HW, int LD)
+{
+    EhDims d; int th;
+    if (!eh_dims(B, T, HW, LD, T, d, th)) return 0;
+    const size_t fwd = ((size_t)2 * HW + (size_t)HW * d.CG + 20) * 4, bwd = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
+    return fwd <= 64 * 1024 && bwd <= 64 * 1024;
+}
+
+// mean, v (pre-softplus) bf16 (B, T, HW, LD) contiguous; w1 (LD), b1 (1), w2 (HW), b2 (1), fill (LD) fp32 masters; u fp32 (B*T) uniform;
+// eps fp32 (B, T, HW, LD) normal; mask fp32 rows of T with pitch mask_pitch (elements) per sample (0: one row for all samples).  HW % 4 == 0, LD % 8 == 0.
+// -> logvar, comp bf16 (B, T, HW, LD); sel, y fp32 (B*T) (y = the noisy logit, kept for the backward); s1 fp32 (B*T, HW);
+//    kl_frame fp32 (B*T): summed over a sample's frames it is the per-sample KL term.
+extern "C" int vvae_encoder_head_fwd(const void* mean, const void* v, const float* w1, const float* b1, const float* w2, const float* b2,
+                                     const float* u, const float* eps, const float* mask, long mask_pitch, const float* fill, void* logvar,
+                                     void* comp, float* sel, float* y, float* s1, float* kl_frame, int B, int T, int HW, int LD, void* stream)
+{
+    EhDims d; int threads;
+    if (!mean || !v || !w1 || !b1 || !w2 || !b2 || !u || !eps || !mask || !fill || !logvar || !comp || !sel || !y || !s1 || !kl_frame ||
+        !eh_dims(B, T, HW, LD, mask_pitch, d, threads) || !vvae_encoder_head_ok(B, T, HW, LD) ||
+        ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)eps | (uintptr_t)logvar | (uintptr_t)comp) % 16) return VVAE_ERR_BAD_ARG;
+    const size_t lds = ((size_t)2 * HW + (size_t)HW * d.CG + 20) * 4;
+    hipLaunchKernelGGL(encoder_head_fwd_kernel, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
+                       w1, b1, w2, b2, u, eps, mask, fill, (bf16_t*)logvar, (bf16_t*)comp, sel, y, s1, kl_frame, d);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dcomp bf16 (B, T, HW, LD) or NULL; dsel fp32 (B*T) or NULL; gkl fp32 or NULL: the gradient of kl_frame[b][t] at gkl[b * gkl_pitch_b + t * gkl_pitch_t]
+// (pitches (1, 0): one gradient per sample, as the loss tail hands it over); dlv_ext bf16 (B, T, HW, LD) or NULL (a gradient arriving at logvar from elsewhere).
+// -> dmean, dv bf16 (B, T, HW, LD); part1 (B*T, LD) = dW1, part2 (B*T, HW) = dW2, part3 (B*T, LD) = d fill, partb (2, B*T, 4) = [db1 0 0 0] rows then
+// [db2 0 0 0] rows: one partial row per frame each, to be summed over rows by the caller.
+extern "C" int vvae_encoder_head_bwd(const void* mean, const void* v, const float* eps, const float* mask, long mask_pitch, const float* fill,
+                                     const float* w1, const float* w2, const float* y, const float* s1, const float* sel, const void* dcomp,
+                                     const float* dsel, const float* gkl, long gkl_pitch_b, long gkl_pitch_t, const void* dlv_ext, void* dmean, void* dv,
+                                     float* part1, float* part2, float* part3, float* partb, int B, int T, int HW, int LD, void* stream)
+{
+    EhDims d; int threads;
+    if (!mean || !v || !eps || !mask || !fill || !w1 || !w2 || !y || !s1 || !sel || !dmean || !dv || !part1 || !part2 || !part3 || !partb ||
+        !eh_dims(B, T, HW, LD, mask_pitch, d, threads) || !vvae_encoder_head_ok(B, T, HW, LD) ||
+        ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)eps | (uintptr_t)dcomp | (uintptr_t)dlv_ext | (uintptr_t)dmean | (uintptr_t)dv) % 16)
+        return VVAE_ERR_BAD_ARG;
+    const size_t lds = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
+    hipLaunchKernelGGL(encoder_head_bwd_kernel, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v, eps,
+                       mask, fill, w1, w2, y, s1, sel, (const bf16_t*)dcomp, dsel, gkl, gkl_pitch_b, gkl_pitch_t, (const bf16_t*)dlv_ext, (bf16_t*)dmean,
+                       (bf16_t*)dv, part1, part2, part3, partb, d);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

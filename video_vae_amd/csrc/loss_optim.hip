@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void sum_chunks2_kernel(const float* __restrict
 // out[5] = loss, MSE, selection_loss, kl_loss, mean density.   grads = [d loss / d mse_b (B) | d / d kl_b (B) | d / d sel_bt (B T)].
 // One workgroup; sample b is thread b's (strided), the means are summed by thread 0 in index order: deterministic.
 constexpr int TAIL_MAX_B = 1024;
-__global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __restrict__ mse, const float* __restrict__ kl,
+__global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __restrict__ mse, const float* __restrict__ kl, int kl_cols,
                                                              const float* __restrict__ sel, const float* __restrict__ mask, int B, int T,
                                                              float inv_max_rate, float magnify, float gamma1, float gamma2,
                                                              float* __restrict__ out, float* __restrict__ grads)
@@ -214,7 +214,11 @@ __global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = 0.f, k = 0.f, q = 0.f, dn = 0.f;
-        for (int b = 0; b < B; ++b) { a += mse[b]; k += kl[b]; q += sq[b]; dn += dens[b]; }
+        for (int b = 0; b < B; ++b) {
+            float kb = 0.f;                                          // the sample's KL term: its partial sums in index order
+            for (int c = 0; c < kl_cols; ++c) kb += kl[b * kl_cols + c];
+            a += mse[b]; k += kb; q += sq[b]; dn += dens[b];
+        }
         a *= invB; k *= invB; q *= invB; dn *= invB;
         out[0] = a + gamma1 * q + gamma2 * k;
         out[1] = a; out[2] = q; out[3] = k; out[4] = dn;
@@ -362,14 +366,15 @@ extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, con
     return 0;
 }
 
-// mse_ps, kl_ps fp32 [B]; selection, mask fp32 (B, T) contiguous.  out fp32 [5], grads fp32 [2 B + B T] (see loss_tail_plain_kernel).
-extern "C" int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, const float* selection, const float* mask, int B, int T,
+// mse_ps fp32 [B], kl_ps fp32 (B, kl_cols) partial sums of the per-sample KL; selection, mask fp32 (B, T) contiguous.  out fp32 [5],
+// grads fp32 [2 B + B T] (see loss_tail_plain_kernel).
+extern "C" int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, int kl_cols, const float* selection, const float* mask, int B, int T,
                                     float max_compression_rate, float magnify_negatives_rate, float gamma1, float gamma2, float* out,
                                     float* grads, void* stream)
 {
-    if (!mse_ps || !kl_ps || !selection || !mask || !out || !grads || B <= 0 || B > TAIL_MAX_B || T <= 0 || !(max_compression_rate > 0.f))
+    if (!mse_ps || !kl_ps || kl_cols <= 0 || !selection || !mask || !out || !grads || B <= 0 || B > TAIL_MAX_B || T <= 0 || !(max_compression_rate > 0.f))
         return VVAE_ERR_BAD_ARG;
-    hipLaunchKernelGGL(loss_tail_plain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_ps, kl_ps, selection, mask, B, T,
+    hipLaunchKernelGGL(loss_tail_plain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_ps, kl_ps, kl_cols, selection, mask, B, T,
                        1.f / max_compression_rate, magnify_negatives_rate, gamma1, gamma2, out, grads);
     VVAE_LAUNCH_CHECK();
     return 0;

@@ -35,7 +35,8 @@ def expand_mask(mask, hw):
 def kl_from_model(model, mean, logvar, mask_bt):
     """Per-sample KL term (rl_nonadversarial.py:146-147).  A train-mode forward already produced it in the same pass that
     reparameterised (ops.reparameterise_kl) and left it on the model, keyed by the very tensors it returned; anything else
-    (eval mode, a foreign model) takes the stand-alone kernel."""
+    (eval mode, a foreign model) takes the stand-alone kernel.  The fused encoder heads (model.Encoder.forward_gated) leave it as
+    (b, t) partial sums, one per frame, which the loss tail adds up."""
     cached = getattr(model, "_kl", None)
     if cached is not None and cached[0] is mean and cached[1] is logvar and cached[2].shape[0] == mask_bt.shape[0]:
         return cached[2]
@@ -101,6 +102,8 @@ def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
         loss, (MSE, selection_loss, kl_loss, density) = ops.plain_loss_tail(mse_ps, kl_ps, selection, om, hparams)
         return loss, {"MSE": MSE, "selection_loss": selection_loss, "kl_loss": kl_loss, "reconstruction": reconstruction,
                       "kept_frame_density": density}
+    if kl_ps.dim() == 2:                                 # per-frame partial sums (ops.encoder_head)
+        kl_ps = kl_ps.sum(1)
     MSE = mse_ps.mean()
     sequence_lengths = torch.clamp(reduce(om, "b time -> b 1", "sum"), min=1.0)
     kl_and_selection_mask = rearrange(om, "b time -> b time 1 1")

@@ -38,7 +38,7 @@ class Encoder(nn.Module):
             FactoredAttention(mlp_dim, self.last_dim, num_heads, qkv_features, max_temporal_len, max_spatial_len, rngs,
                               dtype, param_dtype) for _ in range(depth)])
 
-    def _trunk(self, x, mask):
+    def _features(self, x, mask):
         x = self.patch_embedding(x)
         # each layer hands its last residual add to the next layer's first LayerNorm kernel (layers.FactoredAttention)
         pend, n = None, len(self.layers)
@@ -48,6 +48,10 @@ class Encoder(nn.Module):
                 pend = r
             else:
                 x = r
+        return x
+
+    def _trunk(self, x, mask):
+        x = self._features(x, mask)
         mean = self.spatial_compression(x)
         variance = F.softplus(self.variance_estimator(x))
         log_variance = torch.log(variance)
@@ -58,6 +62,30 @@ class Encoder(nn.Module):
         mean, log_variance, logits = self._trunk(x, mask)
         selection = self.gumbel_sigmoid(logits.float(), rngs, train=train)
         return mean, log_variance, rearrange(selection, "b t 1 -> b t 1 1")
+
+    def gated_ok(self, x, fill_token):
+        """May forward_gated run?  (bf16 GPU model, temperature 1, fp32 parameters, shapes the fused kernel covers.)"""
+        sl1, sl2 = self.selection_layer1, self.selection_layer2
+        b, t = x.shape[0], x.shape[1]
+        hw, ld = sl2.kernel.shape[0], sl1.kernel.shape[0]
+        return (self.dtype == torch.bfloat16 and x.is_cuda and self.gumbel_sigmoid.temperature == 1.0 and fill_token.numel() == ld
+                and all(p.dtype == torch.float32 for p in (sl1.kernel, sl1.bias, sl2.kernel, sl2.bias, fill_token))
+                and bool(ops.lib().vvae_encoder_head_ok(b, t, hw, ld)))
+
+    def forward_gated(self, x, mask, rngs, fill_token):
+        """Train mode on the GPU -> (mean, log_variance, selection, compressed_representation, kl (b, t)): everything behind the two
+        768 -> ld products -- softplus / log, both selection layers, the Gumbel-sigmoid STE, the reparameterisation, the KL term and the
+        latent gate fill * (1 - s) + z * s of VideoVAE.__call__ (model.py:121-133) -- in one launch each way (ops.encoder_head) instead of
+        ~45 framework launches per step.  The noise draws keep the reference's order: Gumbel, then reparameterisation."""
+        sl1, sl2 = self.selection_layer1, self.selection_layer2
+        h = self._features(x, mask)
+        mean, v = self.spatial_compression(h), self.variance_estimator(h)
+        b, t = mean.shape[0], mean.shape[1]
+        u = rngs.draw("gumbel_u", "uniform", (b, t, 1), mean.device)
+        eps = rngs.draw("reparam_eps", "normal", mean.shape, mean.device)
+        log_variance, comp, selection, kl = ops.encoder_head(mean, v, sl1.kernel, sl1.bias, sl2.kernel, sl2.bias, fill_token, u, eps,
+                                                             frame_mask(mask, b, t))
+        return mean, log_variance, selection, comp, kl
 
 
 class Decoder(nn.Module):
@@ -109,8 +137,15 @@ class VideoVAE(nn.Module):
         self.fill_token = nn.Parameter(torch.randn((1, 1, 1, ld), generator=key.generator("cpu")) * 0.02)
 
     def forward(self, x, mask, rngs, train=True):
-        mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
         self._kl = None
+        if train and type(self.encoder) is Encoder and self.encoder.gated_ok(x, self.fill_token):
+            # GPU train step: heads, noise, KL and gate come out of one kernel; compressed_representation holds the decoder's compute dtype
+            # (the reference's fp32 sum rounded once, which is what its decoder's first Linear does to it: the same numbers downstream)
+            mean, log_variance, selection, compressed_representation, kl = self.encoder.forward_gated(x, mask, rngs, self.fill_token)
+            self._kl = (mean, log_variance, kl)
+            reconstruction = self.decoder(compressed_representation, mask, rngs, train=train)
+            return reconstruction, compressed_representation, selection, log_variance, mean
+        mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
         if train:
             noise = rngs.draw("reparam_eps", "normal", log_variance.shape, log_variance.device)
             # z and the per-sample KL term in ONE pass over (mean, log_variance): the loss picks the KL up from here

@@ -1156,11 +1156,12 @@ class _PlainLossTail(torch.autograd.Function):
         out = torch.empty((5,), dtype=torch.float32, device=mse_ps.device)
         grads = torch.empty((2 * b + b * t,), dtype=torch.float32, device=mse_ps.device)
         sel = selection.reshape(b, t).to(torch.float32).contiguous()
-        check(lib().vvae_loss_tail_plain(_p(mse_ps.contiguous()), _p(kl_ps.contiguous()), _p(sel), _p(mask), b, t, float(max_rate),
+        kl_cols = kl_ps.numel() // b                     # (b,) or (b, k) partial sums of the per-sample term (ops.encoder_head: one per frame)
+        check(lib().vvae_loss_tail_plain(_p(mse_ps.contiguous()), _p(kl_ps.contiguous()), kl_cols, _p(sel), _p(mask), b, t, float(max_rate),
                                          float(magnify), float(gamma1), float(gamma2), _p(out), _p(grads), _stream()),
               "vvae_loss_tail_plain")
         ctx.save_for_backward(grads)
-        ctx.bt, ctx.sel_shape, ctx.sel_dtype = (b, t), selection.shape, selection.dtype
+        ctx.bt, ctx.sel_shape, ctx.sel_dtype, ctx.kl_shape = (b, t), selection.shape, selection.dtype, kl_ps.shape
         aux = out[1:]
         ctx.mark_non_differentiable(aux)
         ctx.set_materialize_grads(False)
@@ -1173,12 +1174,16 @@ class _PlainLossTail(torch.autograd.Function):
         (grads,) = ctx.saved_tensors
         b, t = ctx.bt
         g = grads * go                                   # one launch for the three gradients
-        return g[:b], g[b:2 * b], g[2 * b:].view(ctx.sel_shape).to(ctx.sel_dtype), None, None, None, None, None
+        gkl = g[b:2 * b]
+        if len(ctx.kl_shape) == 2:                       # every partial sum of a sample has the sample's gradient: a stride-0 view, no launch
+            gkl = gkl.unsqueeze(1).expand(ctx.kl_shape)
+        return g[:b], gkl, g[2 * b:].view(ctx.sel_shape).to(ctx.sel_dtype), None, None, None, None, None
 
 
 def plain_loss_tail_ok(mse_ps, kl_ps, selection, mask):
     return (mse_ps.is_cuda and mse_ps.dtype == torch.float32 and kl_ps.dtype == torch.float32 and mask.dtype == torch.float32
-            and mask.dim() == 2 and mask.is_contiguous() and mask.shape[0] <= 1024 and selection.numel() == mask.numel())
+            and mask.dim() == 2 and mask.is_contiguous() and mask.shape[0] <= 1024 and selection.numel() == mask.numel()
+            and kl_ps.dim() in (1, 2) and kl_ps.shape[0] == mask.shape[0])
 
 
 def plain_loss_tail(mse_ps, kl_ps, selection, mask, hparams):
@@ -1186,6 +1191,86 @@ def plain_loss_tail(mse_ps, kl_ps, selection, mask, hparams):
     loss, aux = _PlainLossTail.apply(mse_ps, kl_ps, selection, mask, hparams["max_compression_rate"], hparams["magnify_negatives_rate"],
                                      hparams["gamma1"], hparams["gamma2"])
     return loss, aux.unbind(0)
+
+
+# --------------------------------------------------------------------------------------------- encoder heads + latent gate
+class _EncoderHead(torch.autograd.Function):
+    """log-variance, selection logits, Gumbel-sigmoid STE, reparameterisation, per-frame KL and the latent gate of the model.py flavour in
+    ONE launch each way (vvae_encoder_head_fwd / _bwd; reference train/model.py:53-59,121-133, train/layers.py:226-252).  The parameter
+    gradients leave the backward kernel as one partial row per frame and join the grouped folds of ``deferred_wgrad`` (fold_partials)."""
+
+    @staticmethod
+    def forward(ctx, mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):
+        b, t, hw, ld = mean.shape
+        mean, v = mean.contiguous(), v.contiguous()
+        dev = mean.device
+        w1f, b1f, w2f, b2f, ff = _f32(w1), _f32(b1), _f32(w2), _f32(b2), _f32(fill)
+        u = u.to(torch.float32).contiguous()
+        eps = eps.to(torch.float32).contiguous()
+        if mask_bt.dtype != torch.float32 or (mask_bt.shape[1] > 1 and mask_bt.stride(1) != 1):
+            mask_bt = mask_bt.to(torch.float32).contiguous()
+        logvar, comp = torch.empty_like(mean), torch.empty_like(mean)
+        sel = torch.empty((b, t, 1, 1), dtype=torch.float32, device=dev)
+        y = torch.empty((b * t,), dtype=torch.float32, device=dev)
+        s1 = torch.empty((b * t, hw), dtype=torch.float32, device=dev)
+        kl = torch.empty((b, t), dtype=torch.float32, device=dev)
+        mp = mask_bt.stride(0) if mask_bt.shape[0] > 1 else 0
+        check(lib().vvae_encoder_head_fwd(_p(mean), _p(v), _p(w1f), _p(b1f), _p(w2f), _p(b2f), _p(u), _p(eps), _p(mask_bt), mp,
+                                          _p(ff), _p(logvar), _p(comp), _p(sel), _p(y), _p(s1), _p(kl), b, t, hw, ld, _stream()),
+              "vvae_encoder_head_fwd")
+        ctx.save_for_backward(mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, sel)
+        ctx.params = (w1, b1, w2, b2, fill)
+        ctx.set_materialize_grads(False)
+        return logvar, comp, sel, kl
+
+    @staticmethod
+    def backward(ctx, dlv, dcomp, dsel, gkl):
+        mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, sel = ctx.saved_tensors
+        w1, b1, w2, b2, fill = ctx.params
+        b, t, hw, ld = mean.shape
+        dev = mean.device
+        if dcomp is not None:
+            dcomp = dcomp.to(torch.bfloat16).contiguous()
+        if dlv is not None:
+            dlv = dlv.to(torch.bfloat16).contiguous()
+        if dsel is not None:
+            dsel = dsel.to(torch.float32).contiguous()
+        gb = gt = 0
+        if gkl is not None:
+            if gkl.dtype != torch.float32:
+                gkl = gkl.to(torch.float32)
+            gb, gt = gkl.stride(0), gkl.stride(1)
+        dmean, dv = torch.empty_like(mean), torch.empty_like(v)
+        f = b * t
+        part = torch.empty((2 * f * ld + f * hw + 8 * f,), dtype=torch.float32, device=dev)      # row widths: multiples of four floats (the folds)
+        p1, p2, p3 = part[:f * ld].view(f, ld), part[f * ld:f * (ld + hw)].view(f, hw), part[f * (ld + hw):f * (2 * ld + hw)].view(f, ld)
+        pb = part[f * (2 * ld + hw):].view(2, f, 4)
+        mp = mask_bt.stride(0) if mask_bt.shape[0] > 1 else 0
+        check(lib().vvae_encoder_head_bwd(_p(mean), _p(v), _p(eps), _p(mask_bt), mp, _p(ff), _p(w1f), _p(w2f), _p(y), _p(s1), _p(sel),
+                                          _p(dcomp), _p(dsel), _p(gkl), gb, gt, _p(dlv), _p(dmean), _p(dv), _p(p1), _p(p2), _p(p3), _p(pb), b, t, hw,
+                                          ld, _stream()), "vvae_encoder_head_bwd")
+        dw1, _ = fold_partials(p1, w1, None, ld)
+        dw2, _ = fold_partials(p2, w2, None, hw)
+        dfill, _ = fold_partials(p3, fill, None, ld)
+        db1, _ = fold_partials(pb[0], b1, None, 1)
+        db2, _ = fold_partials(pb[1], b2, None, 1)
+        like = lambda g, p: None if g is None else g.reshape(p.shape).to(p.dtype)
+        return (dmean, dv, like(dw1, w1), like(db1, b1), like(dw2, w2), like(db2, b2), like(dfill, fill), None, None, None)
+
+
+def encoder_head_ok(mean, v, w1, b1, w2, b2, fill):
+    """bf16 GPU activations (b, t, hw, ld), fp32 parameters of the shapes nnx.Linear(ld, 1) / nnx.Linear(hw, 1) give, ld a multiple of 8."""
+    if not (mean.is_cuda and mean.dim() == 4 and mean.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and v.shape == mean.shape):
+        return False
+    b, t, hw, ld = mean.shape
+    return (w1.numel() == ld and b1.numel() == 1 and w2.numel() == hw and b2.numel() == 1 and fill.numel() == ld
+            and all(p.dtype == torch.float32 for p in (w1, b1, w2, b2, fill)) and bool(lib().vvae_encoder_head_ok(b, t, hw, ld)))
+
+
+def encoder_head(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):
+    """-> (log_variance bf16, compressed_representation bf16, selection (b, t, 1, 1) in {0, 1} with the straight-through gradient,
+    kl (b, t): the per-sample KL term as one partial sum per frame)."""
+    return _EncoderHead.apply(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt)
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm
