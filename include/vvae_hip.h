@@ -101,12 +101,21 @@ int vvae_colsum_blocks(long V);   /* rows of vvae_colsum's partial buffer */
 /* out[c] = sum over V rows of x[v][c]; part: fp32 scratch, vvae_colsum_blocks(V) x C floats; two stages, no atomics: bitwise reproducible */
 int vvae_colsum(const void* x, int ld, long V, int C, float* out, float* part, int dtype, void* stream);
 
+/* ---- zero-pad (unpad = 0) / cut back (unpad = 1) the last two dims of n <= 8 small contiguous fp32 tensors in one launch: the UNet's
+ *      12-channel weights on the 16-channel matrix-core kernels (train/unet.py:98-104).  pad: src (rows, s0, s1) -> dst (rows, d0, d1);
+ *      unpad: src (rows, d0, d1) -> dst (rows, s0, s1).  Host arrays of device pointers / ints. ---- */
+int vvae_pad_last2_grouped(const float* const* src, float* const* dst, const long* rows, const int* s0, const int* s1, const int* d0,
+                           const int* d1, int n, int unpad, void* stream);
+
 /* ---- 1x1x1 convolutions onto 3 channels as HBM streams (UNet.final_conv train/unet.py:144-153,188; the PatchUnEmbedding
  *      down-projection train/layers.py:60-79).  Reached through vvae_conv3d_{fwd,dgrad,wgrad}; V = voxels, Cin in {12, 16}. ---- */
 int vvae_conv_pointwise_supported(int Cin, int Cout, int kt, int kh, int kw, int ldx, int dtype, const void* x);
 size_t vvae_conv_pointwise_ws_bytes(long V, int Cin, int Cout);
 int vvae_conv_pointwise_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, long V, int Cin, int Cout,
                             int dtype, void* stream);
+/* y = addend + conv(x) + bias (addend: V rows of Cout channels, pitch ldadd, or NULL): the decoder's coarse + UNet(features), train/model.py:97 */
+int vvae_conv_pointwise_fwd_add(const void* x, int ldx, const float* w, const float* bias, const void* addend, int ldadd, void* y, int ldy,
+                                long V, int Cin, int Cout, int dtype, void* stream);
 int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, long V, int Cin, int Cout, int dtype,
                               void* stream);
 int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, long V, int Cin, int Cout,
@@ -201,6 +210,9 @@ int vvae_convt_bf16_supported(int Cin, int Cout, int ld_in, int ld_out);
 size_t vvae_convt_bf16_ws_bytes(int Cin, int Cout);
 int vvae_convt_1x2x2_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
                           int NT, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream);
+/* dgrad bit 8 (0x100): ws already holds that direction's packed weights, written by this call for n <= 16 kernels in one launch
+ * (host arrays of device pointers / ints; ws[i] >= vvae_convt_bf16_ws_bytes(Cin[i], Cout[i]) bytes): once per optimizer step. */
+int vvae_convt_pack_grouped_bf16(const float* const* w, void* const* ws, const int* Cin, const int* Cout, const int* dgrad, int n, void* stream);
 
 /* ---- temporal attention core: q_norm/k_norm + RoPE + masked softmax(QK^T/sqrt(D))V,
  *      train/layers.py:159-170 (called from FactoredAttention, layers.py:212-213).

@@ -1472,6 +1472,94 @@ def test_encoder_head_matches_the_framework_ops(dev, b, t, hw, ld):
         assert_close_scaled(a.float(), w.float(), rel=2e-2, what=what)
 
 
+def test_pad_last2_group_matches_f_pad(dev):
+    """ops.pad_last2_group (the UNet's three 12-channel weight pads in one launch each way) against F.pad: values, and the gradients
+    of a padded-space cotangent cut back to the parameters' shapes."""
+    import torch.nn.functional as F
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(3)
+    km = torch.randn(3, 7, 7, 12, 12, generator=g).to(dev).requires_grad_(True)
+    bm = torch.randn(12, generator=g).to(dev).requires_grad_(True)
+    k1 = torch.randn(3, 3, 3, 12, 16, generator=g).to(dev).requires_grad_(True)
+    kd = torch.randn(12, 3, generator=g).to(dev).requires_grad_(True)
+    outs = ops.pad_last2_group([km, bm, k1, kd], [(16, 16), (16,), (16, 16), (16, 3)])
+    want = [F.pad(km, (0, 4, 0, 4)), F.pad(bm, (0, 4)), F.pad(k1, (0, 0, 0, 4)), F.pad(kd, (0, 0, 0, 4))]
+    cots = [torch.randn(w.shape, generator=g).to(dev) for w in want]
+    for o, w in zip(outs, want):
+        assert o.shape == w.shape and torch.equal(o, w.detach())
+    grads = torch.autograd.grad(outs, [km, bm, k1, kd], cots)
+    refs = torch.autograd.grad(want, [km, bm, k1, kd], cots)
+    for a, r in zip(grads, refs):
+        assert a.shape == r.shape and torch.equal(a, r)
+
+
+def test_pointwise_conv_with_addend(dev):
+    """ops.conv3d_pointwise_add = addend + conv1x1x1(x) (the decoder's coarse + UNet(features), reference train/model.py:97) in one
+    launch: against the two-launch form, forward (one rounding fewer) and all four gradients."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(4)
+    bf = torch.bfloat16
+    x = torch.randn(2, 3, 16, 24, 16, generator=g).to(dev, bf).requires_grad_(True)
+    add = torch.randn(2, 3, 16, 24, 3, generator=g).to(dev, bf).requires_grad_(True)
+    k = (torch.randn(1, 1, 1, 16, 3, generator=g) * 0.3).to(dev).requires_grad_(True)
+    b = torch.randn(3, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(2, 3, 16, 24, 3, generator=g).to(dev, bf)
+    assert ops.conv3d_pointwise_add_ok(x, k, add)
+    y1 = ops.conv3d_pointwise_add(x, k, b, add)
+    g1 = torch.autograd.grad(y1, [x, k, b, add], gy)
+    y0 = add + ops.conv3d(x, k, b)
+    g0 = torch.autograd.grad(y0, [x, k, b, add], gy)
+    ref = add.float() + torch.einsum("...i,io->...o", x.float(), k[0, 0, 0]) + b
+    assert float((y1.float() - ref).abs().max()) <= float((y0.float() - ref).abs().max()) + 1e-6
+    assert_close_scaled(y1.float(), ref, rel=8e-3, what="y")
+    for a, w, what in zip(g1, g0, ("dx", "dk", "db", "d addend")):
+        assert a.shape == w.shape and a.dtype == w.dtype
+        assert_close_scaled(a.float(), w.float(), rel=1e-5, what=what)
+
+
+def test_conv_transpose_prepacked_weights(dev):
+    """ops.convt_prepack (both packings of every up-conv kernel in one launch, once per step) gives bitwise the results of the per-call
+    packing, forward and input gradient, at the three decoder shapes."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(6)
+    ks = [(torch.randn(1, 2, 2, ci, co, generator=g) * 0.1).to(dev) for ci, co in ((128, 64), (64, 32), (32, 16))]
+    packs = ops.convt_prepack(ks)
+    assert all(p is not None for p in packs)
+    for k, pk in zip(ks, packs):
+        ci, co = k.shape[-2:]
+        x = torch.randn(2, 3, 8, 8, ci, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+        b = torch.randn(co, generator=g).to(dev)
+        gy = torch.randn(2, 3, 16, 16, co, generator=g).to(dev, torch.bfloat16)
+        y1 = ops.conv_transpose_1x2x2(x, k, b, pack=pk)
+        y0 = ops.conv_transpose_1x2x2(x, k, b)
+        assert torch.equal(y1, y0)
+        (d1,) = torch.autograd.grad(y1, x, gy)
+        (d0,) = torch.autograd.grad(y0, x, gy)
+        assert torch.equal(d1, d0)
+
+
+def test_linear_pair_matches_two_linears(dev):
+    """layers.linear_pair (the encoder's mean / variance heads as one autograd node: the second input-gradient product accumulates onto
+    the first) against two Linear calls."""
+    import video_vae_amd as V
+    from video_vae_amd.layers import Linear, linear_pair
+    l1 = Linear(768, 96, V.Rngs(1)).to(dev)
+    l2 = Linear(768, 96, V.Rngs(2)).to(dev)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 4, 64, 768, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    g1 = torch.randn(2, 4, 64, 96, generator=g).to(dev, torch.bfloat16)
+    g2 = torch.randn(2, 4, 64, 96, generator=g).to(dev, torch.bfloat16)
+    prm = [l1.kernel, l1.bias, l2.kernel, l2.bias]
+    a1, a2 = linear_pair(x, l1, l2)
+    ga = torch.autograd.grad([a1, a2], [x] + prm, [g1, g2])
+    b1, b2 = l1(x), l2(x)
+    gb = torch.autograd.grad([b1, b2], [x] + prm, [g1, g2])
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert_close_scaled(ga[0].float(), gb[0].float(), rel=8e-3, what="dx")        # one bf16 rounding instead of three
+    for a, w in zip(ga[1:], gb[1:]):
+        assert torch.equal(a, w)
+
+
 def test_fp32_fallback_paths_are_bitwise_reproducible(dev):
     """Round 3: the fp32 / odd-shape fallbacks (generic Conv3d and ConvTranspose weight + bias gradients, the any-head-dim temporal
     attention's q/k-norm scale gradients) accumulated with float atomics -- configs C1-C2 were reproducible to rounding only.  They now

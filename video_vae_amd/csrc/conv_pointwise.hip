@@ -38,9 +38,11 @@ __device__ __forceinline__ void store_vox(T_* __restrict__ p, const float (&x)[C
     }
 }
 
+// addend (row pitch ldadd) != nullptr: y = addend + conv(x) -- the decoder's `coarse + UNet(features)` (reference train/model.py:97) inside
+// the product that ends the UNet, rounded once, instead of a 100 MB add launch behind it.
 template <typename T_, int CIN, int COUT>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const T_* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                     T_* __restrict__ y, PwDims d)
+                                                     T_* __restrict__ y, PwDims d, const T_* __restrict__ addend = nullptr, int ldadd = 0)
 {
     float wr[CIN][COUT], br[COUT];
 #pragma unroll
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const T_* __restrict__ x, c
             float a = br[co];
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) a += xv[ci] * wr[ci][co];
+            if (addend) a += ldf(addend + v * ldadd + co);
             stf(y + v * d.ldy + co, a);
         }
     }
@@ -142,22 +145,30 @@ extern "C" int vvae_conv_pointwise_supported(int Cin, int Cout, int kt, int kh, 
 // scratch for vvae_conv_pointwise_wgrad
 extern "C" size_t vvae_conv_pointwise_ws_bytes(long V, int Cin, int Cout) { return (size_t)pw_blocks(V) * (Cin * Cout + Cout) * sizeof(float); }
 
-extern "C" int vvae_conv_pointwise_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, long V, int Cin, int Cout,
-                                       int dtype, void* stream)
+// addend (V rows of Cout channels, row pitch ldadd, same dtype) may be NULL; otherwise y = addend + conv(x) + bias.
+extern "C" int vvae_conv_pointwise_fwd_add(const void* x, int ldx, const float* w, const float* bias, const void* addend, int ldadd, void* y, int ldy,
+                                           long V, int Cin, int Cout, int dtype, void* stream)
 {
-    if (!x || !w || !y || V <= 0 || ldy < Cout || !vvae_conv_pointwise_supported(Cin, Cout, 1, 1, 1, ldx, dtype, x)) return VVAE_ERR_BAD_ARG;
+    if (!x || !w || !y || V <= 0 || ldy < Cout || (addend && ldadd < Cout) || !vvae_conv_pointwise_supported(Cin, Cout, 1, 1, 1, ldx, dtype, x))
+        return VVAE_ERR_BAD_ARG;
     PwDims d{V, ldx, ldy};
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pw_blocks(V) * 4 > (V + 255) / 256 ? (unsigned)((V + 255) / 256) : (unsigned)(pw_blocks(V) * 4));
     if (dtype == VVAE_DT_F32) {
-        if (Cin == 16) hipLaunchKernelGGL((pw_fwd_kernel<float, 16, 3>), grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, d);
-        else hipLaunchKernelGGL((pw_fwd_kernel<float, 12, 3>), grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, d);
+        if (Cin == 16) hipLaunchKernelGGL((pw_fwd_kernel<float, 16, 3>), grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, d, (const float*)addend, ldadd);
+        else hipLaunchKernelGGL((pw_fwd_kernel<float, 12, 3>), grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, d, (const float*)addend, ldadd);
     } else {
-        if (Cin == 16) hipLaunchKernelGGL((pw_fwd_kernel<bf16_t, 16, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, d);
-        else hipLaunchKernelGGL((pw_fwd_kernel<bf16_t, 12, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, d);
+        if (Cin == 16) hipLaunchKernelGGL((pw_fwd_kernel<bf16_t, 16, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, d, (const bf16_t*)addend, ldadd);
+        else hipLaunchKernelGGL((pw_fwd_kernel<bf16_t, 12, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, d, (const bf16_t*)addend, ldadd);
     }
     VVAE_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vvae_conv_pointwise_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, long V, int Cin, int Cout,
+                                       int dtype, void* stream)
+{
+    return vvae_conv_pointwise_fwd_add(x, ldx, w, bias, nullptr, 0, y, ldy, V, Cin, Cout, dtype, stream);
 }
 
 extern "C" int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, long V, int Cin, int Cout, int dtype,

@@ -338,32 +338,62 @@ template <int MODE, int CIN, int COUT> struct CtCfg {
 
 // packed[(ot*KSTEPS + ks)*64 + lane] = 8 bf16: row = lane&15 (output channel in tile), k = 32ks + 8(lane>>4) + e
 template <int MODE, int CIN, int COUT>
+__device__ __forceinline__ void convt_pack_item(const float* __restrict__ w, uint4* __restrict__ wp, int i)
+{
+    typedef CtCfg<MODE, CIN, COUT> C;
+    const int l = i & 63, ks = (i >> 6) % C::KSTEPS, ot = (i >> 6) / C::KSTEPS;
+    const int row = l & 15, g = l >> 4;
+    uint32_t pk[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int a, b, ci, co;
+        if (MODE == 0) {
+            const int cot = ot % (COUT / 16), ab = ot / (COUT / 16);
+            a = ab >> 1; b = ab & 1; co = cot * 16 + row; ci = 32 * ks + 8 * g + e;
+        } else {
+            ci = ot * 16 + row;
+            int ab;
+            if (COUT >= 32) { ab = ks / (COUT / 32); co = (ks % (COUT / 32)) * 32 + 8 * g + e; }
+            else { ab = 2 * ks + (g >> 1); co = 8 * (g & 1) + e; }
+            a = ab >> 1; b = ab & 1;
+        }
+        const float v = w[((long)((1 - a) * 2 + (1 - b)) * CIN + ci) * COUT + co];
+        const uint32_t h = f2bf(v);
+        if (e & 1) pk[e >> 1] |= h << 16; else pk[e >> 1] = h;
+    }
+    wp[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+template <int MODE, int CIN, int COUT>
 __global__ void convt_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp)
 {
     typedef CtCfg<MODE, CIN, COUT> C;
     const int total = C::OT * C::KSTEPS * 64;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int l = i & 63, ks = (i >> 6) % C::KSTEPS, ot = (i >> 6) / C::KSTEPS;
-        const int row = l & 15, g = l >> 4;
-        uint32_t pk[4];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int a, b, ci, co;
-            if (MODE == 0) {
-                const int cot = ot % (COUT / 16), ab = ot / (COUT / 16);
-                a = ab >> 1; b = ab & 1; co = cot * 16 + row; ci = 32 * ks + 8 * g + e;
-            } else {
-                ci = ot * 16 + row;
-                int ab;
-                if (COUT >= 32) { ab = ks / (COUT / 32); co = (ks % (COUT / 32)) * 32 + 8 * g + e; }
-                else { ab = 2 * ks + (g >> 1); co = 8 * (g & 1) + e; }
-                a = ab >> 1; b = ab & 1;
-            }
-            const float v = w[((long)((1 - a) * 2 + (1 - b)) * CIN + ci) * COUT + co];
-            const uint32_t h = f2bf(v);
-            if (e & 1) pk[e >> 1] |= h << 16; else pk[e >> 1] = h;
-        }
-        wp[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) convt_pack_item<MODE, CIN, COUT>(w, wp, i);
+}
+
+// Grouped form: the forward and input-gradient packings of every ConvTranspose layer of a network in ONE launch, once per optimizer
+// step (they were a 5 us launch in front of each of the six ConvTranspose launches of a step).  Every packing is 4 Cin Cout / 8 fragment
+// lanes whatever the mode; blocks [block_start_e, block_start_{e+1}) of 256 lanes belong to entry e.
+constexpr int CT_PACK_MAX = 16;
+struct CtPackEntry { const float* w; uint4* wp; int mode, cin, total, block_start; };
+struct CtPackArgs { CtPackEntry e[CT_PACK_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void convt_pack_grouped_kernel(CtPackArgs g)
+{
+    int ei = 0;
+    for (int i = 1; i < g.n; ++i) ei = (int)blockIdx.x >= g.e[i].block_start ? i : ei;
+    const CtPackEntry& E = g.e[ei];
+    const int i = ((int)blockIdx.x - E.block_start) * 256 + threadIdx.x;
+    if (i >= E.total) return;
+    if (E.mode == 0) {
+        if (E.cin == 128) convt_pack_item<0, 128, 64>(E.w, E.wp, i);
+        else if (E.cin == 64) convt_pack_item<0, 64, 32>(E.w, E.wp, i);
+        else convt_pack_item<0, 32, 16>(E.w, E.wp, i);
+    } else {
+        if (E.cin == 128) convt_pack_item<1, 128, 64>(E.w, E.wp, i);
+        else if (E.cin == 64) convt_pack_item<1, 64, 32>(E.w, E.wp, i);
+        else convt_pack_item<1, 32, 16>(E.w, E.wp, i);
     }
 }
 
@@ -433,12 +463,14 @@ __global__ __launch_bounds__(256) void convt_bf16_kernel(const bf16_t* __restric
 
 template <int MODE, int CIN, int COUT>
 int launch_convt_bf16(const void* in, int ldin, const float* w, const float* bias, void* out, int ldout, int NT, int H, int W, void* ws,
-                      hipStream_t s)
+                      hipStream_t s, bool prepacked)
 {
     typedef CtCfg<MODE, CIN, COUT> C;
     uint4* wp = (uint4*)ws;
-    hipLaunchKernelGGL((convt_pack_kernel<MODE, CIN, COUT>), dim3(ceil_div(C::OT * C::KSTEPS * 64, 256)), dim3(256), 0, s, w, wp);
-    VVAE_LAUNCH_CHECK();
+    if (!prepacked) {
+        hipLaunchKernelGGL((convt_pack_kernel<MODE, CIN, COUT>), dim3(ceil_div(C::OT * C::KSTEPS * 64, 256)), dim3(256), 0, s, w, wp);
+        VVAE_LAUNCH_CHECK();
+    }
     const long nvt = ((long)NT * H * W + 15) / 16;
     long blocks = (nvt + (4 / C::WSPLIT) - 1) / (4 / C::WSPLIT);
     if (blocks > 4096) blocks = 4096;
@@ -460,19 +492,43 @@ extern "C" int vvae_convt_bf16_supported(int Cin, int Cout, int ld_in, int ld_ou
 
 extern "C" size_t vvae_convt_bf16_ws_bytes(int Cin, int Cout) { return convt_bf16_shape(Cin, Cout) ? (size_t)4 * Cin * Cout * 2 : 0; }
 
-// dgrad = 0: x (NT,H,W,Cin) -> y (NT,2H,2W,Cout) + bias.  dgrad = 1: "x" is dy (NT,2H,2W,Cout), "y" is dx (NT,H,W,Cin).
+// Pack n <= 16 ConvTranspose kernels w[i] (1,2,2,Cin[i],Cout[i]) fp32 for the forward (dgrad[i] = 0) or input-gradient (1) kernel into
+// ws[i] (>= vvae_convt_bf16_ws_bytes(Cin[i], Cout[i]) bytes, 16-byte aligned) in one launch; pass dgrad | 0x100 to vvae_convt_1x2x2_bf16
+// afterwards.  Host arrays of device pointers / ints.
+extern "C" int vvae_convt_pack_grouped_bf16(const float* const* w, void* const* ws, const int* Cin, const int* Cout, const int* dgrad, int n,
+                                            void* stream)
+{
+    if (!w || !ws || !Cin || !Cout || !dgrad || n <= 0 || n > CT_PACK_MAX) return VVAE_ERR_BAD_ARG;
+    CtPackArgs g;
+    g.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || !ws[i] || ((uintptr_t)ws[i] % 16) || !convt_bf16_shape(Cin[i], Cout[i])) return VVAE_ERR_BAD_ARG;
+        const int total = 4 * Cin[i] * Cout[i] / 8;
+        g.e[i] = CtPackEntry{w[i], (uint4*)ws[i], dgrad[i] & 1, Cin[i], total, blocks};
+        blocks += ceil_div(total, 256);
+    }
+    hipLaunchKernelGGL(convt_pack_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dgrad bit 0 = 0: x (NT,H,W,Cin) -> y (NT,2H,2W,Cout) + bias.  bit 0 = 1: "x" is dy (NT,2H,2W,Cout), "y" is dx (NT,H,W,Cin).
+// bit 8 (0x100): ws already holds this direction's packed weights (vvae_convt_pack_grouped_bf16); w may then be NULL.
 extern "C" int vvae_convt_1x2x2_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
                                      int NT, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream)
 {
-    if (!x || !w || !y || NT <= 0 || H <= 0 || W <= 0 || !convt_bf16_shape(Cin, Cout)) return VVAE_ERR_BAD_ARG;
+    const bool prepacked = (dgrad & 0x100) != 0;
+    dgrad &= 1;
+    if (!x || (!w && !prepacked) || !y || NT <= 0 || H <= 0 || W <= 0 || !convt_bf16_shape(Cin, Cout)) return VVAE_ERR_BAD_ARG;
     const int cin_side = dgrad ? Cout : Cin, cout_side = dgrad ? Cin : Cout;
     if (ldx < cin_side || ldy < cout_side || ldx % 8 || ldy % 4 || ((uintptr_t)x % 16) || ((uintptr_t)y % 8)) return VVAE_ERR_BAD_ARG;
     if (!ws || ws_bytes < vvae_convt_bf16_ws_bytes(Cin, Cout) || ((uintptr_t)ws % 16)) return VVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
 #define CT_GO(CI, CO)                                                                                                   \
     if (Cin == CI && Cout == CO)                                                                                        \
-        return dgrad ? launch_convt_bf16<1, CI, CO>(x, ldx, w, nullptr, y, ldy, NT, H, W, ws, s)                        \
-                     : launch_convt_bf16<0, CI, CO>(x, ldx, w, bias, y, ldy, NT, H, W, ws, s);
+        return dgrad ? launch_convt_bf16<1, CI, CO>(x, ldx, w, nullptr, y, ldy, NT, H, W, ws, s, prepacked)             \
+                     : launch_convt_bf16<0, CI, CO>(x, ldx, w, bias, y, ldy, NT, H, W, ws, s, prepacked);
     CT_GO(128, 64) CT_GO(64, 32) CT_GO(32, 16)
 #undef CT_GO
     return VVAE_ERR_BAD_ARG;

@@ -112,7 +112,7 @@ class GraphedTrainStep:
         self._capture(warmup)
 
     def _loss(self):
-        emask = L.expand_mask(self.mask, self.hw)
+        emask = L.compact_mask(self.mask)                # a view: the (b*hw, 1, 1, t) expansion would be two launches of every replay
         if self.rl:
             return L.loss_fn(self.model, self.video, emask, self.mask, self.rngs, self.hparams, self.ploss, self.vgg_params)
         return L.loss_fn_plain(self.model, self.video, emask, self.mask, self.rngs, self.hparams)

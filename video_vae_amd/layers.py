@@ -131,18 +131,66 @@ class _LinearBf16(torch.autograd.Function):
             dy2 = dy2.to(torch.bfloat16)
         dres = dy if ctx.has_res else None               # the residual edge: identity
         dx = torch.mm(dy2, wb.t()).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ops.wgrad_deferrable(x2, dy2, ctx.kparam, ctx.bparam):
-            # parked: multiplied after backward in a grouped launch, straight into the optimizer's flat gradient buffer
-            ops.WGRAD_QUEUE[0].append((x2, dy2, ctx.kparam, ctx.bparam))
-            return dx, None, None, dres, None
-        if ctx.needs_input_grad[1] and ops.gemm_tn_supported(x2, dy2):
-            # split-K weight-gradient GEMM on the HIP kernel (bias gradient rides along): K = tokens >> M, N
-            dw, db = ops.gemm_tn(x2, dy2, ctx.needs_input_grad[2])
-        else:
-            dw = _dw_f32(x2, dy2) if ctx.needs_input_grad[1] else None
-            db = _colsum_f32(dy2) if ctx.needs_input_grad[2] else None
+        # parked (multiplied after backward in a grouped launch, straight into the optimizer's flat gradient buffer), the split-K HIP kernel
+        # (bias gradient rides along: K = tokens >> M, N), or the batched library product
+        dw, db = _linear_param_grads(x2, dy2, ctx.kparam, ctx.bparam, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, dres, None
+
+
+def _linear_param_grads(x2, dy2, kparam, bparam, need_w, need_b):
+    """(dW, db) of a bf16 Linear as _LinearBf16.backward forms them: parked for the grouped launch (-> None, None), the own split-K
+    kernel, or the batched library product for widths it does not take."""
+    if need_w and need_b and ops.wgrad_deferrable(x2, dy2, kparam, bparam):
+        ops.WGRAD_QUEUE[0].append((x2, dy2, kparam, bparam))
+        return None, None
+    if need_w and ops.gemm_tn_supported(x2, dy2):
+        return ops.gemm_tn(x2, dy2, need_b)
+    return (_dw_f32(x2, dy2) if need_w else None), (_colsum_f32(dy2) if need_b else None)
+
+
+class _LinearPairBf16(torch.autograd.Function):
+    """(x @ W1 + b1, x @ W2 + b2) for two Linear layers reading the same tensor (the encoder's mean and variance heads, reference
+    train/model.py:53-55).  One autograd node so that the two input gradients meet INSIDE the second product (dy2 @ W2^T accumulated onto
+    dy1 @ W1^T through the library's C operand) instead of in a 25 MB add launch behind two products."""
+
+    @staticmethod
+    def forward(ctx, x, k1, b1, k2, b2):
+        x2 = x.reshape(-1, x.shape[-1])
+        w = [getattr(k, "bf16", None) if getattr(k, "bf16", None) is not None else k.detach().to(torch.bfloat16) for k in (k1, k2)]
+        b = [getattr(t, "bf16", None) if getattr(t, "bf16", None) is not None else t.detach().to(torch.bfloat16) for t in (b1, b2)]
+        ctx.save_for_backward(x2, w[0], w[1])
+        ctx.xshape = x.shape
+        ctx.params = (k1, b1, k2, b2)
+        ctx.set_materialize_grads(False)
+        return tuple(torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1]) for wb, bb in zip(w, b))
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x2, w1, w2 = ctx.saved_tensors
+        k1, b1, k2, b2 = ctx.params
+        g = [None if d is None else d.reshape(-1, d.shape[-1]).to(torch.bfloat16) for d in (dy1, dy2)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            for d, wb in zip(g, (w1, w2)):
+                if d is not None:
+                    dx = torch.mm(d, wb.t()) if dx is None else dx.addmm_(d, wb.t())
+            dx = dx.view(ctx.xshape) if dx is not None else None
+        out = [dx]
+        for i, (d, kp, bp) in enumerate(((g[0], k1, b1), (g[1], k2, b2))):
+            if d is None:
+                out += [None, None]
+            else:
+                out += list(_linear_param_grads(x2, d, kp, bp, ctx.needs_input_grad[1 + 2 * i], ctx.needs_input_grad[2 + 2 * i]))
+        return tuple(out)
+
+
+def linear_pair(x, lin1, lin2):
+    """(lin1(x), lin2(x)) for two Linear modules of equal dtype; on the bf16 GPU path one autograd node (_LinearPairBf16)."""
+    x = x.to(lin1.dtype)
+    if (lin1.dtype == torch.bfloat16 and lin2.dtype == torch.bfloat16 and x.is_cuda and lin1.kernel.dtype == torch.float32
+            and lin2.kernel.dtype == torch.float32):
+        return _LinearPairBf16.apply(x, lin1.kernel, lin1.bias, lin2.kernel, lin2.bias)
+    return lin1(x), lin2(x)
 
 
 class _SiluLinearBf16(torch.autograd.Function):
@@ -354,7 +402,7 @@ class PatchUnEmbedding(nn.Module):
         x = self.upsample(self.linear(x))
         feat = _UnpatchPad.apply(x, p, self.height // p, self.width // p, u, pad)
         ds = self.downsample
-        kd = F.pad(ds.kernel, (0, 0, 0, pad))
+        (kd,) = ops.pad_last2_group([ds.kernel], [(cu + pad, ds.kernel.shape[1])])      # zero rows for the pad channels, one launch each way
         coarse = ops.conv3d(feat.to(ds.dtype), kd.view(1, 1, 1, *kd.shape), ds.bias)
         return feat, coarse
 

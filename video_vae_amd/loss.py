@@ -32,6 +32,12 @@ def expand_mask(mask, hw):
     return rearrange(mask, "b hw 1 1 time -> (b hw) 1 1 time")
 
 
+def compact_mask(mask):
+    """(b, t) -> (b, 1, 1, t): the un-expanded form claude_distributed/layers.py:213-214 takes.  Every block of this package accepts both
+    forms (layers.FactoredAttention); this one is a view -- no copy and no (b*hw, t) conversion inside the captured step."""
+    return mask.reshape(mask.shape[0], 1, 1, mask.shape[1])
+
+
 def kl_from_model(model, mean, logvar, mask_bt):
     """Per-sample KL term (rl_nonadversarial.py:146-147).  A train-mode forward already produced it in the same pass that
     reparameterised (ops.reparameterise_kl) and left it on the model, keyed by the very tensors it returned; anything else
@@ -127,8 +133,8 @@ def train_step(model, optimizer, video, mask, hparams, hw, rngs, perceptual_loss
     ``optimizer`` is a ``video_vae_amd.optim.Optimizer``; with a DDP-wrapped model the gradient all-reduce
     overlaps this backward (see ddp.py).
     """
-    original_mask = mask.clone()
-    emask = expand_mask(mask, hw)
+    original_mask = mask                               # nothing below writes to it (the reference's arrays are immutable)
+    emask = compact_mask(mask)                         # what expand_mask(mask, hw) carries (rl_nonadversarial.py:190-192), as a view
     optimizer.zero_grad()
     if _is_rl(model):
         loss, aux = loss_fn(model, video, emask, original_mask, rngs, hparams, perceptual_loss_fn, vgg_params)
@@ -145,8 +151,8 @@ def train_step(model, optimizer, video, mask, hparams, hw, rngs, perceptual_loss
 @torch.no_grad()
 def eval_step(model, video, mask, hparams, hw, rngs, perceptual_loss_fn=None, vgg_params=None):
     """eval_step calls the loss with train=True on purpose (rl_nonadversarial.py:200-208)."""
-    original_mask = mask.clone()
-    emask = expand_mask(mask, hw)
+    original_mask = mask
+    emask = compact_mask(mask)
     if _is_rl(model):
         return loss_fn(model, video, emask, original_mask, rngs, hparams, perceptual_loss_fn, vgg_params, train=True)
     return loss_fn_plain(model, video, emask, original_mask, rngs, hparams, train=True)

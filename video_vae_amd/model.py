@@ -5,7 +5,7 @@ from einops import rearrange
 from torch import nn
 
 from . import ops
-from .layers import PatchEmbedding, FactoredAttention, GumbelSigmoidSTE, PatchUnEmbedding, Linear
+from .layers import PatchEmbedding, FactoredAttention, GumbelSigmoidSTE, PatchUnEmbedding, Linear, linear_pair
 from .rngs import Rngs
 from .unet import UNet
 
@@ -79,7 +79,7 @@ class Encoder(nn.Module):
         ~45 framework launches per step.  The noise draws keep the reference's order: Gumbel, then reparameterisation."""
         sl1, sl2 = self.selection_layer1, self.selection_layer2
         h = self._features(x, mask)
-        mean, v = self.spatial_compression(h), self.variance_estimator(h)
+        mean, v = linear_pair(h, self.spatial_compression, self.variance_estimator)      # one node: the two input gradients meet inside a product
         b, t = mean.shape[0], mean.shape[1]
         u = rngs.draw("gumbel_u", "uniform", (b, t, 1), mean.device)
         eps = rngs.draw("reparam_eps", "normal", mean.shape, mean.device)
@@ -118,7 +118,7 @@ class Decoder(nn.Module):
                 x = r
         out = self.patch_unembedding.forward_padded(x)              # bf16 GPU path: un-patchify + channel pad in one copy
         feat, x = out if out is not None else self.patch_unembedding(x)
-        return x + self.unet(feat)
+        return self.unet(feat, residual=x)                          # x + self.unet(feat): the add rides in the UNet's final product
 
 
 class VideoVAE(nn.Module):

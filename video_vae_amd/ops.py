@@ -193,6 +193,65 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None, k_real=0
     return out
 
 
+# --------------------------------------------------------------------------------------------- grouped zero-padding of small weights
+def _pad_group_launch(srcs, dsts, rows_, s01, d01, unpad):
+    n = len(srcs)
+    VP, LA, IA = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+    check(lib().vvae_pad_last2_grouped(VP(*[t.data_ptr() for t in srcs]), VP(*[t.data_ptr() for t in dsts]), LA(*rows_),
+                                       IA(*[a for a, _ in s01]), IA(*[b for _, b in s01]), IA(*[a for a, _ in d01]), IA(*[b for _, b in d01]),
+                                       n, 1 if unpad else 0, _stream()), "vvae_pad_last2_grouped")
+
+
+def _last2(shape):
+    return (shape[-2], shape[-1]) if len(shape) >= 2 else (1, shape[-1])
+
+
+class _PadLast2Group(torch.autograd.Function):
+    """Zero-pad the last two dims of up to 8 small fp32 parameters in one launch (vvae_pad_last2_grouped); the backward cuts the padded
+    gradients back in one launch too -- inside ``deferred_wgrad`` straight into the parameters' slots of the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, targets, *srcs):
+        ctx.params = srcs
+        ctx.targets = targets
+        s32 = [_f32(t) for t in srcs]
+        outs = [torch.empty(tuple(t.shape[:-len(tg)]) + tuple(tg), dtype=torch.float32, device=t.device) for t, tg in zip(s32, targets)]
+        s01 = [_last2(t.shape) for t in s32]
+        d01 = [_last2(o.shape) for o in outs]
+        _pad_group_launch(s32, outs, [t.numel() // (a * b) for t, (a, b) in zip(s32, s01)], s01, d01, False)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        q = WGRAD_QUEUE[0]
+        todo, res = [], []
+        for p, g in zip(ctx.params, gs):
+            if g is None:
+                res.append(None)
+                continue
+            g = g.to(torch.float32).contiguous()
+            direct = q is not None and getattr(p, "gview", None) is not None and p.dtype == torch.float32
+            dst = p.gview.view(p.shape) if direct else torch.empty(p.shape, dtype=torch.float32, device=g.device)
+            todo.append((g, dst, p, direct))
+            res.append(None if direct else dst)
+        if todo:
+            s01 = [_last2(d.shape) for _, d, _, _ in todo]
+            d01 = [_last2(g.shape) for g, _, _, _ in todo]
+            _pad_group_launch([g for g, _, _, _ in todo], [d for _, d, _, _ in todo],
+                              [d.numel() // (a * b) for (_, d, _, _), (a, b) in zip(todo, s01)], s01, d01, True)
+            for _, _, p, direct in todo:
+                if direct:
+                    q.opt.mark_external(p)
+        return (None,) + tuple(r if r is None else r.to(p.dtype) for r, p in zip(res, ctx.params))
+
+
+def pad_last2_group(tensors, targets):
+    """-> zero-padded fp32 copies of ``tensors`` (GPU parameters): ``targets[i]`` is the new size of the last two dims (one dim for a
+    vector).  One launch forward, one backward, however many tensors (<= 8)."""
+    return _PadLast2Group.apply(tuple(tuple(t) for t in targets), *tensors)
+
+
 # --------------------------------------------------------------------------------------------- Conv3d
 def conv3d_fwd_raw(x, kernel, bias, out=None, packed=None, k_real=0, price=None):
     x, ldx = rows(x)
@@ -369,6 +428,48 @@ class _Conv3d(torch.autograd.Function):
             dw, db = conv3d_wgrad_raw(x, dy, tuple(k32.shape), ctx.has_bias, price=ctx.price)
             dw = dw.to(ctx.kdtype)
         return dx, dw, db
+
+
+class _PointwiseAdd(torch.autograd.Function):
+    """addend + conv1x1x1(x) in one launch (vvae_conv_pointwise_fwd_add): the decoder's ``coarse + UNet(features)`` (reference
+    train/model.py:97) inside the product that ends the UNet.  Backward = _Conv3d's, and the gradient itself for the addend."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, addend):
+        k32 = _f32(kernel)
+        b32 = _f32(bias) if bias is not None else None
+        ctx.save_for_backward(x, k32)
+        ctx.real = ctx.price = ctx.pack = None
+        ctx.has_bias = bias is not None
+        ctx.kdtype = kernel.dtype
+        ctx.kparam, ctx.bparam = kernel, bias
+        xr, ldx = rows(x)
+        ar, lda = rows(addend)
+        cin, cout = k32.shape[-2], k32.shape[-1]
+        out = torch.empty(addend.shape, dtype=x.dtype, device=x.device)
+        vox = x.numel() // cin
+        h, w = x.shape[-3], x.shape[-2]
+        check(_launch(f"conv3d_fwd+add {cin}->{cout} k111 @{h}x{w}", vox * (cin + 2 * cout) * x.element_size(), 2 * vox * cin * cout, "pw_fwd_kernel",
+                      lambda: lib().vvae_conv_pointwise_fwd_add(_p(xr), ldx, _p(k32), _p(b32), _p(ar), lda, _p(out), out.stride(-2), vox, cin, cout,
+                                                                _dt(x), _stream())), "vvae_conv_pointwise_fwd_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dw, db = _Conv3d._backward(ctx, dy)
+        return dx, dw, db, dy
+
+
+def conv3d_pointwise_add_ok(x, kernel, addend):
+    kt, kh, kw, cin, cout = kernel.shape
+    return (x.is_cuda and not _FORCE_GENERIC[0] and x.dtype == addend.dtype and x.dtype in DT and x.shape[-1] == cin
+            and addend.shape == (*x.shape[:-1], cout) and x.stride(-1) == 1 and addend.stride(-1) == 1
+            and lib().vvae_conv_pointwise_supported(cin, cout, kt, kh, kw, x.stride(-2), DT[x.dtype], _p(x)) == 1)
+
+
+def conv3d_pointwise_add(x, kernel, bias, addend):
+    """addend + conv3d(x, kernel (1,1,1,Cin,Cout), bias), one pass and one rounding."""
+    return _PointwiseAdd.apply(x, kernel, bias, addend)
 
 
 # ---- conv over concat([xa, xb], channels) held as two dense tensors (the decoder's 16 + 16 channel level) ----
@@ -654,40 +755,71 @@ def _convt_fast(x, cin, cout, ld_in, ld_out):
             and lib().vvae_convt_bf16_supported(cin, cout, ld_in, ld_out) == 1)
 
 
-def _convt_bf16(x, ldx, kernel, bias, out, nt, h, w, cin, cout, dgrad):
-    """bf16 MFMA ConvTranspose (h, w = low resolution).  dgrad=1: x is dy at 2h x 2w, out is dx at h x w."""
-    wsb = lib().vvae_convt_bf16_ws_bytes(cin, cout)
-    ws, wsb = _ws(wsb, x.device)
+def _convt_bf16(x, ldx, kernel, bias, out, nt, h, w, cin, cout, dgrad, packed=None):
+    """bf16 MFMA ConvTranspose (h, w = low resolution).  dgrad=1: x is dy at 2h x 2w, out is dx at h x w.
+    ``packed``: this direction's weights already packed for the whole step (convt_prepack)."""
+    if packed is not None:
+        ws, wsb, flags = packed, packed.numel(), dgrad | 0x100
+    else:
+        wsb = lib().vvae_convt_bf16_ws_bytes(cin, cout)
+        ws, wsb = _ws(wsb, x.device)
+        flags = dgrad
     vox = nt * h * w
     alg = vox * (cin + 4 * cout) * 2
     tag = f"convt_{'dgrad' if dgrad else 'fwd'} {cin}->{cout} @{h}x{w}"
     check(_launch(tag, alg, 2 * vox * 4 * cin * cout, "convt_bf16_kernel",
                   lambda: lib().vvae_convt_1x2x2_bf16(_p(x), ldx, _p(kernel), _p(bias), _p(out), out.stride(-2), nt, h, w, cin, cout,
-                                                      dgrad, _p(ws), wsb, _stream())), "vvae_convt_1x2x2_bf16")
+                                                      flags, _p(ws), wsb, _stream())), "vvae_convt_1x2x2_bf16")
     return out
 
 
-def convt_fwd_raw(x, kernel, bias, out=None):
+def convt_prepack(kernels):
+    """Pack the forward and input-gradient forms of every ConvTranspose kernel (1, 2, 2, Cin, Cout) of a network in ONE launch
+    (vvae_convt_pack_grouped_bf16) -> list of ConvPack (None where the bf16 matrix-core path does not take the layer)."""
+    todo = [k for k in kernels if k.is_cuda and k.dtype == torch.float32 and not _FORCE_GENERIC[0]
+            and lib().vvae_convt_bf16_supported(k.shape[-2], k.shape[-1], 8, 8) == 1]
+    if not todo:
+        return [None] * len(kernels)
+    sizes = [(lib().vvae_convt_bf16_ws_bytes(k.shape[-2], k.shape[-1]) + 255) // 256 * 256 for k in todo]
+    buf = torch.empty(2 * sum(sizes), dtype=torch.uint8, device=todo[0].device)
+    packs, ent, off = {}, [], 0
+    for k, nb in zip(todo, sizes):
+        views = []
+        for which in (0, 1):
+            v = buf[off:off + nb]
+            off += nb
+            views.append(v)
+            ent.append((k.contiguous(), v, which))
+        packs[id(k)] = ConvPack(views[0], views[1])
+    n = len(ent)
+    VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    check(lib().vvae_convt_pack_grouped_bf16(VP(*[k.data_ptr() for k, _, _ in ent]), VP(*[v.data_ptr() for _, v, _ in ent]),
+                                             IA(*[k.shape[-2] for k, _, _ in ent]), IA(*[k.shape[-1] for k, _, _ in ent]),
+                                             IA(*[w for _, _, w in ent]), n, _stream()), "vvae_convt_pack_grouped_bf16")
+    return [packs.get(id(k)) for k in kernels]
+
+
+def convt_fwd_raw(x, kernel, bias, out=None, packed=None):
     x, ldx = rows(x)
     n, t, h, w, cin = x.shape
     cout = kernel.shape[-1]
     if out is None:
         out = torch.empty((n, t, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device)
     if _convt_fast(x, cin, cout, ldx, out.stride(-2)):
-        return _convt_bf16(x, ldx, kernel, bias, out, n * t, h, w, cin, cout, 0)
+        return _convt_bf16(x, ldx, kernel, bias, out, n * t, h, w, cin, cout, 0, packed)
     check(lib().vvae_convt_1x2x2_fwd(_p(x), ldx, _p(kernel), _p(bias), _p(out), out.stride(-2), n * t, h, w, cin, cout,
                                      _dt(x), _stream()), "vvae_convt_1x2x2_fwd")
     return out
 
 
-def convt_dgrad_raw(dy, kernel, out=None):
+def convt_dgrad_raw(dy, kernel, out=None, packed=None):
     dy, lddy = rows(dy)
     n, t, h2, w2, cout = dy.shape
     cin = kernel.shape[-2]
     if out is None:
         out = torch.empty((n, t, h2 // 2, w2 // 2, cin), dtype=dy.dtype, device=dy.device)
     if _convt_fast(dy, cin, cout, lddy, out.stride(-2)):
-        return _convt_bf16(dy, lddy, kernel, None, out, n * t, h2 // 2, w2 // 2, cin, cout, 1)
+        return _convt_bf16(dy, lddy, kernel, None, out, n * t, h2 // 2, w2 // 2, cin, cout, 1, packed)
     check(lib().vvae_convt_1x2x2_dgrad(_p(dy), lddy, _p(kernel), _p(out), out.stride(-2), n * t, h2 // 2, w2 // 2, cin, cout,
                                        _dt(dy), _stream()), "vvae_convt_1x2x2_dgrad")
     return out
@@ -738,25 +870,26 @@ def colsum_raw(x):
 
 class _ConvT(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias, out=None):
+    def forward(ctx, x, kernel, bias, out=None, pack=None):
         k32, b32 = _f32(kernel), _f32(bias)
         ctx.save_for_backward(x, k32)
         ctx.kdtype = kernel.dtype
-        return convt_fwd_raw(x, k32, b32, out)
+        ctx.pack = pack
+        return convt_fwd_raw(x, k32, b32, out, pack.fwd if pack is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
         x, k32 = ctx.saved_tensors
         dy = dy.to(x.dtype)
-        dx = convt_dgrad_raw(dy, k32) if ctx.needs_input_grad[0] else None
+        dx = convt_dgrad_raw(dy, k32, packed=ctx.pack.dgrad if ctx.pack is not None else None) if ctx.needs_input_grad[0] else None
         dw, db = convt_wgrad_db_raw(x, dy, tuple(k32.shape))
-        return dx, dw.to(ctx.kdtype), db.to(ctx.kdtype), None
+        return dx, dw.to(ctx.kdtype), db.to(ctx.kdtype), None, None
 
 
-def conv_transpose_1x2x2(x, kernel, bias, out=None):
+def conv_transpose_1x2x2(x, kernel, bias, out=None, pack=None):
     """nnx.ConvTranspose((1,2,2), strides (1,2,2)) (reference train/unet.py:61-69).  ``out``: a channel slice of a wider
-    NDHWC buffer to write into (see join_channels)."""
-    return _ConvT.apply(x, kernel, bias, out)
+    NDHWC buffer to write into (see join_channels).  ``pack``: this step's packed weights (convt_prepack)."""
+    return _ConvT.apply(x, kernel, bias, out, pack)
 
 
 class _JoinChannels(torch.autograd.Function):

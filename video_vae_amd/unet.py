@@ -39,8 +39,8 @@ class ConvTranspose(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features, dtype=param_dtype))
         self.dtype = dtype
 
-    def forward(self, x, out=None):
-        return ops.conv_transpose_1x2x2(x.to(self.dtype), self.kernel, self.bias, out)
+    def forward(self, x, out=None, pack=None):
+        return ops.conv_transpose_1x2x2(x.to(self.dtype), self.kernel, self.bias, out, pack)
 
 
 class GroupNorm(nn.Module):
@@ -100,14 +100,14 @@ class UpBlock3D(nn.Module):
         self.conv1 = ConvBlock3D(out_channels * 2, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
         self.conv2 = ConvBlock3D(out_channels, out_channels, 3, rngs, temporal_kernel, dtype, param_dtype)
 
-    def forward(self, x, skip, joint=None, packs=(None, None)):
+    def forward(self, x, skip, joint=None, packs=(None, None), up_pack=None):
         """joint: the (.., 2C) buffer whose upper channel half ``skip`` already is; the up-conv writes the lower half and the
-        concat of the reference (unet.py:79, a 268 MB copy at the 256^2 level) disappears."""
+        concat of the reference (unet.py:79, a 268 MB copy at the 256^2 level) disappears.  up_pack: the up-conv's packed weights."""
         if joint is not None:
             c = skip.shape[-1]
-            x = ops.join_channels(self.upsample(x, out=joint[..., :c]), skip, joint)
+            x = ops.join_channels(self.upsample(x, out=joint[..., :c], pack=up_pack), skip, joint)
             return self.conv2(self.conv1(x, pack=packs[0]), pack=packs[1])
-        up = self.upsample(x)
+        up = self.upsample(x, pack=up_pack)
         if ops.conv3d_cat2_ok(up, skip, self.conv1.conv.kernel):
             # 16 + 16 channels: two dense tensors instead of the halves of a joint buffer (a 32-byte half-voxel write runs at a third
             # of the HBM rate); conv1 reads both, its input gradient writes both
@@ -143,7 +143,9 @@ class UNet(nn.Module):
             in_ch = out_ch
         self.final_conv = Conv(base_features, out_features, (1, 1, 1), rngs, dtype, param_dtype, zero_init=True)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual``: (b, t, h, w, out_features) added to the result -- the decoder's ``x + self.unet(feat)`` (reference train/model.py:97)
+        inside the final 1x1x1 product where the pointwise kernels take the shape, else a separate add."""
         x = x.to(self.dtype)
         c = self.patch_mixer.kernel.shape[-2]
         pad = (-c) % 16 if (x.is_cuda and self.dtype == torch.bfloat16 and len(self.encoders) > 0) else 0
@@ -157,12 +159,17 @@ class UNet(nn.Module):
                 x = F.pad(x, (0, pad))
             elif x.shape[-1] != c + pad:
                 raise ValueError(f"UNet expects {c} (or {c + pad} zero-padded) input channels, got {x.shape[-1]}")
-            km, bm = F.pad(km, (0, pad, 0, pad)), F.pad(bm, (0, pad))
-            k1 = F.pad(self.encoders[0].conv1.conv.kernel, (0, 0, 0, pad))
+            k1 = self.encoders[0].conv1.conv.kernel
+            if x.is_cuda and all(p.dtype == torch.float32 for p in (km, bm, k1)):
+                # the three pads in one launch (and their backward slices in one): six + four framework launches per step otherwise
+                km, bm, k1 = ops.pad_last2_group([km, bm, k1], [(c + pad, c + pad), (c + pad,), (c + pad, k1.shape[-1])])
+            else:
+                km, bm = F.pad(km, (0, pad, 0, pad)), F.pad(bm, (0, pad))
+                k1 = F.pad(k1, (0, 0, 0, pad))
         # the padded mixer tells the kernels how many of its 16 K channels are real: the product over the padding is skipped
         mixer_real = (c, c) if pad else None
         # every conv layer's weights are packed for the matrix-core kernels once per step, in one launch (they were 28 launches)
-        packs = None
+        packs, upacks = None, [None] * len(self.decoders)
         if x.is_cuda and self.dtype == torch.bfloat16:
             ks = [km]
             for i, enc in enumerate(self.encoders):
@@ -171,6 +178,7 @@ class UNet(nn.Module):
             for dec in self.decoders:
                 ks += [dec.conv1.conv.kernel, dec.conv2.conv.kernel]
             packs = ops.conv3d_prepack([k.detach() for k in ks], [mixer_real] + [None] * (len(ks) - 1))
+            upacks = ops.convt_prepack([dec.upsample.kernel.detach() for dec in self.decoders])      # likewise the up-convs: six launches
         pk = (lambda j: packs[j]) if packs is not None else (lambda j: None)
         x = ops.conv3d(x.to(self.patch_mixer.dtype), km, bm, pack=pk(0), real=mixer_real)
         skips, joints = [], []
@@ -191,5 +199,12 @@ class UNet(nn.Module):
         nb = 1 + 2 * len(self.encoders)
         x = self.bottleneck2(self.bottleneck1(x, pack=pk(nb)), pack=pk(nb + 1))
         for j, (dec, skip, joint) in enumerate(zip(self.decoders, reversed(skips), reversed(joints))):
-            x = dec(x, skip, joint, packs=(pk(nb + 2 + 2 * j), pk(nb + 3 + 2 * j)))
-        return self.final_conv(x)
+            x = dec(x, skip, joint, packs=(pk(nb + 2 + 2 * j), pk(nb + 3 + 2 * j)), up_pack=upacks[j])
+        if residual is None:
+            return self.final_conv(x)
+        fc = self.final_conv
+        x = x.to(fc.dtype)
+        residual = residual.to(fc.dtype)
+        if ops.conv3d_pointwise_add_ok(x, fc.kernel, residual):
+            return ops.conv3d_pointwise_add(x, fc.kernel, fc.bias, residual)
+        return residual + fc(x)
