@@ -1472,6 +1472,20 @@ def test_encoder_head_matches_the_framework_ops(dev, b, t, hw, ld):
         assert_close_scaled(a.float(), w.float(), rel=2e-2, what=what)
 
 
+@pytest.mark.parametrize("v,c,dt", [(16384, 768, torch.bfloat16), (16384, 96, torch.bfloat16), (1000, 8, torch.bfloat16), (777, 20, torch.float32),
+                                    (4096, 2048, torch.bfloat16), (300, 7, torch.bfloat16), (64, 1, torch.bfloat16)])
+def test_colsum_vector_and_scalar_forms(dev, v, c, dt):
+    """vvae_colsum (bias gradients of the Linear layers outside the GEMM kernels' shapes): the 16-byte vector form, the column-group loop
+    (more than 256 column vectors), the scalar fallback (odd widths), a pitched slice; against the fp64 column sums, twice (bitwise equal)."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(v + c)
+    x = torch.randn(v, c + 8, generator=g).to(dev, dt)[:, :c] if c % 8 == 0 else torch.randn(v, c, generator=g).to(dev, dt)
+    a = ops.colsum_raw(x)
+    b = ops.colsum_raw(x)
+    assert torch.equal(a, b) and a.shape == (c,) and a.dtype == torch.float32
+    assert_close_scaled(a, x.double().sum(0), rel=2e-5 if dt == torch.float32 else 1e-4, what="colsum")
+
+
 def test_pad_last2_group_matches_f_pad(dev):
     """ops.pad_last2_group (the UNet's three 12-channel weight pads in one launch each way) against F.pad: values, and the gradients
     of a padded-space cotangent cut back to the parameters' shapes."""

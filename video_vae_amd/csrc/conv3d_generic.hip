@@ -176,6 +176,47 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
         __syncthreads();
     }
 }
+// stage 1, vector form (C % VEC == 0, rows 16-byte aligned): a thread owns VEC consecutive columns and walks rows with 16-byte loads;
+// 256 / (C / VEC) row lanes per pass (column groups beyond 256 threads are walked in turn), folded through LDS in lane order.
+// The scalar form above reads 2 bytes per load: 198 us for the (16 384, 768) bias gradient of the decoder's first Linear, this one 10.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_part_vec_kernel(const T* __restrict__ x, int ld, long V, int C, float* __restrict__ part,
+                                                              int rows_per_block)
+{
+    __shared__ float red[256][VEC];
+    const int cvecs = C / VEC;
+    const int cpp = cvecs < 256 ? cvecs : 256;                       // column vectors per pass
+    const int rows = 256 / cpp;
+    const int cl = threadIdx.x % cpp, rl = threadIdx.x / cpp;
+    const long vbeg = (long)blockIdx.x * rows_per_block;
+    long vend = vbeg + rows_per_block;
+    if (vend > V) vend = V;
+    for (int c0 = 0; c0 < cvecs; c0 += cpp) {
+        const int cv = c0 + cl;
+        float a[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+        if (rl < rows && cv < cvecs)
+            for (long v = vbeg + rl; v < vend; v += rows) {
+                float t[VEC];
+                VecIO<T, VEC>::load(x + v * (long)ld + cv * VEC, t);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a[e] += t[e];
+            }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[threadIdx.x][e] = a[e];
+        __syncthreads();
+        if (rl == 0 && cv < cvecs) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float t = 0.f;
+                for (int i = 0; i < rows; ++i) t += red[i * cpp + cl][e];
+                part[(long)blockIdx.x * C + cv * VEC + e] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
 // stage 2: out[c] = sum_b part[b][c], b in index order
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out)
 {
@@ -334,7 +375,7 @@ extern "C" int vvae_conv3d_wgrad_generic(const void* x, int ldx, const void* dy,
 extern "C" int vvae_colsum_blocks(long V)
 {
     if (V <= 0) return 0;
-    const long b = (V + 255) / 256;                                  // >= 256 rows per workgroup, at most 1024 workgroups
+    const long b = (V + 31) / 32;                                    // >= 32 rows per workgroup, at most 1024 workgroups
     return (int)(b < 1024 ? b : 1024);
 }
 
@@ -348,12 +389,17 @@ extern "C" int vvae_colsum(const void* x, int ld, long V, int C, float* out, flo
     hipStream_t s = (hipStream_t)stream;
     const int nblk = vvae_colsum_blocks(V);
     const int vb = (int)((V + nblk - 1) / nblk);
-    if (dtype == VVAE_DT_F32)
-        hipLaunchKernelGGL((colsum_part_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)x, ld, V, C, part, vb);
-    else
-        hipLaunchKernelGGL((colsum_part_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, ld, V, C, part, vb);
+    const bool al = ((uintptr_t)x % 16) == 0;
+    if (dtype == VVAE_DT_F32) {
+        if (al && C % 4 == 0 && ld % 4 == 0) hipLaunchKernelGGL((colsum_part_vec_kernel<float, 4>), dim3(nblk), dim3(256), 0, s, (const float*)x, ld, V, C, part, vb);
+        else hipLaunchKernelGGL((colsum_part_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)x, ld, V, C, part, vb);
+    } else {
+        if (al && C % 8 == 0 && ld % 8 == 0) hipLaunchKernelGGL((colsum_part_vec_kernel<bf16_t, 8>), dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, ld, V, C, part, vb);
+        else hipLaunchKernelGGL((colsum_part_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, ld, V, C, part, vb);
+    }
     VVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, part, nblk, C, out);
+    // the partial rows sit in L2: 8 row lanes x 8 loads in flight per thread (common.hpp), same index order every time
+    hipLaunchKernelGGL(vvae_reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, s, (const float*)part, nblk, (long)C, C, out, C, (float*)nullptr);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
