@@ -147,7 +147,7 @@ int vvae_encoder_head_ok(int B, int T, int HW, int LD);
 int vvae_encoder_head_fwd(const void* mean, const void* v, const float* w1, const float* b1, const float* w2, const float* b2,
                           const float* u, const float* eps, const float* mask, long mask_pitch, const float* fill, void* logvar,
                           void* comp, float* sel, float* y, float* s1, float* kl_frame, int B, int T, int HW, int LD, void* stream);
-int vvae_encoder_head_bwd(const void* mean, const void* v, const float* eps, const float* mask, long mask_pitch, const float* fill,
+int vvae_encoder_head_bwd(const void* mean, const void* v, const void* logvar, const float* eps, const float* mask, long mask_pitch, const float* fill,
                           const float* w1, const float* w2, const float* y, const float* s1, const float* sel, const void* dcomp,
                           const float* dsel, const float* gkl, long gkl_pitch_b, long gkl_pitch_t, const void* dlv_ext, void* dmean, void* dv,
                           float* part1, float* part2, float* part3, float* partb, int B, int T, int HW, int LD, void* stream);

@@ -26,8 +26,16 @@ struct EhDims { int T, HW, LD, CG, TY; long mask_pitch; };
 
 __device__ __forceinline__ float bfr(float v) { return bf2f(f2bf(v)); }
 
-// softplus as the framework computes it (beta 1, threshold 20), in the compute dtype: result rounded to bf16
-__device__ __forceinline__ float softplus_bf(float v) { return bfr(v > 20.f ? v : log1pf(expf(v))); }
+// softplus as the framework computes it (beta 1, threshold 20), in the compute dtype: result rounded to bf16.  Hardware exp / log
+// (v_exp_f32 / v_log_f32, ~1e-6 relative) instead of the correctly rounded library calls: the result is rounded to 8 bits anyway, and
+// the library forms made these kernels VALU-bound (50 us each for 6 MB of operands; ~300 instructions per element).  log(1 + e) loses
+// the small e in the addition, so below v = -4 (e < 0.018) the series e - e^2/2 + e^3/3 stands in for log1p (relative error e^3/4 < 2e-6).
+__device__ __forceinline__ float softplus_bf(float v)
+{
+    if (v > 20.f) return bfr(v);
+    const float e = __expf(v);
+    return bfr(v < -4.f ? e * (1.f - e * (0.5f - e * (1.f / 3.f))) : __logf(1.f + e));
+}
 
 // sum over the workgroup in fixed order (lanes by butterfly, waves by index) -> every thread gets the total
 __device__ __forceinline__ float block_total(float v, float* red, float* out_slot)
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
             const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                lv[e] = bfr(logf(softplus_bf(vv[e])));
+                lv[e] = bfr(__logf(softplus_bf(vv[e])));
                 const float z = m[e] + ee[e] * __expf(0.5f * lv[e]);
                 o[e] = sel != 0.f ? z : fr[e];
                 kl += 0.5f * (__expf(lv[e]) - 1.f - lv[e] + m[e] * m[e]);
@@ -135,8 +143,8 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
 // part1 (F, LD) = dW1, part2 (F, HW) = dW2, part3 (F, LD) = d fill, partb (2, F, 4) = [db1 0 0 0] then [db2 0 0 0]: this frame's row of each
 // (row widths are multiples of four floats: what the caller's fold kernels take).
 __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
-    const bf16_t* __restrict__ mean, const bf16_t* __restrict__ v, const float* __restrict__ eps, const float* __restrict__ mask,
-    const float* __restrict__ fill, const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ y_in,
+    const bf16_t* __restrict__ mean, const bf16_t* __restrict__ v, const bf16_t* __restrict__ logvar, const float* __restrict__ eps,
+    const float* __restrict__ mask, const float* __restrict__ fill, const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ y_in,
     const float* __restrict__ s1_in, const float* __restrict__ sel_in, const bf16_t* __restrict__ dcomp, const float* __restrict__ dsel,
     const float* __restrict__ gkl, long gkl_pitch_b, long gkl_pitch_t, const bf16_t* __restrict__ dlv_ext, bf16_t* __restrict__ dmean, bf16_t* __restrict__ dv,
     float* __restrict__ part1, float* __restrict__ part2, float* __restrict__ part3, float* __restrict__ partb, EhDims d)
@@ -165,16 +173,15 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
     if (active && dcomp)
         for (int j = ty; j < d.HW; j += d.TY) {
             const long g = base + (long)j * d.LD;
-            float m[8], vv[8], dc[8];
+            float m[8], lvv[8], dc[8];
             VecIO<bf16_t, 8>::load(mean + g, m);
-            VecIO<bf16_t, 8>::load(v + g, vv);
+            VecIO<bf16_t, 8>::load(logvar + g, lvv);
             VecIO<bf16_t, 8>::load(dcomp + g, dc);
             const float4 e0 = *reinterpret_cast<const float4*>(eps + g), e1 = *reinterpret_cast<const float4*>(eps + g + 4);
             const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float lv = bfr(logf(softplus_bf(vv[e])));
-                const float z = m[e] + ee[e] * __expf(0.5f * lv);
+                const float z = m[e] + ee[e] * __expf(0.5f * lvv[e]);
                 ds += dc[e] * (z - fr[e]);
                 if (!keep) dfa[e] += dc[e];
             }
@@ -196,9 +203,10 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
         for (int j = ty; j < d.HW; j += d.TY) {
             const long g = base + (long)j * d.LD;
             const float dsi = bfr(dl * w2b[j]);
-            float m[8], vv[8], dc[8], dm[8], dvv[8], dx[8];
+            float m[8], vv[8], lvv[8], dc[8], dm[8], dvv[8], dx[8];
             VecIO<bf16_t, 8>::load(mean + g, m);
             VecIO<bf16_t, 8>::load(v + g, vv);
+            VecIO<bf16_t, 8>::load(logvar + g, lvv);
             if (dcomp && keep) VecIO<bf16_t, 8>::load(dcomp + g, dc);
             else {
 #pragma unroll
@@ -214,12 +222,12 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float var = softplus_bf(vv[e]);
-                const float lv = bfr(logf(var));
+                const float lv = lvv[e];
                 const float elv = __expf(lv);
                 dm[e] = dc[e] + kscale * m[e] + dsi * w1r[e];
                 const float dlv = dc[e] * ee[e] * 0.5f * __expf(0.5f * lv) + kscale * 0.5f * (elv - 1.f) + dx[e];
-                const float dsp = vv[e] > 20.f ? 1.f : 1.f / (1.f + expf(-vv[e]));          // softplus'
-                dvv[e] = dlv / var * dsp;
+                const float dsp = vv[e] > 20.f ? 1.f : __builtin_amdgcn_rcpf(1.f + __expf(-vv[e]));          // softplus'
+                dvv[e] = dlv * __builtin_amdgcn_rcpf(var) * dsp;
                 dw1[e] += m[e] * dsi;
             }
             VecIO<bf16_t, 8>::store(dmean + g, dm);
@@ -292,23 +300,23 @@ extern "C" int vvae_encoder_head_fwd(const void* mean, const void* v, const floa
     return 0;
 }
 
-// dcomp bf16 (B, T, HW, LD) or NULL; dsel fp32 (B*T) or NULL; gkl fp32 or NULL: the gradient of kl_frame[b][t] at gkl[b * gkl_pitch_b + t * gkl_pitch_t]
+// logvar: the forward's output.  dcomp bf16 (B, T, HW, LD) or NULL; dsel fp32 (B*T) or NULL; gkl fp32 or NULL: the gradient of kl_frame[b][t] at gkl[b * gkl_pitch_b + t * gkl_pitch_t]
 // (pitches (1, 0): one gradient per sample, as the loss tail hands it over); dlv_ext bf16 (B, T, HW, LD) or NULL (a gradient arriving at logvar from elsewhere).
 // -> dmean, dv bf16 (B, T, HW, LD); part1 (B*T, LD) = dW1, part2 (B*T, HW) = dW2, part3 (B*T, LD) = d fill, partb (2, B*T, 4) = [db1 0 0 0] rows then
 // [db2 0 0 0] rows: one partial row per frame each, to be summed over rows by the caller.
-extern "C" int vvae_encoder_head_bwd(const void* mean, const void* v, const float* eps, const float* mask, long mask_pitch, const float* fill,
+extern "C" int vvae_encoder_head_bwd(const void* mean, const void* v, const void* logvar, const float* eps, const float* mask, long mask_pitch, const float* fill,
                                      const float* w1, const float* w2, const float* y, const float* s1, const float* sel, const void* dcomp,
                                      const float* dsel, const float* gkl, long gkl_pitch_b, long gkl_pitch_t, const void* dlv_ext, void* dmean, void* dv,
                                      float* part1, float* part2, float* part3, float* partb, int B, int T, int HW, int LD, void* stream)
 {
     EhDims d; int threads;
-    if (!mean || !v || !eps || !mask || !fill || !w1 || !w2 || !y || !s1 || !sel || !dmean || !dv || !part1 || !part2 || !part3 || !partb ||
+    if (!mean || !v || !logvar || !eps || !mask || !fill || !w1 || !w2 || !y || !s1 || !sel || !dmean || !dv || !part1 || !part2 || !part3 || !partb ||
         !eh_dims(B, T, HW, LD, mask_pitch, d, threads) || !vvae_encoder_head_ok(B, T, HW, LD) ||
-        ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)eps | (uintptr_t)dcomp | (uintptr_t)dlv_ext | (uintptr_t)dmean | (uintptr_t)dv) % 16)
+        ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)logvar | (uintptr_t)eps | (uintptr_t)dcomp | (uintptr_t)dlv_ext | (uintptr_t)dmean | (uintptr_t)dv) % 16)
         return VVAE_ERR_BAD_ARG;
     const size_t lds = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
-    hipLaunchKernelGGL(encoder_head_bwd_kernel, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v, eps,
-                       mask, fill, w1, w2, y, s1, sel, (const bf16_t*)dcomp, dsel, gkl, gkl_pitch_b, gkl_pitch_t, (const bf16_t*)dlv_ext, (bf16_t*)dmean,
+    hipLaunchKernelGGL(encoder_head_bwd_kernel, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
+                       (const bf16_t*)logvar, eps, mask, fill, w1, w2, y, s1, sel, (const bf16_t*)dcomp, dsel, gkl, gkl_pitch_b, gkl_pitch_t, (const bf16_t*)dlv_ext, (bf16_t*)dmean,
                        (bf16_t*)dv, part1, part2, part3, partb, d);
     VVAE_LAUNCH_CHECK();
     return 0;

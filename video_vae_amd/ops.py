@@ -1351,14 +1351,14 @@ class _EncoderHead(torch.autograd.Function):
         check(lib().vvae_encoder_head_fwd(_p(mean), _p(v), _p(w1f), _p(b1f), _p(w2f), _p(b2f), _p(u), _p(eps), _p(mask_bt), mp,
                                           _p(ff), _p(logvar), _p(comp), _p(sel), _p(y), _p(s1), _p(kl), b, t, hw, ld, _stream()),
               "vvae_encoder_head_fwd")
-        ctx.save_for_backward(mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, sel)
+        ctx.save_for_backward(mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, sel, logvar)
         ctx.params = (w1, b1, w2, b2, fill)
         ctx.set_materialize_grads(False)
         return logvar, comp, sel, kl
 
     @staticmethod
     def backward(ctx, dlv, dcomp, dsel, gkl):
-        mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, sel = ctx.saved_tensors
+        mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, sel, logvar = ctx.saved_tensors
         w1, b1, w2, b2, fill = ctx.params
         b, t, hw, ld = mean.shape
         dev = mean.device
@@ -1379,7 +1379,7 @@ class _EncoderHead(torch.autograd.Function):
         p1, p2, p3 = part[:f * ld].view(f, ld), part[f * ld:f * (ld + hw)].view(f, hw), part[f * (ld + hw):f * (2 * ld + hw)].view(f, ld)
         pb = part[f * (2 * ld + hw):].view(2, f, 4)
         mp = mask_bt.stride(0) if mask_bt.shape[0] > 1 else 0
-        check(lib().vvae_encoder_head_bwd(_p(mean), _p(v), _p(eps), _p(mask_bt), mp, _p(ff), _p(w1f), _p(w2f), _p(y), _p(s1), _p(sel),
+        check(lib().vvae_encoder_head_bwd(_p(mean), _p(v), _p(logvar), _p(eps), _p(mask_bt), mp, _p(ff), _p(w1f), _p(w2f), _p(y), _p(s1), _p(sel),
                                           _p(dcomp), _p(dsel), _p(gkl), gb, gt, _p(dlv), _p(dmean), _p(dv), _p(p1), _p(p2), _p(p3), _p(pb), b, t, hw,
                                           ld, _stream()), "vvae_encoder_head_bwd")
         dw1, _ = fold_partials(p1, w1, None, ld)
