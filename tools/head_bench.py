@@ -2,9 +2,10 @@
 
     python tools/head_bench.py [iters]
 """
+import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from video_vae_amd import ops
