@@ -275,7 +275,7 @@ int vvae_spatial_attn_bwd(const void* qkv, int ld, const void* out, int ldo, con
  *      bwd writes per-workgroup partials part (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy]. ---- */
 int vvae_layernorm_supported(int C, int dtype);
 int vvae_layernorm_bwd_blocks(long rows, int C, int dtype);
-int vvae_layernorm_config(int bwd_cap);   /* tuning hook: workgroups (= partial rows) of the backward kernel, default 512 (8 waves each) */
+int vvae_layernorm_config(int bwd_cap);   /* tuning hook: workgroups (= partial rows) of the backward kernel, default 384 (8 waves each) */
 int vvae_layernorm_fwd_mode(int late_stage);   /* test hook: 1 = round-1 forward variant (affine parked behind the first rows' loads, raw s_barrier) */
 int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                        const void* addend, void* xsum, long rows, int C, int inner, long outer_pitch, long inner_pitch, float eps,

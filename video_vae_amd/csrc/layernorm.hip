@@ -244,7 +244,9 @@ __global__ __launch_bounds__(64 * LN_BW) void layernorm_bwd_kernel(const T_* __r
     }
 }
 
-int g_ln_bwd_cap = 512;
+int g_ln_bwd_cap = 384;      // workgroups (= partial dgamma / dbeta rows) of the backward kernel.  Every row is 6 KB written here and read again by the grouped fold:
+                             // 84 launches x 512 rows were 264 MB each way per step.  Whole step (tools/ab_hook.py, 5 alternating rounds): 256 -> 34.05 ms, 384 -> 33.96,
+                             // 512 -> 34.03, 1024 -> 34.31
 int g_ln_fwd_late = 0;        // forward kernel: 1 = stage the affine behind the first rows' loads (LDS-only wait + raw barrier)
 
 inline int ln_blocks(long rows, int lpr, int cap = 0)
@@ -379,7 +381,7 @@ extern "C" int vvae_layernorm_bwd(const void* x, const void* dy, const float* ga
 // Tuning hook: workgroups (= partial rows) of the backward kernel.
 extern "C" int vvae_layernorm_config(int bwd_cap)
 {
-    g_ln_bwd_cap = bwd_cap > 0 ? bwd_cap : 512;
+    g_ln_bwd_cap = bwd_cap > 0 ? bwd_cap : 384;
     return 0;
 }
 
