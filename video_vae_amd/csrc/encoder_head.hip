@@ -60,7 +60,7 @@ __device__ __forceinline__ float seq_len(const float* __restrict__ mrow, int T)
     return fmaxf(s, 1.0f);
 }
 
-// LDS: w2b[HW] | s1s[HW] | pt[HW * CG] | red[16] | slot[4]
+// LDS: w2b[HW] | pt[HW * CG] | red[16] | slot[4]
 __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
     const bf16_t* __restrict__ mean, const bf16_t* __restrict__ v, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u, const float* __restrict__ eps,
@@ -69,8 +69,7 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w2b = lds;
-    float* s1s = w2b + d.HW;
-    float* pt = s1s + d.HW;
+    float* pt = w2b + d.HW;
     float* red = pt + (long)d.HW * d.CG;
     float* slot = red + 16;
     const int f = blockIdx.x, b = f / d.T, t = f % d.T;
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
         float a = 0.f;
         for (int c = 0; c < d.CG; ++c) a += pt[j * d.CG + c];
         const float s = bfr(a + b1b);
-        s1s[j] = s;
         s1_out[(long)f * d.HW + j] = s;
         acc += s * w2b[j];
     }
@@ -277,7 +275,7 @@ extern "C" int vvae_encoder_head_ok(int B, int T, int HW, int LD)
 {
     EhDims d; int th;
     if (!eh_dims(B, T, HW, LD, T, d, th)) return 0;
-    const size_t fwd = ((size_t)2 * HW + (size_t)HW * d.CG + 20) * 4, bwd = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
+    const size_t fwd = ((size_t)HW + (size_t)HW * d.CG + 20) * 4, bwd = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
     return fwd <= 64 * 1024 && bwd <= 64 * 1024;
 }
 
@@ -293,7 +291,7 @@ extern "C" int vvae_encoder_head_fwd(const void* mean, const void* v, const floa
     if (!mean || !v || !w1 || !b1 || !w2 || !b2 || !u || !eps || !mask || !fill || !logvar || !comp || !sel || !y || !s1 || !kl_frame ||
         !eh_dims(B, T, HW, LD, mask_pitch, d, threads) || !vvae_encoder_head_ok(B, T, HW, LD) ||
         ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)eps | (uintptr_t)logvar | (uintptr_t)comp) % 16) return VVAE_ERR_BAD_ARG;
-    const size_t lds = ((size_t)2 * HW + (size_t)HW * d.CG + 20) * 4;
+    const size_t lds = ((size_t)HW + (size_t)HW * d.CG + 20) * 4;
     hipLaunchKernelGGL(encoder_head_fwd_kernel, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
                        w1, b1, w2, b2, u, eps, mask, fill, (bf16_t*)logvar, (bf16_t*)comp, sel, y, s1, kl_frame, d);
     VVAE_LAUNCH_CHECK();
