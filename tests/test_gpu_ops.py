@@ -647,11 +647,12 @@ def test_temporal_attention_strided_layout(dev, dtype):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 1000), (768, 1536, 4096), (512, 128, 33), (256, 256, 32), (512, 768, 2080),
-                                   (768, 512, 16384), (256, 512, 96)])
+                                   (768, 512, 16384), (256, 512, 96), (768, 96, 16384), (96, 768, 16384), (96, 96, 500), (8, 200, 77), (136, 24, 64)])
 @pytest.mark.parametrize("big", [True, False])
 def test_gemm_tn_weight_gradient(dev, m, n, k, big):
     """dW = X^T dY and db = colsum(dY) from the split-K HIP kernels vs fp32 torch on the same bf16 operands.
-    big=True: 256 x 256 tiles (LDS-DMA ring, staggered wave halves) where M, N, K allow; False: the 128 x 128 kernel."""
+    big=True: 256 x 256 tiles (LDS-DMA ring, staggered wave halves) where M, N, K allow; False: the 128 x 128 kernel.  M, N that are
+    multiples of 8 but not of 128 (the 96-wide latent heads) run on edge tiles of the 128 x 128 kernel: zero columns in, guarded stores out."""
     from video_vae_amd._lib import lib
     ops = _ops()
     a = rnd((k, m), 80).to(dev, torch.bfloat16)

@@ -11,7 +11,9 @@
 //   * 128x128 tile per workgroup, 4 waves x (64x64 = 4x4 MFMA tiles), 32-token k-steps, register-staged double-buffered LDS
 //     with ONE barrier per k-step (global loads of step i+1 are in flight while step i computes);
 //   * split-K partial tiles go to an fp32 slab, summed by a second kernel in fixed order: deterministic, no float atomics;
-//   * the bias gradient rides along as an all-ones A fragment in the m-block-0 workgroups (no separate column-sum pass).
+//   * the bias gradient rides along as an all-ones A fragment in the m-block-0 workgroups (no separate column-sum pass);
+//   * M, N need only be multiples of 8 (round 3): the columns of a tile past M / N are staged as zeros and not stored -- the 96-wide latent
+//     heads (768 x 96, 96 x 768) took a batched library product + a framework sum + a two-kernel column sum each (4 launches, ~39 us).
 #include "common.hpp"
 
 namespace tn256 {            // gemm_tn256.hip: 256 x 256 tiles for M, N multiples of 256
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
     const bf16_t* ga = A + (long)m0 + part * 8;
     const bf16_t* gb = B + (long)n0 + part * 8;
     const int lds_item = tok0 * PITCH + part * 16;
+    const bool a_in = m0 + part * 8 < d.M, b_in = n0 + part * 8 < d.N;      // edge tiles (M, N multiples of 8, not of 128): zero columns
     // transposed-read lane offset: lane (g = l>>4, q = (l>>2)&3, p = l&3) -> token row 4g+q, channels 4p..4p+3
     const int loff = (4 * (lane >> 4) + ((lane >> 2) & 3)) * PITCH + 8 * (lane & 3);
     const bool do_bias = slab_db != nullptr && blockIdx.x == 0 && wm == 0;
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
             const int kt = k + tok0 + 16 * i;
             ra[i] = make_uint4(0, 0, 0, 0); rb[i] = make_uint4(0, 0, 0, 0);
             if (kt < k_end) {
-                ra[i] = *reinterpret_cast<const uint4*>(ga + (long)kt * d.lda);
-                rb[i] = *reinterpret_cast<const uint4*>(gb + (long)kt * d.ldb);
+                if (a_in) ra[i] = *reinterpret_cast<const uint4*>(ga + (long)kt * d.lda);
+                if (b_in) rb[i] = *reinterpret_cast<const uint4*>(gb + (long)kt * d.ldb);
             }
         }
     };
@@ -119,11 +122,16 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                out[(long)(m0 + wm * 64 + i * 16 + rg * 4 + e) * d.N + n0 + wn * 64 + j * 16 + col] = acc[i][j][e];
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * 64 + i * 16 + rg * 4 + e, n = n0 + wn * 64 + j * 16 + col;
+                if (m < d.M && n < d.N) out[(long)m * d.N + n] = acc[i][j][e];
+            }
     if (do_bias && rg == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) slab_db[(long)sp * d.N + n0 + wn * 64 + j * 16 + col] = accb[j][0];
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + col;
+            if (n < d.N) slab_db[(long)sp * d.N + n] = accb[j][0];
+        }
     }
 }
 
@@ -152,7 +160,7 @@ bool g_tn_big = true;
 
 inline int pick_splits(int M, int N, int K)
 {
-    const int tiles = (M / BM) * (N / BN);
+    const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
     int s = (640 + tiles - 1) / tiles;                 // ~2.5 workgroups per CU over the chip
     const int max_s = (K + 4 * KS - 1) / (4 * KS);     // at least 4 k-steps per split
     if (s > max_s) s = max_s;
@@ -165,13 +173,13 @@ inline int pick_splits(int M, int N, int K)
 // 1 if vvae_gemm_tn_bf16 takes this shape.
 extern "C" int vvae_gemm_tn_supported(int M, int N, int K, int lda, int ldb)
 {
-    return (M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N) ? 1 : 0;
+    return (M > 0 && N > 0 && K > 0 && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N) ? 1 : 0;
 }
 
 // Scratch bytes for vvae_gemm_tn_bf16 (split-K slabs).
 extern "C" size_t vvae_gemm_tn_ws_bytes(int M, int N, int K)
 {
-    if (M % BM || N % BN) return 0;
+    if (M <= 0 || N <= 0 || M % 8 || N % 8) return 0;
     const int s = (g_tn_big && tn256::supported(M, N, K, M, N)) ? tn256::pick_splits(M, N, K) : pick_splits(M, N, K);
     return ((size_t)s * M * N + (size_t)s * N) * sizeof(float);
 }
@@ -203,7 +211,7 @@ extern "C" int vvae_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb,
     GemmDims d{M, N, K, lda, ldb, klen};
     float* slab = (float*)ws;
     float* slab_db = db ? slab + (size_t)splits * M * N : nullptr;
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(M / BM, N / BN, used), dim3(256), LDS_BYTES, s, (const bf16_t*)A, (const bf16_t*)B, slab,
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(ceil_div(M, BM), ceil_div(N, BN), used), dim3(256), LDS_BYTES, s, (const bf16_t*)A, (const bf16_t*)B, slab,
                        slab_db, d);
     VVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(ceil_div(MN / 4 + N, 256)), dim3(256), 0, s, slab, slab_db, C, db, MN, N, used);
