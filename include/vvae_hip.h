@@ -127,10 +127,11 @@ int vvae_transpose_grouped_bf16(const void* const* src, void* const* dst, const 
 
 /* The scalar end of the recon + KL loss, value and gradients in one launch (reference train/legacy/training_loop_adversarial.py:100-124:
  * selection density against 1 / max_compression_rate with magnified negatives, MSE + gamma1 selection + gamma2 KL).
- * mse_ps fp32 [B]; kl_ps fp32 (B, kl_cols): the per-sample KL term as kl_cols >= 1 partial sums (summed here in index order: the per-frame
- * partials of vvae_encoder_head_fwd, or kl_cols = 1); selection, mask fp32 (B, T) contiguous.  out fp32 [5] = loss, MSE, selection_loss,
- * kl_loss, mean kept-frame density.  grads fp32 [2 B + B T] = d loss / d mse_ps | d loss / d (per-sample KL) | d loss / d selection.  B <= 1024. */
-int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, int kl_cols, const float* selection, const float* mask, int B, int T,
+ * mse_ps fp32 (B, mse_cols), kl_ps fp32 (B, kl_cols): the per-sample MSE / KL terms as >= 1 partial sums each (summed here in index order: the
+ * per-workgroup partials of vvae_masked_mse_mae_fwd, the per-frame partials of vvae_encoder_head_fwd, or one column); selection, mask fp32 (B, T)
+ * contiguous.  out fp32 [5] = loss, MSE, selection_loss, kl_loss, mean kept-frame density.  grads fp32 [2 B + B T] = d loss / d (per-sample MSE) |
+ * d loss / d (per-sample KL) | d loss / d selection.  B <= 1024. */
+int vvae_loss_tail_plain(const float* mse_ps, int mse_cols, const float* kl_ps, int kl_cols, const float* selection, const float* mask, int B, int T,
                          float max_compression_rate, float magnify_negatives_rate, float gamma1, float gamma2, float* out,
                          float* grads, void* stream);
 
@@ -292,7 +293,8 @@ int vvae_reparam_kl_fwd(const void* mean, const void* logvar, const float* eps, 
 int vvae_reparam_kl_bwd(const void* mean, const void* logvar, const float* eps, const float* mask, const float* dz,
                         const float* gkl, void* dmean, void* dlogvar, int B, int T, long per, int dtype, void* stream);
 
-/* ---- masked MSE / MAE: train/rl_nonadversarial.py:114-121.  video sample = b / video_div (pair doubling). ---- */
+/* ---- masked MSE / MAE: train/rl_nonadversarial.py:114-121.  video sample = b / video_div (pair doubling).  mse = mae = NULL: no fold, the
+ *      caller reads part = [mse (B, chunks) | mae (B, chunks)], chunks = vvae_loss_part_floats / (2 B). ---- */
 int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* mask, float* mse, float* mae,
                             float* part, int B, int T, long P, int video_div, int dtype, void* stream);
 int vvae_masked_mse_mae_bwd(const void* video, const void* recon, const float* mask, const float* gmse, const float* gmae,

@@ -1398,6 +1398,20 @@ def test_plain_loss_tail_sums_kl_partials(dev):
     assert_close(aux2[2], aux1[2].detach(), rtol=1e-6, atol=1e-7, what="kl_loss")
     assert klp.grad.shape == (b, k)
     assert torch.equal(klp.grad, kls.grad[:, None].expand(b, k))
+    # the MSE term likewise: the per-workgroup partials of ops.masked_mse_mae(partials=True) against their row sums, through to d recon
+    bf = torch.bfloat16
+    video = torch.rand(b, t, 8, 8, 3, generator=g).to(dev, bf)
+    outs = []
+    for partials in (True, False):
+        recon = torch.rand(b, t, 8, 8, 3, generator=torch.Generator().manual_seed(11)).to(dev, bf).requires_grad_(True)
+        mse, mae = ops.masked_mse_mae(video, recon, mask, 1, partials)
+        assert mse.dim() == (2 if partials else 1)
+        loss, _ = ops.plain_loss_tail(mse, kls.detach(), sel, mask, HPARAMS)
+        loss.backward()
+        outs.append((loss.detach(), mse.detach().reshape(b, -1).sum(1), recon.grad))
+    assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-7, what="loss from MSE partials")
+    assert_close(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-7, what="per-sample MSE")
+    assert torch.equal(outs[0][2], outs[1][2])
 
 
 def _heads_reference(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):

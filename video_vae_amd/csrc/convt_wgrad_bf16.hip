@@ -152,11 +152,44 @@ __global__ __launch_bounds__(256) void convt_wgrad_bf16_kernel(const bf16_t* __r
     }
 }
 
-// db[co] = sum over the four taps of the folded bias sums
-__global__ __launch_bounds__(64) void convt_db_fold_kernel(const float* __restrict__ t4, int cout, float* __restrict__ db)
+// Fold the per-workgroup slabs in fixed order: column c < nw -> dw[c]; the 4 x cout bias columns behind them (one run per tap) -> db[co] as
+// ((t0 + t1) + (t2 + t3)) of the four folded taps -- one launch (round 3; the taps were folded by a second 5 us launch).
+// Block = 32 outputs x 8 row lanes, 8 loads in flight per thread (the slabs are L2-resident: latency is what the fold pays for).
+__global__ __launch_bounds__(256) void cw_reduce_kernel(const float* __restrict__ part, int rows, long stride, int nw, int cout,
+                                                        float* __restrict__ dw, float* __restrict__ db)
 {
-    const int co = blockIdx.x * 64 + threadIdx.x;
-    if (co < cout) db[co] = (t4[co] + t4[cout + co]) + (t4[2 * cout + co] + t4[3 * cout + co]);
+    __shared__ float red[8][32][4];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const bool is_w = c < nw, is_b = !is_w && db && c < nw + cout;
+    const int ntap = is_b ? 4 : 1;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (is_w || is_b) {
+        for (int t = 0; t < ntap; ++t) {
+            const long col = is_w ? c : nw + (long)t * cout + (c - nw);
+            for (int r0 = rl; r0 < rows; r0 += 8 * 8) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = r0 + 8 * i;
+                    v[i] = r < rows ? part[(long)r * stride + col] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[t] += v[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[rl][cl][t] = s[t];
+    __syncthreads();
+    if (rl == 0 && (is_w || is_b)) {
+        float tot[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            tot[t] = ((red[0][cl][t] + red[1][cl][t]) + (red[2][cl][t] + red[3][cl][t])) + ((red[4][cl][t] + red[5][cl][t]) + (red[6][cl][t] + red[7][cl][t]));
+        if (is_w) dw[c] = tot[0];
+        else db[c - nw] = (tot[0] + tot[1]) + (tot[2] + tot[3]);
+    }
 }
 
 inline bool cw_shape(int Cin, int Cout) { return (Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 32) || (Cin == 32 && Cout == 16); }
@@ -186,16 +219,10 @@ int launch_cw(const void* x, const void* dy, float* dw, float* db, float* slab, 
     }
     hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy, slab, d);
     VVAE_LAUNCH_CHECK();
-    // fold the slabs in fixed order: weight columns straight into dw, the 4 x COUT bias columns into the scratch row behind the slabs
+    // fold the slabs in fixed order: weight columns straight into dw, the 4 x COUT bias columns (one run per tap) into db
     const int nw = 4 * CIN * COUT;
-    float* t4 = slab + (long)nblk * C::SLAB;
-    hipLaunchKernelGGL(vvae_reduce_rows_kernel, dim3(ceil_div(C::SLAB, 32)), dim3(256), 0, s, slab, nblk, (long)C::SLAB, C::SLAB, dw, nw,
-                       db ? t4 : nullptr);
+    hipLaunchKernelGGL(cw_reduce_kernel, dim3(ceil_div(nw + COUT, 32)), dim3(256), 0, s, slab, nblk, (long)C::SLAB, nw, COUT, dw, db);
     VVAE_LAUNCH_CHECK();
-    if (db) {
-        hipLaunchKernelGGL(convt_db_fold_kernel, dim3(ceil_div(COUT, 64)), dim3(64), 0, s, t4, COUT, db);
-        VVAE_LAUNCH_CHECK();
-    }
     return 0;
 }
 

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void sum_chunks2_kernel(const float* __restrict
 // out[5] = loss, MSE, selection_loss, kl_loss, mean density.   grads = [d loss / d mse_b (B) | d / d kl_b (B) | d / d sel_bt (B T)].
 // One workgroup; sample b is thread b's (strided), the means are summed by thread 0 in index order: deterministic.
 constexpr int TAIL_MAX_B = 1024;
-__global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __restrict__ mse, const float* __restrict__ kl, int kl_cols,
+__global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __restrict__ mse, int mse_cols, const float* __restrict__ kl, int kl_cols,
                                                              const float* __restrict__ sel, const float* __restrict__ mask, int B, int T,
                                                              float inv_max_rate, float magnify, float gamma1, float gamma2,
                                                              float* __restrict__ out, float* __restrict__ grads)
@@ -215,9 +215,10 @@ __global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __res
     if (threadIdx.x == 0) {
         float a = 0.f, k = 0.f, q = 0.f, dn = 0.f;
         for (int b = 0; b < B; ++b) {
-            float kb = 0.f;                                          // the sample's KL term: its partial sums in index order
+            float kb = 0.f, mb = 0.f;                                // the sample's KL / MSE term: its partial sums in index order
             for (int c = 0; c < kl_cols; ++c) kb += kl[b * kl_cols + c];
-            a += mse[b]; k += kb; q += sq[b]; dn += dens[b];
+            for (int c = 0; c < mse_cols; ++c) mb += mse[b * mse_cols + c];
+            a += mb; k += kb; q += sq[b]; dn += dens[b];
         }
         a *= invB; k *= invB; q *= invB; dn *= invB;
         out[0] = a + gamma1 * q + gamma2 * k;
@@ -341,12 +342,13 @@ extern "C" int vvae_reparam_kl_bwd(const void* mean, const void* logvar, const f
     return 0;
 }
 
-// video (B/video_div, T, P), recon (B, T, P) in `dtype`; mask fp32 (B,T); mse, mae fp32 [B] overwritten.
-// part: vvae_loss_part_floats(B, T * P) floats of scratch.
+// video (B/video_div, T, P), recon (B, T, P) in `dtype`; mask fp32 (B,T); mse, mae fp32 [B] overwritten -- or both NULL: the caller takes
+// the partial sums themselves, part = [mse (B, chunks) | mae (B, chunks)] with chunks = vvae_loss_part_floats / (2 B) (vvae_loss_tail_plain
+// adds a sample's partials up itself).  part: vvae_loss_part_floats(B, T * P) floats of scratch.
 extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, const float* mask, float* mse_out, float* mae_out,
                                        float* part, int B, int T, long P, int video_div, int dtype, void* stream)
 {
-    if (!video || !recon || !mask || !mse_out || !mae_out || !part || B <= 0 || T <= 0 || P <= 0 || video_div <= 0) return VVAE_ERR_BAD_ARG;
+    if (!video || !recon || !mask || (!mse_out) != (!mae_out) || !part || B <= 0 || T <= 0 || P <= 0 || video_div <= 0) return VVAE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)T * P;
     const int epb = pick_epb(M, B);
@@ -361,20 +363,20 @@ extern "C" int vvae_masked_mse_mae_fwd(const void* video, const void* recon, con
         if (al && M % 8 == 0) hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
         else hipLaunchKernelGGL((masked_mse_mae_fwd_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)video, (const bf16_t*)recon, mask, mse, mae, T, P, video_div, epb);
     } else return VVAE_ERR_BAD_ARG;
-    hipLaunchKernelGGL(sum_chunks2_kernel, dim3(2 * B), dim3(64), 0, s, part, (int)grid.x, mse_out, mae_out, B);
+    if (mse_out) hipLaunchKernelGGL(sum_chunks2_kernel, dim3(2 * B), dim3(64), 0, s, part, (int)grid.x, mse_out, mae_out, B);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
 
-// mse_ps fp32 [B], kl_ps fp32 (B, kl_cols) partial sums of the per-sample KL; selection, mask fp32 (B, T) contiguous.  out fp32 [5],
-// grads fp32 [2 B + B T] (see loss_tail_plain_kernel).
-extern "C" int vvae_loss_tail_plain(const float* mse_ps, const float* kl_ps, int kl_cols, const float* selection, const float* mask, int B, int T,
+// mse_ps fp32 (B, mse_cols), kl_ps fp32 (B, kl_cols): partial sums of the per-sample MSE / KL terms; selection, mask fp32 (B, T) contiguous.
+// out fp32 [5], grads fp32 [2 B + B T] (see loss_tail_plain_kernel).
+extern "C" int vvae_loss_tail_plain(const float* mse_ps, int mse_cols, const float* kl_ps, int kl_cols, const float* selection, const float* mask, int B, int T,
                                     float max_compression_rate, float magnify_negatives_rate, float gamma1, float gamma2, float* out,
                                     float* grads, void* stream)
 {
-    if (!mse_ps || !kl_ps || kl_cols <= 0 || !selection || !mask || !out || !grads || B <= 0 || B > TAIL_MAX_B || T <= 0 || !(max_compression_rate > 0.f))
+    if (!mse_ps || mse_cols <= 0 || !kl_ps || kl_cols <= 0 || !selection || !mask || !out || !grads || B <= 0 || B > TAIL_MAX_B || T <= 0 || !(max_compression_rate > 0.f))
         return VVAE_ERR_BAD_ARG;
-    hipLaunchKernelGGL(loss_tail_plain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_ps, kl_ps, kl_cols, selection, mask, B, T,
+    hipLaunchKernelGGL(loss_tail_plain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_ps, mse_cols, kl_ps, kl_cols, selection, mask, B, T,
                        1.f / max_compression_rate, magnify_negatives_rate, gamma1, gamma2, out, grads);
     VVAE_LAUNCH_CHECK();
     return 0;

@@ -111,6 +111,11 @@ class GraphedTrainStep:
         self.debug_dot = debug_dot           # path: write the captured graph (hipGraphDebugDotPrint) there, for tools/
         self._capture(warmup)
 
+    @staticmethod
+    def _unit(loss):
+        """The root gradient as a constant tensor (ops.unit_grad) where the loss is an fp32 scalar: no ones_like fill inside the graph."""
+        return ops.unit_grad(loss) if (loss.dtype == torch.float32 and loss.dim() == 0) else None
+
     def _loss(self):
         emask = L.compact_mask(self.mask)                # a view: the (b*hw, 1, 1, t) expansion would be two launches of every replay
         if self.rl:
@@ -144,7 +149,7 @@ class GraphedTrainStep:
         opt.hooks_active = False
         params = [opt.params[i] for i in self.stage_idx[0]]
         with ops.deferred_wgrad(opt):
-            grads = torch.autograd.grad(loss, params + self._cuts[0], allow_unused=True)
+            grads = torch.autograd.grad(loss, params + self._cuts[0], grad_outputs=self._unit(loss), allow_unused=True)
         self._gcut = list(grads[len(params):])
         opt.land_subset(self.stage_idx[0], grads[:len(params)])
         return loss.detach(), {k: v.detach() for k, v in aux.items() if k != "reconstruction"}
@@ -190,7 +195,7 @@ class GraphedTrainStep:
         self.opt.external = set()
         self.opt.hooks_active = False                    # gradients arrive through land_all below, not through the hooks
         with ops.deferred_wgrad(self.opt):               # dense weight gradients: parked, then grouped launches into the flat buffer
-            grads = torch.autograd.grad(loss, self.opt.params, allow_unused=True)
+            grads = torch.autograd.grad(loss, self.opt.params, grad_outputs=self._unit(loss), allow_unused=True)
         self.opt.land_all(grads)
         return loss.detach(), {k: v.detach() for k, v in aux.items() if k != "reconstruction"}
 

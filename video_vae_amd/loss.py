@@ -101,7 +101,8 @@ def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn
 def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
     reconstruction, _comp, selection, logvar, mean = model(video, mask, rngs, train=train)
     om = original_mask.to(torch.float32)
-    mse_ps, _ = ops.masked_mse_mae(video, reconstruction, om, video_div=1)
+    # on the GPU the per-workgroup partial sums go straight to the loss tail, which adds a sample's up itself (no fold launch)
+    mse_ps, _ = ops.masked_mse_mae(video, reconstruction, om, video_div=1, partials=reconstruction.is_cuda)
     kl_ps = kl_from_model(model, mean, logvar, om)
     if ops.plain_loss_tail_ok(mse_ps, kl_ps, selection, om):
         # GPU: the per-sample algebra below (and its backward) as ONE launch instead of ~45 framework kernels of a few bytes each
@@ -110,6 +111,8 @@ def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):
                       "kept_frame_density": density}
     if kl_ps.dim() == 2:                                 # per-frame partial sums (ops.encoder_head)
         kl_ps = kl_ps.sum(1)
+    if mse_ps.dim() == 2:
+        mse_ps = mse_ps.sum(1)
     MSE = mse_ps.mean()
     sequence_lengths = torch.clamp(reduce(om, "b time -> b 1", "sum"), min=1.0)
     kl_and_selection_mask = rearrange(om, "b time -> b time 1 1")
@@ -141,7 +144,7 @@ def train_step(model, optimizer, video, mask, hparams, hw, rngs, perceptual_loss
     else:
         loss, aux = loss_fn_plain(model, video, emask, original_mask, rngs, hparams)
     with ops.deferred_wgrad(optimizer):
-        loss.backward()
+        loss.backward(gradient=ops.unit_grad(loss) if (loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0) else None)
     optimizer.update()
     # detached: a caller that keeps the aux of step i while step i + 1 is captured as a hipGraph must not keep step i's autograd graph
     # (and with it AccumulateGrad nodes pinned to this stream) alive -- graph.GraphedTrainStep captures on a stream of its own

@@ -1243,41 +1243,63 @@ def reparameterise_kl(mean, logvar, eps, mask_bt):
 # --------------------------------------------------------------------------------------------- masked MSE / MAE
 class _MaskedMseMae(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, video, recon, mask, video_div):
+    def forward(ctx, video, recon, mask, video_div, partials=False):
         recon = recon.contiguous()
         video = video.to(recon.dtype).contiguous()
         mask = mask.to(torch.float32).contiguous()
         b, t = recon.shape[0], recon.shape[1]
         p = recon.numel() // (b * t)
         assert video.shape[0] * video_div == b and video.shape[1:] == recon.shape[1:]
-        mse = torch.empty((b,), dtype=torch.float32, device=recon.device)
-        mae = torch.empty((b,), dtype=torch.float32, device=recon.device)
         part = _loss_part(b, t * p, recon.device)
+        if partials:                                     # (b, chunks) per-workgroup partial sums: the loss tail adds them up, no fold launch
+            mse = mae = None
+        else:
+            mse = torch.empty((b,), dtype=torch.float32, device=recon.device)
+            mae = torch.empty((b,), dtype=torch.float32, device=recon.device)
         check(lib().vvae_masked_mse_mae_fwd(_p(video), _p(recon), _p(mask), _p(mse), _p(mae), _p(part), b, t, p, video_div,
                                             _dt(recon), _stream()), "vvae_masked_mse_mae_fwd")
         ctx.save_for_backward(video, recon, mask)
         ctx.video_div = video_div
         ctx.set_materialize_grads(False)                 # an unused output's gradient stays None (the kernel takes NULL), no zero fill
+        if partials:
+            chunks = part.numel() // (2 * b)
+            return part[:b * chunks].view(b, chunks), part[b * chunks:].view(b, chunks)
         return mse, mae
 
     @staticmethod
     def backward(ctx, gmse, gmae):
         video, recon, mask = ctx.saved_tensors
         if gmse is None and gmae is None:
-            return None, None, None, None
+            return None, None, None, None, None
         b, t = recon.shape[0], recon.shape[1]
         p = recon.numel() // (b * t)
-        gmse = gmse.to(torch.float32).contiguous() if gmse is not None else None
-        gmae = gmae.to(torch.float32).contiguous() if gmae is not None else None
+        # partial-sum outputs: every partial of a sample carries the sample's gradient (a stride-0 expansion): column 0 is it
+        gmse = (gmse[:, 0] if gmse.dim() == 2 else gmse).to(torch.float32).contiguous() if gmse is not None else None
+        gmae = (gmae[:, 0] if gmae.dim() == 2 else gmae).to(torch.float32).contiguous() if gmae is not None else None
         dr = torch.empty_like(recon)
         check(lib().vvae_masked_mse_mae_bwd(_p(video), _p(recon), _p(mask), _p(gmse), _p(gmae), _p(dr), b, t, p, ctx.video_div,
                                             _dt(recon), _stream()), "vvae_masked_mse_mae_bwd")
-        return None, dr, None, None
+        return None, dr, None, None, None
 
 
-def masked_mse_mae(video, recon, mask_bt, video_div=1):
-    """Per-sample masked MSE and MAE (reference train/rl_nonadversarial.py:114-121); gradient flows to recon only."""
-    return _MaskedMseMae.apply(video, recon, mask_bt, video_div)
+def masked_mse_mae(video, recon, mask_bt, video_div=1, partials=False):
+    """Per-sample masked MSE and MAE (reference train/rl_nonadversarial.py:114-121); gradient flows to recon only.
+    ``partials``: return each as (b, chunks) partial sums instead (their row sums are the per-sample values; ops.plain_loss_tail takes them)."""
+    return _MaskedMseMae.apply(video, recon, mask_bt, video_div, partials)
+
+
+_UNIT_GRAD = {}
+
+
+def unit_grad(like):
+    """A cached fp32 scalar 1.0 on ``like``'s device: the root gradient of ``loss.backward`` / ``torch.autograd.grad(loss, ...)``.  Handing it
+    over explicitly (``gradient=`` / ``grad_outputs=``) spares the engine's ``ones_like`` fill launch, and a backward that recognises it by
+    its storage (_PlainLossTail) spares the multiplication by it: two ~5 us launches of every replayed step."""
+    key = (like.device.type, like.device.index)
+    t = _UNIT_GRAD.get(key)
+    if t is None:
+        t = _UNIT_GRAD[key] = torch.ones((), dtype=torch.float32, device=like.device)
+    return t
 
 
 class _PlainLossTail(torch.autograd.Function):
@@ -1290,11 +1312,12 @@ class _PlainLossTail(torch.autograd.Function):
         grads = torch.empty((2 * b + b * t,), dtype=torch.float32, device=mse_ps.device)
         sel = selection.reshape(b, t).to(torch.float32).contiguous()
         kl_cols = kl_ps.numel() // b                     # (b,) or (b, k) partial sums of the per-sample term (ops.encoder_head: one per frame)
-        check(lib().vvae_loss_tail_plain(_p(mse_ps.contiguous()), _p(kl_ps.contiguous()), kl_cols, _p(sel), _p(mask), b, t, float(max_rate),
+        mse_cols = mse_ps.numel() // b                   # likewise (ops.masked_mse_mae(partials=True): one per workgroup)
+        check(lib().vvae_loss_tail_plain(_p(mse_ps.contiguous()), mse_cols, _p(kl_ps.contiguous()), kl_cols, _p(sel), _p(mask), b, t, float(max_rate),
                                          float(magnify), float(gamma1), float(gamma2), _p(out), _p(grads), _stream()),
               "vvae_loss_tail_plain")
         ctx.save_for_backward(grads)
-        ctx.bt, ctx.sel_shape, ctx.sel_dtype, ctx.kl_shape = (b, t), selection.shape, selection.dtype, kl_ps.shape
+        ctx.bt, ctx.sel_shape, ctx.sel_dtype, ctx.kl_shape, ctx.mse_shape = (b, t), selection.shape, selection.dtype, kl_ps.shape, mse_ps.shape
         aux = out[1:]
         ctx.mark_non_differentiable(aux)
         ctx.set_materialize_grads(False)
@@ -1306,17 +1329,21 @@ class _PlainLossTail(torch.autograd.Function):
             return (None,) * 8
         (grads,) = ctx.saved_tensors
         b, t = ctx.bt
-        g = grads * go                                   # one launch for the three gradients
-        gkl = g[b:2 * b]
+        unit = _UNIT_GRAD.get((go.device.type, go.device.index))
+        # one launch for the three gradients -- none when the root gradient is the constant 1.0 of unit_grad (same storage)
+        g = grads if (unit is not None and go.data_ptr() == unit.data_ptr() and go.numel() == 1) else grads * go
+        gmse, gkl = g[:b], g[b:2 * b]
         if len(ctx.kl_shape) == 2:                       # every partial sum of a sample has the sample's gradient: a stride-0 view, no launch
             gkl = gkl.unsqueeze(1).expand(ctx.kl_shape)
-        return g[:b], gkl, g[2 * b:].view(ctx.sel_shape).to(ctx.sel_dtype), None, None, None, None, None
+        if len(ctx.mse_shape) == 2:
+            gmse = gmse.unsqueeze(1).expand(ctx.mse_shape)
+        return gmse, gkl, g[2 * b:].view(ctx.sel_shape).to(ctx.sel_dtype), None, None, None, None, None
 
 
 def plain_loss_tail_ok(mse_ps, kl_ps, selection, mask):
     return (mse_ps.is_cuda and mse_ps.dtype == torch.float32 and kl_ps.dtype == torch.float32 and mask.dtype == torch.float32
             and mask.dim() == 2 and mask.is_contiguous() and mask.shape[0] <= 1024 and selection.numel() == mask.numel()
-            and kl_ps.dim() in (1, 2) and kl_ps.shape[0] == mask.shape[0])
+            and kl_ps.dim() in (1, 2) and kl_ps.shape[0] == mask.shape[0] and mse_ps.dim() in (1, 2) and mse_ps.shape[0] == mask.shape[0])
 
 
 def plain_loss_tail(mse_ps, kl_ps, selection, mask, hparams):
