@@ -390,10 +390,12 @@ class PatchUnEmbedding(nn.Module):
         self.downsample = Linear(channels * upsample_rate, channels, rngs, dtype, param_dtype)
         self.linear = Linear(d, d, rngs, dtype, param_dtype)
 
-    def forward_padded(self, x):
+    def forward_padded(self, x, more_pads=None):
         """forward() for the decoder's bf16 GPU path: the features come back with their channels zero-padded to a multiple of 16
         (what the UNet's matrix-core kernels want), written by ONE strided copy (un-patchify + pad) instead of a rearrange copy
-        followed by a pad copy, and the 1x1x1 down-projection reads the same buffer through zero-padded weight rows."""
+        followed by a pad copy, and the 1x1x1 down-projection reads the same buffer through zero-padded weight rows.
+        ``more_pads`` = (tensors, sizes) (unet.UNet.pad_plan): padded in the same launch as the down-projection's rows; the result is then
+        (feat, coarse, padded tensors)."""
         p, u = self.patch_size, self.upsample_rate
         cu = self.downsample.kernel.shape[0]
         pad = (-cu) % 16
@@ -402,9 +404,10 @@ class PatchUnEmbedding(nn.Module):
         x = self.upsample(self.linear(x))
         feat = _UnpatchPad.apply(x, p, self.height // p, self.width // p, u, pad)
         ds = self.downsample
-        (kd,) = ops.pad_last2_group([ds.kernel], [(cu + pad, ds.kernel.shape[1])])      # zero rows for the pad channels, one launch each way
+        extra_t, extra_s = more_pads if more_pads is not None else ([], [])
+        kd, *extra = ops.pad_last2_group([ds.kernel] + list(extra_t), [(cu + pad, ds.kernel.shape[1])] + list(extra_s))   # one launch each way
         coarse = ops.conv3d(feat.to(ds.dtype), kd.view(1, 1, 1, *kd.shape), ds.bias)
-        return feat, coarse
+        return (feat, coarse) if more_pads is None else (feat, coarse, tuple(extra))
 
     def forward(self, x):
         x = self.upsample(self.linear(x))

@@ -116,7 +116,11 @@ class Decoder(nn.Module):
                 pend = r
             else:
                 x = r
-        out = self.patch_unembedding.forward_padded(x)              # bf16 GPU path: un-patchify + channel pad in one copy
+        plan = self.unet.pad_plan(x.is_cuda)                        # the UNet's 12-channel weights ride in the un-embedding's pad launch
+        out = self.patch_unembedding.forward_padded(x, plan)       # bf16 GPU path: un-patchify + channel pad in one copy
+        if out is not None and plan is not None:
+            feat, x, padded = out
+            return self.unet(feat, residual=x, padded=padded)
         feat, x = out if out is not None else self.patch_unembedding(x)
         return self.unet(feat, residual=x)                          # x + self.unet(feat): the add rides in the UNet's final product
 

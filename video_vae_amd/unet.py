@@ -143,15 +143,33 @@ class UNet(nn.Module):
             in_ch = out_ch
         self.final_conv = Conv(base_features, out_features, (1, 1, 1), rngs, dtype, param_dtype, zero_init=True)
 
-    def forward(self, x, residual=None):
+    def pad_plan(self, on_gpu):
+        """-> (parameters, padded sizes of their last dims) for ops.pad_last2_group, or None: the weights forward() zero-pads to the 16-channel
+        granule of the matrix-core kernels.  A caller with pads of its own (model.Decoder: the un-embedding's down-projection) runs them all in
+        ONE launch each way and hands the padded tensors back as forward(padded=...)."""
+        c = self.patch_mixer.kernel.shape[-2]
+        pad = (-c) % 16 if (on_gpu and self.dtype == torch.bfloat16 and len(self.encoders) > 0) else 0
+        if not pad:
+            return None
+        km, bm, k1 = self.patch_mixer.kernel, self.patch_mixer.bias, self.encoders[0].conv1.conv.kernel
+        if not all(p.dtype == torch.float32 for p in (km, bm, k1)):
+            return None
+        return [km, bm, k1], [(c + pad, c + pad), (c + pad,), (c + pad, k1.shape[-1])]
+
+    def forward(self, x, residual=None, padded=None):
         """``residual``: (b, t, h, w, out_features) added to the result -- the decoder's ``x + self.unet(feat)`` (reference train/model.py:97)
-        inside the final 1x1x1 product where the pointwise kernels take the shape, else a separate add."""
+        inside the final 1x1x1 product where the pointwise kernels take the shape, else a separate add.  ``padded``: the tensors of pad_plan(),
+        already padded by the caller."""
         x = x.to(self.dtype)
         c = self.patch_mixer.kernel.shape[-2]
         pad = (-c) % 16 if (x.is_cuda and self.dtype == torch.bfloat16 and len(self.encoders) > 0) else 0
         k1 = None
         km, bm = self.patch_mixer.kernel, self.patch_mixer.bias
-        if pad:
+        if pad and padded is not None:
+            if x.shape[-1] != c + pad:
+                raise ValueError(f"UNet expects {c + pad} zero-padded input channels beside padded weights, got {x.shape[-1]}")
+            km, bm, k1 = padded
+        elif pad:
             # bf16 MFMA kernels want channel counts in multiples of 16: run the mixer and the first encoder conv on
             # zero-padded channels (zero weights in the pad rows/columns => identical results, grads sliced by autograd).
             # A caller may hand the features over already padded (layers.PatchUnEmbedding.forward_padded).
