@@ -181,6 +181,11 @@ int vvae_gn_stats(const void* x, int ldx, int N, long S, int C, int G, double* s
 int vvae_gn_finalize(const float* part, int N, int nblk, int G, double* sums, void* stream);   /* second half of vvae_gn_stats for partials written by vvae_conv3d_fwd_bf16_gn */
 int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const double* sums, const float* gamma, const float* beta,
                      int N, long S, int C, int G, float eps, int dtype, void* stream);
+/* silu(GroupNorm(x)) and its (1,2,2) max-pool in one launch (conv2 -> GN -> SiLU -> max_pool of an encoder level, train/unet.py:44-51):
+ * y (N,T,H,W,C) pitch ldy, pool (N,T,H/2,W/2,C) pitch ldp; `sums` as for vvae_gn_silu_fwd. */
+int vvae_gn_silu_pool_supported(int H, int W, int C, int G, int ldx, int ldy, int ldp, int dtype);
+int vvae_gn_silu_pool_fwd(const void* x, int ldx, void* y, int ldy, void* pool, int ldp, const double* sums, const float* gamma,
+                          const float* beta, int N, int T, int H, int W, int C, int G, float eps, int dtype, void* stream);
 int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const double* sums,
                      const float* gamma, const float* beta, double* csum /* fp64 [N][C][2] scratch */, float* part,
                      float* dgamma, float* dbeta, int N, long S, int C, int G, float eps, int dtype, void* stream);

@@ -1501,6 +1501,38 @@ def test_colsum_vector_and_scalar_forms(dev, v, c, dt):
     assert_close_scaled(a, x.double().sum(0), rel=2e-5 if dt == torch.float32 else 1e-4, what="colsum")
 
 
+@pytest.mark.parametrize("c,h,w,dt,sliced", [(16, 32, 32, torch.bfloat16, False), (32, 16, 24, torch.bfloat16, True), (64, 8, 8, torch.bfloat16, True),
+                                              (128, 4, 6, torch.bfloat16, False), (16, 8, 8, torch.float32, False)])
+def test_group_norm_silu_with_pool(dev, c, h, w, dt, sliced):
+    """ops.group_norm_silu(pool=True) (GroupNorm + SiLU + the (1,2,2) max-pool of an encoder level in one launch, vvae_gn_silu_pool_fwd)
+    against GroupNorm + SiLU followed by ops.max_pool_fork: bitwise the same outputs -- also into the channel half of a joint buffer -- and,
+    the backward being the same kernels in the same order, bitwise the same gradients."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(c + h)
+    groups = min(8, c)
+    x = torch.randn(2, 3, h, w, c, generator=g).to(dev, dt)
+    sc = (1 + 0.1 * torch.randn(c, generator=g)).to(dev)
+    bi = (0.1 * torch.randn(c, generator=g)).to(dev)
+    gy = torch.randn(2, 3, h, w, c, generator=g).to(dev, dt)
+    gp = torch.randn(2, 3, h // 2, w // 2, c, generator=g).to(dev, dt)
+    res = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (x, sc, bi)]
+        out = torch.zeros(2, 3, h, w, 2 * c, device=dev, dtype=dt)[..., c:] if sliced else None
+        assert ops.gn_silu_pool_ok(leaves[0], groups, out)
+        if fused:
+            y, p = ops.group_norm_silu(leaves[0], leaves[1], leaves[2], groups, 1e-6, out, pool=True)
+        else:
+            p, y = ops.max_pool_fork(ops.group_norm_silu(leaves[0], leaves[1], leaves[2], groups, 1e-6, out))
+        grads = torch.autograd.grad([y, p], leaves, [gy, gp])
+        res.append((y.detach().clone(), p.detach().clone(), grads))
+    (y1, p1, g1), (y0, p0, g0) = res
+    assert torch.equal(y1, y0) and torch.equal(p1, p0)
+    assert torch.equal(p1, torch.nn.functional.max_pool3d(y1.permute(0, 4, 1, 2, 3).float(), (1, 2, 2)).permute(0, 2, 3, 4, 1).to(dt))
+    for a, b, what in zip(g1, g0, ("dx", "dscale", "dbias")):
+        assert torch.equal(a, b), what
+
+
 def test_pad_last2_group_matches_f_pad(dev):
     """ops.pad_last2_group (the UNet's three 12-channel weight pads in one launch each way) against F.pad: values, and the gradients
     of a padded-space cotangent cut back to the parameters' shapes."""

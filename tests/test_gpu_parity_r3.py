@@ -142,6 +142,10 @@ def test_production_model_bf16_256_graph_replay_vs_oracle(dev, oracle_runs):
     # captured on OTHER inputs (an all-ones mask, another clip): the replay below must depend on what is copied into the static buffers only
     g = torch.Generator().manual_seed(99)
     step = GraphedTrainStep(m, opt, torch.rand(video.shape, generator=g).to(dev, torch.bfloat16), torch.ones_like(mg), L.HPARAMS, cfg.hw, V.Rngs(3), warmup=1)
+    # the replayed production step as a graph: kernels only -- no memset node, no memcpy node, and no more than 800 launches
+    # (880 at the end of round 2; the count does not depend on the batch)
+    census = step.census[0]
+    assert census is not None and set(census) == {"kernel"} and census["kernel"] <= 800, census
     step()                                                              # one replay with other inputs and fresh noise first
     loss, aux = step(vg, mg, noise={k: v.to(dev) for k, v in noise.items()})
     torch.cuda.synchronize()

@@ -154,42 +154,47 @@ __global__ __launch_bounds__(256) void convt_wgrad_bf16_kernel(const bf16_t* __r
 
 // Fold the per-workgroup slabs in fixed order: column c < nw -> dw[c]; the 4 x cout bias columns behind them (one run per tap) -> db[co] as
 // ((t0 + t1) + (t2 + t3)) of the four folded taps -- one launch (round 3; the taps were folded by a second 5 us launch).
-// Block = 32 outputs x 8 row lanes, 8 loads in flight per thread (the slabs are L2-resident: latency is what the fold pays for).
+// Block = 32 columns x 8 row lanes, 8 loads in flight per thread (the slabs are L2-resident: latency is what the fold pays for).  Blocks
+// [0, ceil(nw / 32)) take weight columns; the blocks behind them take 8 output channels x 4 taps each, so that a tap fold stays inside a block
+// and no thread walks more rows than any other.
 __global__ __launch_bounds__(256) void cw_reduce_kernel(const float* __restrict__ part, int rows, long stride, int nw, int cout,
                                                         float* __restrict__ dw, float* __restrict__ db)
 {
-    __shared__ float red[8][32][4];
+    __shared__ float red[8][32];
+    __shared__ float taps[32];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    const bool is_w = c < nw, is_b = !is_w && db && c < nw + cout;
-    const int ntap = is_b ? 4 : 1;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (is_w || is_b) {
-        for (int t = 0; t < ntap; ++t) {
-            const long col = is_w ? c : nw + (long)t * cout + (c - nw);
-            for (int r0 = rl; r0 < rows; r0 += 8 * 8) {
-                float v[8];
+    const int wblocks = (nw + 31) / 32;
+    const bool bias_blk = (int)blockIdx.x >= wblocks;
+    long col = -1;
+    int co = -1;
+    if (!bias_blk) { const int c = blockIdx.x * 32 + cl; if (c < nw) col = c; }
+    else {
+        co = ((int)blockIdx.x - wblocks) * 8 + (cl & 7);
+        if (co < cout) col = nw + (long)(cl >> 3) * cout + co;      // tap cl >> 3
+    }
+    float s = 0.f;
+    if (col >= 0) {
+        for (int r0 = rl; r0 < rows; r0 += 8 * 8) {
+            float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = r0 + 8 * i;
-                    v[i] = r < rows ? part[(long)r * stride + col] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s[t] += v[i];
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + 8 * i;
+                v[i] = r < rows ? part[(long)r * stride + col] : 0.f;
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
         }
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) red[rl][cl][t] = s[t];
+    red[rl][cl] = s;
     __syncthreads();
-    if (rl == 0 && (is_w || is_b)) {
-        float tot[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            tot[t] = ((red[0][cl][t] + red[1][cl][t]) + (red[2][cl][t] + red[3][cl][t])) + ((red[4][cl][t] + red[5][cl][t]) + (red[6][cl][t] + red[7][cl][t]));
-        if (is_w) dw[c] = tot[0];
-        else db[c - nw] = (tot[0] + tot[1]) + (tot[2] + tot[3]);
+    if (rl == 0) {
+        const float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+        if (!bias_blk) { if (col >= 0) dw[col] = t; }
+        else taps[cl] = t;
     }
+    __syncthreads();
+    if (bias_blk && threadIdx.x < 8 && co >= 0 && co < cout && db)
+        db[co] = (taps[threadIdx.x] + taps[8 + threadIdx.x]) + (taps[16 + threadIdx.x] + taps[24 + threadIdx.x]);
 }
 
 inline bool cw_shape(int Cin, int Cout) { return (Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 32) || (Cin == 32 && Cout == 16); }
@@ -221,7 +226,7 @@ int launch_cw(const void* x, const void* dy, float* dw, float* db, float* slab, 
     VVAE_LAUNCH_CHECK();
     // fold the slabs in fixed order: weight columns straight into dw, the 4 x COUT bias columns (one run per tap) into db
     const int nw = 4 * CIN * COUT;
-    hipLaunchKernelGGL(cw_reduce_kernel, dim3(ceil_div(nw + COUT, 32)), dim3(256), 0, s, slab, nblk, (long)C::SLAB, nw, COUT, dw, db);
+    hipLaunchKernelGGL(cw_reduce_kernel, dim3(ceil_div(nw, 32) + (db ? ceil_div(COUT, 8) : 0)), dim3(256), 0, s, slab, nblk, (long)C::SLAB, nw, COUT, dw, db);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

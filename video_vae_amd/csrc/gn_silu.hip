@@ -187,6 +187,55 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ 
         }
 }
 
+// y = silu(GroupNorm(x)) AND pool = max over the (1,2,2) windows of y in one pass: conv2 -> GroupNorm -> SiLU -> max_pool of an encoder level
+// (/root/reference/train/unet.py:44-51).  The separate pool re-read the skip tensor it had just written (3 launches, 66 us per step).
+// A thread owns VEC channels of one 2 x 2 window: four loads of x, four stores of y (the rounded values, as the pool of the stored tensor
+// saw them), one store of their maximum.  grid (blocks, N); items = T * (H/2) * (W/2) * (C/VEC) per sample; 256 % (C/VEC) == 0.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_silu_pool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, T* __restrict__ pool,
+                                                               int ldp, const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, GnDims d, int H, int W, long items_per_block)
+{
+    __shared__ float ab[kMaxC][2];
+    __shared__ float mean_g[64], rstd_g[64];
+    const int n = blockIdx.y;
+    load_affine(sums, gamma, beta, d, n, ab, mean_g, rstd_g);
+    const int cvecs = d.C / VEC, Ho = H / 2, Wo = W / 2;
+    const long items = d.S / 4 * cvecs;
+    const long ibeg = (long)blockIdx.x * items_per_block;
+    long iend = ibeg + items_per_block;
+    if (iend > items) iend = items;
+    const int c0 = (threadIdx.x % cvecs) * VEC;              // 256 % cvecs == 0: a thread keeps its channel vector
+    float aa[VEC], bb[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { aa[i] = ab[c0 + i][0]; bb[i] = ab[c0 + i][1]; }
+    const T* xs = x + (long)n * d.S * ldx + c0;
+    T* ys = y + (long)n * d.S * ldy + c0;
+    T* ps = pool + (long)n * (d.S / 4) * ldp + c0;
+    for (long it = ibeg + threadIdx.x; it < iend; it += 256) {
+        long q = it / cvecs;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho); const long t = q / Ho;
+        const long vi = (t * H + 2 * ho) * W + 2 * wo;
+        const long vs[4] = {vi, vi + 1, vi + W, vi + W + 1};
+        float v[4][VEC], m[VEC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) VecIO<T, VEC>::load(xs + vs[k] * ldx, v[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float z = v[k][i] * aa[i] + bb[i];
+                v[k][i] = round_to<T>(z * sigmoidf_(z));
+            }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m[i] = fmaxf(fmaxf(v[0][i], v[1][i]), fmaxf(v[2][i], v[3][i]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) VecIO<T, VEC>::store(ys + vs[k] * ldy, v[k]);
+        VecIO<T, VEC>::store(ps + ((t * Ho + ho) * Wo + wo) * ldp, m);
+    }
+}
+
 // dz = dy * silu'(z), silu'(z) = s*(1 + z*(1-s)), s = sigmoid(z)
 __device__ __forceinline__ float dsilu(float z) {
     const float s = sigmoidf_(z);
@@ -404,6 +453,41 @@ extern "C" int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const 
                                           : (vec_ok<bf16_t>(x, ldx, C) && vec_ok<bf16_t>(y, ldy, C));
     if (!vok && C > 256) return VVAE_ERR_BAD_ARG;
     GN_DISPATCH(gn_silu_fwd_kernel, vok, (const T*)x, ldx, (T*)y, ldy, sums, gamma, beta, d, vpb);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// 1 if vvae_gn_silu_pool_fwd takes the layer: 16-byte channel vectors that tile a 256-thread workgroup, even H and W.
+extern "C" int vvae_gn_silu_pool_supported(int H, int W, int C, int G, int ldx, int ldy, int ldp, int dtype)
+{
+    const int vec = dtype == VVAE_DT_F32 ? 4 : dtype == VVAE_DT_BF16 ? 8 : 0;
+    if (!vec || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || C % vec || G <= 0 || G > 64 || C % G || C > kMaxC) return 0;
+    const int cvecs = C / vec;
+    return (256 % cvecs == 0 && ldx % vec == 0 && ldy % vec == 0 && ldp % vec == 0 && ldx >= C && ldy >= C && ldp >= C) ? 1 : 0;
+}
+
+// y (N, T, H, W, C) = silu(GroupNorm(x)) with the statistics `sums` (vvae_gn_stats / vvae_gn_finalize) and pool (N, T, H/2, W/2, C) = the
+// (1,2,2) max-pool of y, in one launch.  Row pitches in elements.
+extern "C" int vvae_gn_silu_pool_fwd(const void* x, int ldx, void* y, int ldy, void* pool, int ldp, const double* sums, const float* gamma,
+                                     const float* beta, int N, int T, int H, int W, int C, int G, float eps, int dtype, void* stream)
+{
+    if (!x || !y || !pool || !sums || !gamma || !beta || N <= 0 || T <= 0 || !vvae_gn_silu_pool_supported(H, W, C, G, ldx, ldy, ldp, dtype) ||
+        ((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)pool % 16)) return VVAE_ERR_BAD_ARG;
+    const long S = (long)T * H * W;
+    GnDims d{N, S, C, G, eps};
+    const int vec = dtype == VVAE_DT_F32 ? 4 : 8;
+    const long items = S / 4 * (C / vec);
+    long want = 4096 / N; if (want < 1) want = 1;
+    long ipb = (items + want - 1) / want;
+    ipb = (ipb + 255) / 256 * 256;                               // whole passes of the workgroup: a thread's channel vector stays put
+    dim3 grid((unsigned)((items + ipb - 1) / ipb), N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VVAE_DT_F32)
+        hipLaunchKernelGGL((gn_silu_pool_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, (float*)pool, ldp, sums, gamma,
+                           beta, d, H, W, ipb);
+    else
+        hipLaunchKernelGGL((gn_silu_pool_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (bf16_t*)pool, ldp, sums,
+                           gamma, beta, d, H, W, ipb);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -194,8 +194,36 @@ __global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __res
                                                              float inv_max_rate, float magnify, float gamma1, float gamma2,
                                                              float* __restrict__ out, float* __restrict__ grads)
 {
-    __shared__ float sq[TAIL_MAX_B], dens[TAIL_MAX_B];
+    __shared__ float sq[TAIL_MAX_B], dens[TAIL_MAX_B], msum[TAIL_MAX_B], ksum[TAIL_MAX_B];
+    __shared__ float red[256];
     const float invB = 1.f / (float)B;
+    // per-sample MSE / KL terms from their partial sums.  Few samples with many partials each (B = 4: 512 + 16): the whole workgroup
+    // sums one sample at a time -- thread i takes columns i, i + 256, ..., then a fixed tree -- instead of one thread walking 2 048 dependent
+    // loads (93 us); many samples with few partials: one thread per sample.  Either way a fixed order.
+    if (mse_cols + kl_cols > 16 && B <= 64) {
+        for (int b = 0; b < B; ++b)
+            for (int which = 0; which < 2; ++which) {
+                const float* p = which ? kl + (long)b * kl_cols : mse + (long)b * mse_cols;
+                const int n = which ? kl_cols : mse_cols;
+                float a = 0.f;
+                for (int c = threadIdx.x; c < n; c += 256) a += p[c];
+                red[threadIdx.x] = a;
+                __syncthreads();
+                for (int st = 128; st > 0; st >>= 1) {
+                    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) (which ? ksum : msum)[b] = red[0];
+                __syncthreads();
+            }
+    } else {
+        for (int b = threadIdx.x; b < B; b += 256) {
+            float kb = 0.f, mb = 0.f;
+            for (int c = 0; c < kl_cols; ++c) kb += kl[(long)b * kl_cols + c];
+            for (int c = 0; c < mse_cols; ++c) mb += mse[(long)b * mse_cols + c];
+            msum[b] = mb; ksum[b] = kb;
+        }
+    }
     for (int b = threadIdx.x; b < B; b += 256) {
         float len = 0.f, ssum = 0.f;
         for (int t = 0; t < T; ++t) { const float m = mask[b * T + t]; len += m; ssum += sel[b * T + t] * m; }
@@ -214,12 +242,7 @@ __global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = 0.f, k = 0.f, q = 0.f, dn = 0.f;
-        for (int b = 0; b < B; ++b) {
-            float kb = 0.f, mb = 0.f;                                // the sample's KL / MSE term: its partial sums in index order
-            for (int c = 0; c < kl_cols; ++c) kb += kl[b * kl_cols + c];
-            for (int c = 0; c < mse_cols; ++c) mb += mse[b * mse_cols + c];
-            a += mb; k += kb; q += sq[b]; dn += dens[b];
-        }
+        for (int b = 0; b < B; ++b) { a += msum[b]; k += ksum[b]; q += sq[b]; dn += dens[b]; }
         a *= invB; k *= invB; q *= invB; dn *= invB;
         out[0] = a + gamma1 * q + gamma2 * k;
         out[1] = a; out[2] = q; out[3] = k; out[4] = dn;

@@ -655,32 +655,62 @@ def gn_silu_bwd_raw(x, dy, sums, scale, bias, groups, eps, out=None):
     return out, dg, db
 
 
+def gn_silu_pool_ok(x, groups, out=None):
+    """May group_norm_silu(..., pool=True) run?  (vvae_gn_silu_pool_fwd: 5-D NDHWC on the GPU, even H and W, 16-byte channel vectors.)"""
+    if not (x.is_cuda and x.dim() == 5 and x.dtype in DT and x.stride(-1) == 1) or _FORCE_GENERIC[0]:
+        return False
+    h, w, c = x.shape[-3], x.shape[-2], x.shape[-1]
+    ldy = out.stride(-2) if out is not None else c
+    return lib().vvae_gn_silu_pool_supported(h, w, c, groups, x.stride(-2), ldy, c, DT[x.dtype]) == 1
+
+
 class _GnSilu(torch.autograd.Function):
+    """silu(GroupNorm(x)).  ``pool``: also return its (1,2,2) max-pool from the same launch (the encoder levels' conv2 -> GN -> SiLU ->
+    max_pool, reference train/unet.py:44-51); the backward then first routes the pool's gradient to the window maxima and adds the skip's
+    (maxpool_bwd_raw, as ops.max_pool_fork did) and runs the GroupNorm backward on the sum."""
+
     @staticmethod
-    def forward(ctx, x, scale, bias, groups, eps, out=None, part=None, nblk=0):
+    def forward(ctx, x, scale, bias, groups, eps, out=None, part=None, nblk=0, pool=False):
         s32, b32 = _f32(scale), _f32(bias)
         if part is not None:                             # the producing conv already summed its outputs (conv3d_with_gn_stats)
             sums = torch.empty((x.shape[0], groups, 2), dtype=torch.float64, device=x.device)
             check(lib().vvae_gn_finalize(_p(part), x.shape[0], nblk, groups, _p(sums), _stream()), "vvae_gn_finalize")
         else:
             sums = gn_stats_raw(x, groups)
-        ctx.save_for_backward(x, sums, s32, b32)
-        ctx.groups, ctx.eps, ctx.pdtype = groups, eps, scale.dtype
-        return gn_silu_fwd_raw(x, sums, s32, b32, groups, eps, out)
+        ctx.groups, ctx.eps, ctx.pdtype, ctx.pool = groups, eps, scale.dtype, bool(pool)
+        ctx.set_materialize_grads(False)
+        if not pool:
+            ctx.save_for_backward(x, sums, s32, b32)
+            return gn_silu_fwd_raw(x, sums, s32, b32, groups, eps, out)
+        xr, ldx = rows(x)
+        n, t, h, w, c = xr.shape
+        y = out if out is not None else torch.empty(xr.shape, dtype=xr.dtype, device=xr.device)
+        pooled = torch.empty((n, t, h // 2, w // 2, c), dtype=xr.dtype, device=xr.device)
+        check(lib().vvae_gn_silu_pool_fwd(_p(xr), ldx, _p(y), y.stride(-2), _p(pooled), c, _p(sums), _p(s32), _p(b32), n, t, h, w, c, groups,
+                                          eps, _dt(xr), _stream()), "vvae_gn_silu_pool_fwd")
+        ctx.save_for_backward(x, sums, s32, b32, y)
+        return y, pooled
 
     @staticmethod
-    def backward(ctx, dy):
-        x, sums, s32, b32 = ctx.saved_tensors
+    def backward(ctx, dy, dpool=None):
+        if ctx.pool:
+            x, sums, s32, b32, y = ctx.saved_tensors
+            if dpool is not None:
+                dy = maxpool_bwd_raw(y, dpool.to(y.dtype), None if dy is None else dy.to(y.dtype))
+        else:
+            x, sums, s32, b32 = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 9
         dx, dg, db = gn_silu_bwd_raw(x, dy.to(x.dtype), sums, s32, b32, ctx.groups, ctx.eps)
-        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None, None, None, None
+        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None, None, None, None, None
 
 
-def group_norm_silu(x, scale, bias, groups, eps=1e-6, out=None, stats=None):
+def group_norm_silu(x, scale, bias, groups, eps=1e-6, out=None, stats=None, pool=False):
     """silu(GroupNorm(x)) over (t,h,w,C/G) per sample (reference train/unet.py:22-23,28-29).  ``out``: a channel slice of a
-    wider NDHWC buffer to write into (see join_channels).  ``stats``: from conv3d_with_gn_stats."""
+    wider NDHWC buffer to write into (see join_channels).  ``stats``: from conv3d_with_gn_stats.  ``pool`` (gn_silu_pool_ok): -> (y, max_pool_1x2x2(y))."""
     if stats is not None:
-        return _GnSilu.apply(x, scale, bias, groups, eps, out, stats[0], stats[1])
-    return _GnSilu.apply(x, scale, bias, groups, eps, out)
+        return _GnSilu.apply(x, scale, bias, groups, eps, out, stats[0], stats[1], pool)
+    return _GnSilu.apply(x, scale, bias, groups, eps, out, None, 0, pool)
 
 
 # --------------------------------------------------------------------------------------------- max-pool (1,2,2)

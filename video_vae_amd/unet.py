@@ -62,7 +62,8 @@ class ConvBlock3D(nn.Module):
         self.conv = Conv(in_channels, out_channels, (temporal_kernel, kernel_size, kernel_size), rngs, dtype, param_dtype)
         self.norm = GroupNorm(min(8, out_channels), out_channels, param_dtype)
 
-    def forward(self, x, kernel=None, out=None, pack=None, x2=None, price=None):
+    def forward(self, x, kernel=None, out=None, pack=None, x2=None, price=None, pool=False):
+        # ``pool``: -> (y, max_pool(1,2,2)(y)), the pool from the GroupNorm + SiLU launch where ops.gn_silu_pool_ok, else a launch of its own
         # ``price``: (Cin, Cout) the layer really has when ``kernel`` is a zero-padded stand-in (roofline accounting only)
         # ``kernel``: optional stand-in for self.conv.kernel (UNet passes a zero-padded view for 16-channel alignment)
         # ``out``: channel slice of a wider buffer for the block's output (the skip half of a decoder's concat buffer)
@@ -74,7 +75,13 @@ class ConvBlock3D(nn.Module):
         else:
             x, stats = ops.conv3d_with_gn_stats(x.to(self.conv.dtype), self.conv.kernel if kernel is None else kernel, self.conv.bias,
                                                 self.norm.num_groups, pack, price)
-        return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out, stats)
+        if pool and ops.gn_silu_pool_ok(x, self.norm.num_groups, out):
+            return ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out, stats, pool=True)
+        y = ops.group_norm_silu(x, self.norm.scale, self.norm.bias, self.norm.num_groups, 1e-6, out, stats)
+        if pool:
+            pooled, y = ops.max_pool_fork(y)
+            return y, pooled
+        return y
 
 
 class DownBlock3D(nn.Module):
@@ -87,8 +94,8 @@ class DownBlock3D(nn.Module):
 
     def forward(self, x, kernel1=None, skip_out=None, packs=(None, None)):
         price = None if kernel1 is None else tuple(self.conv1.conv.kernel.shape[-2:])
-        x = self.conv2(self.conv1(x, kernel1, pack=packs[0], price=price), out=skip_out, pack=packs[1])
-        return ops.max_pool_fork(x)
+        skip, pooled = self.conv2(self.conv1(x, kernel1, pack=packs[0], price=price), out=skip_out, pack=packs[1], pool=True)
+        return pooled, skip
 
 
 class UpBlock3D(nn.Module):
