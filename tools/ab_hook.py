@@ -30,7 +30,11 @@ def set_value(v):
     if hook.startswith("py:"):                            # a module-level switch: py:video_vae_amd.layers.NT_SILU
         import importlib
         mod, name = hook[3:].rsplit(".", 1)
-        setattr(importlib.import_module(mod), name, v[0])
+        m = importlib.import_module(mod)
+        if isinstance(getattr(m, name), list):               # a one-element list switch (ops.GN_POOL_BWD_FUSED = [True])
+            getattr(m, name)[0] = type(getattr(m, name)[0])(v[0])
+        else:
+            setattr(m, name, v[0])
     else:
         assert getattr(lib(), hook)(*v) == 0
 

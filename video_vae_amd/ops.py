@@ -664,6 +664,35 @@ def gn_silu_pool_ok(x, groups, out=None):
     return lib().vvae_gn_silu_pool_supported(h, w, c, groups, x.stride(-2), ldy, c, DT[x.dtype]) == 1
 
 
+GN_POOL_BWD_FUSED = [True]       # test hook: False = the separate pool backward (maxpool_bwd_raw) in front of the GroupNorm backward
+
+
+def gn_silu_pool_bwd_raw(x, dskip, dpool, sums, scale, bias, groups, eps):
+    """Backward of group_norm_silu(pool=True) without a dy tensor (vvae_gn_silu_pool_bwd) -> (dx, dgamma, dbeta), or None where the
+    kernel does not take the operands' layout."""
+    if not GN_POOL_BWD_FUSED[0]:
+        return None
+    xr, ldx = rows(x)
+    n, t, h, w, c = xr.shape
+    dpool, ldp = rows(dpool.to(xr.dtype))
+    ldds = 0
+    if dskip is not None:
+        dskip, ldds = rows(dskip.to(xr.dtype))
+    vec = 8 if xr.dtype == torch.bfloat16 else 4
+    if (lib().vvae_gn_silu_pool_supported(h, w, c, groups, ldx, c, ldp, _dt(xr)) != 1 or (dskip is not None and (ldds % vec or dskip.data_ptr() % 16))
+            or xr.data_ptr() % 16 or dpool.data_ptr() % 16):
+        return None
+    dx = torch.empty(xr.shape, dtype=xr.dtype, device=xr.device)
+    s = t * h * w
+    csum = torch.empty((n, c, 2), dtype=torch.float64, device=xr.device)
+    part = torch.empty((lib().vvae_gn_part_floats(n, s, c),), dtype=torch.float32, device=xr.device)
+    dg = torch.empty((c,), dtype=torch.float32, device=xr.device)
+    db = torch.empty((c,), dtype=torch.float32, device=xr.device)
+    check(lib().vvae_gn_silu_pool_bwd(_p(xr), ldx, _p(dskip), ldds, _p(dpool), ldp, _p(dx), c, _p(sums), _p(scale), _p(bias), _p(csum), _p(part),
+                                      _p(dg), _p(db), n, t, h, w, c, groups, eps, _dt(xr), _stream()), "vvae_gn_silu_pool_bwd")
+    return dx, dg, db
+
+
 class _GnSilu(torch.autograd.Function):
     """silu(GroupNorm(x)).  ``pool``: also return its (1,2,2) max-pool from the same launch (the encoder levels' conv2 -> GN -> SiLU ->
     max_pool, reference train/unet.py:44-51); the backward then first routes the pool's gradient to the window maxima and adds the skip's
@@ -696,6 +725,10 @@ class _GnSilu(torch.autograd.Function):
         if ctx.pool:
             x, sums, s32, b32, y = ctx.saved_tensors
             if dpool is not None:
+                fused = gn_silu_pool_bwd_raw(x, dy, dpool, sums, s32, b32, ctx.groups, ctx.eps)
+                if fused is not None:                    # no dy tensor: both GroupNorm passes find the window maxima again from x
+                    dx, dg, db = fused
+                    return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None, None, None, None, None
                 dy = maxpool_bwd_raw(y, dpool.to(y.dtype), None if dy is None else dy.to(y.dtype))
         else:
             x, sums, s32, b32 = ctx.saved_tensors
