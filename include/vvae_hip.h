@@ -186,11 +186,6 @@ int vvae_gn_silu_fwd(const void* x, int ldx, void* y, int ldy, const double* sum
 int vvae_gn_silu_pool_supported(int H, int W, int C, int G, int ldx, int ldy, int ldp, int dtype);
 int vvae_gn_silu_pool_fwd(const void* x, int ldx, void* y, int ldy, void* pool, int ldp, const double* sums, const float* gamma,
                           const float* beta, int N, int T, int H, int W, int C, int G, float eps, int dtype, void* stream);
-/* ... and its backward without a dy tensor: dskip = the gradient arriving at y (or NULL), dpool = the one arriving at the pool; the window
- * maxima are found again from x (first maximum wins, as in vvae_maxpool_1x2x2_bwd). */
-int vvae_gn_silu_pool_bwd(const void* x, int ldx, const void* dskip, int ldds, const void* dpool, int ldp, void* dx, int lddx,
-                          const double* sums, const float* gamma, const float* beta, double* csum, float* part, float* dgamma,
-                          float* dbeta, int N, int T, int H, int W, int C, int G, float eps, int dtype, void* stream);
 int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const double* sums,
                      const float* gamma, const float* beta, double* csum /* fp64 [N][C][2] scratch */, float* part,
                      float* dgamma, float* dbeta, int N, long S, int C, int G, float eps, int dtype, void* stream);

@@ -1506,7 +1506,7 @@ def test_colsum_vector_and_scalar_forms(dev, v, c, dt):
 def test_group_norm_silu_with_pool(dev, c, h, w, dt, sliced):
     """ops.group_norm_silu(pool=True) (GroupNorm + SiLU + the (1,2,2) max-pool of an encoder level in one launch, vvae_gn_silu_pool_fwd)
     against GroupNorm + SiLU followed by ops.max_pool_fork: bitwise the same outputs -- also into the channel half of a joint buffer -- and,
-    gradients that agree to rounding (fused backward) / bitwise (separate pool backward)."""
+    the backward being the same kernels in the same order, bitwise the same gradients."""
     from video_vae_amd import ops
     g = torch.Generator().manual_seed(c + h)
     groups = min(8, c)
@@ -1529,22 +1529,7 @@ def test_group_norm_silu_with_pool(dev, c, h, w, dt, sliced):
     (y1, p1, g1), (y0, p0, g0) = res
     assert torch.equal(y1, y0) and torch.equal(p1, p0)
     assert torch.equal(p1, torch.nn.functional.max_pool3d(y1.permute(0, 4, 1, 2, 3).float(), (1, 2, 2)).permute(0, 2, 3, 4, 1).to(dt))
-    # backward: the fused form (no dy tensor, window maxima found again from x) routes the same rounded dy through the same GroupNorm algebra;
-    # only the order of the partial sums differs from pool backward + GroupNorm backward
-    tol = 2e-2 if dt == torch.bfloat16 else 1e-4
-    for a, b, what in zip(g1, g0, ("dx", "dscale", "dbias")):
-        assert a.shape == b.shape and a.dtype == b.dtype
-        assert_close_scaled(a.float(), b.float(), rel=tol, what=what)
-    # ... and with the fused backward switched off the two paths are the same kernels in the same order: bitwise equal
-    ops.GN_POOL_BWD_FUSED[0] = False
-    try:
-        leaves = [t.clone().requires_grad_(True) for t in (x, sc, bi)]
-        out = torch.zeros(2, 3, h, w, 2 * c, device=dev, dtype=dt)[..., c:] if sliced else None
-        y, p = ops.group_norm_silu(leaves[0], leaves[1], leaves[2], groups, 1e-6, out, pool=True)
-        g2 = torch.autograd.grad([y, p], leaves, [gy, gp])
-    finally:
-        ops.GN_POOL_BWD_FUSED[0] = True
-    for a, b, what in zip(g2, g0, ("dx", "dscale", "dbias")):
+    for a, b, what in zip(g1, g0, ("dx", "dscale", "dbias")):           # the backward is the same kernels in the same order
         assert torch.equal(a, b), what
 
 

@@ -372,166 +372,6 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restr
         }
 }
 
-// ---- backward of GroupNorm + SiLU + (1,2,2) max-pool (gn_silu_pool_fwd_kernel) without materialising the gradient of y ----------------
-// dy[v] = dskip[v] + (v is the FIRST maximum of its 2 x 2 window of y ? dpool[window] : 0)   (maxpool_bwd_kernel's rule), rounded to the
-// storage dtype as the separate pool backward stored it; y is recomputed from x with the forward's arithmetic (same bits).  A thread owns
-// VEC channels and walks whole windows, so both passes of the GroupNorm backward read x, dskip and the quarter-size dpool instead of a dy
-// tensor that a pool-backward launch had to write first (3 launches and ~3 passes over the level's tensor per encoder level).
-template <typename T, int VEC>
-__device__ __forceinline__ void pool_window_dy(const T* __restrict__ xs, int ldx, const T* __restrict__ dss, int ldds, const T* __restrict__ dps, int ldp,
-                                               long q, int H, int W, const float (&aa)[VEC], const float (&bb)[VEC], long (&vs)[4],
-                                               float (&xv)[4][VEC], float (&dyv)[4][VEC])
-{
-    const int Ho = H / 2, Wo = W / 2;
-    const int wo = (int)(q % Wo); long r = q / Wo;
-    const int ho = (int)(r % Ho); const long t = r / Ho;
-    const long vi = (t * H + 2 * ho) * W + 2 * wo;
-    vs[0] = vi; vs[1] = vi + 1; vs[2] = vi + W; vs[3] = vi + W + 1;
-    float g[VEC];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) VecIO<T, VEC>::load(xs + vs[k] * ldx, xv[k]);
-    VecIO<T, VEC>::load(dps + q * ldp, g);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (dss) VecIO<T, VEC>::load(dss + vs[k] * ldds, dyv[k]);
-        else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) dyv[k][i] = 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        float yk[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const float z = xv[k][i] * aa[i] + bb[i]; yk[k] = round_to<T>(z * sigmoidf_(z)); }
-        int best = 0; float m = yk[0];
-#pragma unroll
-        for (int k = 1; k < 4; ++k) if (yk[k] > m) { m = yk[k]; best = k; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dyv[k][i] = round_to<T>(dyv[k][i] + (k == best ? g[i] : 0.f));
-    }
-}
-
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void gn_silu_pool_bwd_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dskip, int ldds,
-                                                                      const T* __restrict__ dpool, int ldp, const double* __restrict__ sums,
-                                                                      const float* __restrict__ gamma, const float* __restrict__ beta, GnDims d,
-                                                                      int H, int W, float* __restrict__ part, long quads_per_block)
-{
-    __shared__ float ab[kMaxC][2];
-    __shared__ float mean_g[64], rstd_g[64];
-    __shared__ float red[256][2];
-    const int n = blockIdx.y;
-    load_affine(sums, gamma, beta, d, n, ab, mean_g, rstd_g);
-    const int cvecs = d.C / VEC, rows = 256 / cvecs, cpg = d.C / d.G;
-    const int cl = threadIdx.x % cvecs, rl = threadIdx.x / cvecs, c0 = cl * VEC;
-    const long Q = d.S / 4;
-    const long qbeg = (long)blockIdx.x * quads_per_block;
-    long qend = qbeg + quads_per_block;
-    if (qend > Q) qend = Q;
-    const T* xs = x + (long)n * d.S * ldx + c0;
-    const T* dss = dskip ? dskip + (long)n * d.S * ldds + c0 : nullptr;
-    const T* dps = dpool + (long)n * Q * ldp + c0;
-    float s1[VEC], s2[VEC], mu[VEC], rs[VEC], aa[VEC], bb[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        s1[i] = s2[i] = 0.f;
-        const int g = (c0 + i) / cpg;
-        mu[i] = mean_g[g]; rs[i] = rstd_g[g];
-        aa[i] = ab[c0 + i][0]; bb[i] = ab[c0 + i][1];
-    }
-    if (rl < rows)
-        for (long q = qbeg + rl; q < qend; q += rows) {
-            long vs[4];
-            float xv[4][VEC], dyv[4][VEC];
-            pool_window_dy<T, VEC>(xs, ldx, dss, ldds, dps, ldp, q, H, W, aa, bb, vs, xv, dyv);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const float dz = dyv[k][i] * dsilu(xv[k][i] * aa[i] + bb[i]);
-                    s1[i] += dz * (xv[k][i] - mu[i]) * rs[i];
-                    s2[i] += dz;
-                }
-        }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        float a = s1[i], b = s2[i];
-        column_reduce(a, b, cvecs, rows, red);
-        if (threadIdx.x < cvecs) {
-            float* p = part + (((long)n * gridDim.x + blockIdx.x) * d.C + c0 + i) * 2;       // part[n][block][c][2]
-            p[0] = a; p[1] = b;
-        }
-    }
-}
-
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void gn_silu_pool_bwd_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dskip, int ldds,
-                                                                     const T* __restrict__ dpool, int ldp, T* __restrict__ dx, int lddx,
-                                                                     const double* __restrict__ sums, const double* __restrict__ csum,
-                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, GnDims d, int H, int W,
-                                                                     long quads_per_block)
-{
-    __shared__ float ab[kMaxC][2];
-    __shared__ float mean_g[64], rstd_g[64], m1_g[64], m2_g[64];
-    const int n = blockIdx.y;
-    if (blockIdx.x == 0 && n == 0)                        // the affine-parameter gradients ride along in one workgroup
-        for (int c = threadIdx.x; c < d.C; c += 256) {
-            double a = 0.0, b = 0.0;
-            for (int m = 0; m < d.N; ++m) { a += csum[((long)m * d.C + c) * 2]; b += csum[((long)m * d.C + c) * 2 + 1]; }
-            dgamma[c] = (float)a;
-            dbeta[c] = (float)b;
-        }
-    load_affine(sums, gamma, beta, d, n, ab, mean_g, rstd_g);
-    const int cvecs = d.C / VEC, cpg = d.C / d.G;
-    if (threadIdx.x < d.G) {
-        const double M = (double)d.S * cpg;
-        double a = 0.0, b = 0.0;
-        for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
-            a += (double)gamma[c] * csum[((long)n * d.C + c) * 2 + 1];
-            b += (double)gamma[c] * csum[((long)n * d.C + c) * 2];
-        }
-        m1_g[threadIdx.x] = (float)(a / M);
-        m2_g[threadIdx.x] = (float)(b / M);
-    }
-    __syncthreads();
-    const int rows = 256 / cvecs, cl = threadIdx.x % cvecs, rl = threadIdx.x / cvecs, c0 = cl * VEC;
-    const long Q = d.S / 4;
-    const long qbeg = (long)blockIdx.x * quads_per_block;
-    long qend = qbeg + quads_per_block;
-    if (qend > Q) qend = Q;
-    const T* xs = x + (long)n * d.S * ldx + c0;
-    const T* dss = dskip ? dskip + (long)n * d.S * ldds + c0 : nullptr;
-    const T* dps = dpool + (long)n * Q * ldp + c0;
-    T* dxs = dx + (long)n * d.S * lddx + c0;
-    float aa[VEC], bb[VEC], k1[VEC], k2[VEC], k3[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        const int c = c0 + i, gi = c / cpg;
-        aa[i] = ab[c][0]; bb[i] = ab[c][1];
-        const float rs = rstd_g[gi], mu = mean_g[gi];
-        k1[i] = rs * gamma[c];
-        k3[i] = rs * rs * m2_g[gi];
-        k2[i] = rs * m1_g[gi] - k3[i] * mu;
-    }
-    if (rl < rows)
-        for (long q = qbeg + rl; q < qend; q += rows) {
-            long vs[4];
-            float xv[4][VEC], dyv[4][VEC];
-            pool_window_dy<T, VEC>(xs, ldx, dss, ldds, dps, ldp, q, H, W, aa, bb, vs, xv, dyv);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const float dz = dyv[k][i] * dsilu(xv[k][i] * aa[i] + bb[i]);
-                    xv[k][i] = k1[i] * dz - k2[i] - xv[k][i] * k3[i];
-                }
-                VecIO<T, VEC>::store(dxs + vs[k] * lddx, xv[k]);
-            }
-        }
-}
-
 inline int pick_vpb(long S, int N, int total_blocks = 4096) {
     // ~total_blocks workgroups over the whole tensor, at least 128 voxels each.  The reducing kernels pay a fixed
     // epilogue per workgroup (cross-wave folds + fp64 atomics), so they take fewer, longer workgroups (~4 per CU).
@@ -648,49 +488,6 @@ extern "C" int vvae_gn_silu_pool_fwd(const void* x, int ldx, void* y, int ldy, v
     else
         hipLaunchKernelGGL((gn_silu_pool_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (bf16_t*)pool, ldp, sums,
                            gamma, beta, d, H, W, ipb);
-    VVAE_LAUNCH_CHECK();
-    return 0;
-}
-
-// Backward of vvae_gn_silu_pool_fwd in three launches (reduce, finalize, apply) and no dy tensor: dskip (N,T,H,W,C) is the gradient arriving
-// at y itself (may be NULL), dpool (N,T,H/2,W/2,C) the one arriving at the pool.  csum / part / dgamma / dbeta as for vvae_gn_silu_bwd
-// (part: vvae_gn_part_floats(N, T*H*W, C) floats).
-extern "C" int vvae_gn_silu_pool_bwd(const void* x, int ldx, const void* dskip, int ldds, const void* dpool, int ldp, void* dx, int lddx,
-                                     const double* sums, const float* gamma, const float* beta, double* csum, float* part, float* dgamma,
-                                     float* dbeta, int N, int T, int H, int W, int C, int G, float eps, int dtype, void* stream)
-{
-    if (!x || !dpool || !dx || !sums || !gamma || !beta || !csum || !part || !dgamma || !dbeta || N <= 0 || T <= 0 ||
-        !vvae_gn_silu_pool_supported(H, W, C, G, ldx, lddx, ldp, dtype) || (dskip && (ldds < C || ldds % (dtype == VVAE_DT_F32 ? 4 : 8))) ||
-        ((uintptr_t)x % 16) || ((uintptr_t)dskip % 16) || ((uintptr_t)dpool % 16) || ((uintptr_t)dx % 16)) return VVAE_ERR_BAD_ARG;
-    const long S = (long)T * H * W;
-    GnDims d{N, S, C, G, eps};
-    hipStream_t s = (hipStream_t)stream;
-    const long Q = S / 4;
-    const long nblk_r = ceil_div(S, pick_vpb(S, N, 1024));            // rows of `part` the caller provided per sample
-    const long qpb_r = (Q + nblk_r - 1) / nblk_r;
-    const dim3 grid_r((unsigned)((Q + qpb_r - 1) / qpb_r), N);
-    const long nblk_a = ceil_div(S, pick_vpb(S, N));
-    const long qpb_a = (Q + nblk_a - 1) / nblk_a;
-    const dim3 grid_a((unsigned)((Q + qpb_a - 1) / qpb_a), N);
-    if (dtype == VVAE_DT_F32) {
-        typedef float T_;
-        hipLaunchKernelGGL((gn_silu_pool_bwd_reduce_kernel<T_, 4>), grid_r, dim3(256), 0, s, (const T_*)x, ldx, (const T_*)dskip, ldds, (const T_*)dpool, ldp,
-                           sums, gamma, beta, d, H, W, part, qpb_r);
-        VVAE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(2 * C, 32), N), dim3(256), 0, s, part, csum, (int)grid_r.x, C);
-        VVAE_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gn_silu_pool_bwd_apply_kernel<T_, 4>), grid_a, dim3(256), 0, s, (const T_*)x, ldx, (const T_*)dskip, ldds, (const T_*)dpool, ldp,
-                           (T_*)dx, lddx, sums, csum, gamma, beta, dgamma, dbeta, d, H, W, qpb_a);
-    } else {
-        typedef bf16_t T_;
-        hipLaunchKernelGGL((gn_silu_pool_bwd_reduce_kernel<T_, 8>), grid_r, dim3(256), 0, s, (const T_*)x, ldx, (const T_*)dskip, ldds, (const T_*)dpool, ldp,
-                           sums, gamma, beta, d, H, W, part, qpb_r);
-        VVAE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(2 * C, 32), N), dim3(256), 0, s, part, csum, (int)grid_r.x, C);
-        VVAE_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gn_silu_pool_bwd_apply_kernel<T_, 8>), grid_a, dim3(256), 0, s, (const T_*)x, ldx, (const T_*)dskip, ldds, (const T_*)dpool, ldp,
-                           (T_*)dx, lddx, sums, csum, gamma, beta, dgamma, dbeta, d, H, W, qpb_a);
-    }
     VVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -655,42 +655,16 @@ def gn_silu_bwd_raw(x, dy, sums, scale, bias, groups, eps, out=None):
     return out, dg, db
 
 
+GN_POOL_FWD_FUSED = [True]       # test / A-B hook: False = GroupNorm + SiLU, then the pool as a launch of its own
+
+
 def gn_silu_pool_ok(x, groups, out=None):
     """May group_norm_silu(..., pool=True) run?  (vvae_gn_silu_pool_fwd: 5-D NDHWC on the GPU, even H and W, 16-byte channel vectors.)"""
-    if not (x.is_cuda and x.dim() == 5 and x.dtype in DT and x.stride(-1) == 1) or _FORCE_GENERIC[0]:
+    if not (x.is_cuda and x.dim() == 5 and x.dtype in DT and x.stride(-1) == 1) or _FORCE_GENERIC[0] or not GN_POOL_FWD_FUSED[0]:
         return False
     h, w, c = x.shape[-3], x.shape[-2], x.shape[-1]
     ldy = out.stride(-2) if out is not None else c
     return lib().vvae_gn_silu_pool_supported(h, w, c, groups, x.stride(-2), ldy, c, DT[x.dtype]) == 1
-
-
-GN_POOL_BWD_FUSED = [True]       # test hook: False = the separate pool backward (maxpool_bwd_raw) in front of the GroupNorm backward
-
-
-def gn_silu_pool_bwd_raw(x, dskip, dpool, sums, scale, bias, groups, eps):
-    """Backward of group_norm_silu(pool=True) without a dy tensor (vvae_gn_silu_pool_bwd) -> (dx, dgamma, dbeta), or None where the
-    kernel does not take the operands' layout."""
-    if not GN_POOL_BWD_FUSED[0]:
-        return None
-    xr, ldx = rows(x)
-    n, t, h, w, c = xr.shape
-    dpool, ldp = rows(dpool.to(xr.dtype))
-    ldds = 0
-    if dskip is not None:
-        dskip, ldds = rows(dskip.to(xr.dtype))
-    vec = 8 if xr.dtype == torch.bfloat16 else 4
-    if (lib().vvae_gn_silu_pool_supported(h, w, c, groups, ldx, c, ldp, _dt(xr)) != 1 or (dskip is not None and (ldds % vec or dskip.data_ptr() % 16))
-            or xr.data_ptr() % 16 or dpool.data_ptr() % 16):
-        return None
-    dx = torch.empty(xr.shape, dtype=xr.dtype, device=xr.device)
-    s = t * h * w
-    csum = torch.empty((n, c, 2), dtype=torch.float64, device=xr.device)
-    part = torch.empty((lib().vvae_gn_part_floats(n, s, c),), dtype=torch.float32, device=xr.device)
-    dg = torch.empty((c,), dtype=torch.float32, device=xr.device)
-    db = torch.empty((c,), dtype=torch.float32, device=xr.device)
-    check(lib().vvae_gn_silu_pool_bwd(_p(xr), ldx, _p(dskip), ldds, _p(dpool), ldp, _p(dx), c, _p(sums), _p(scale), _p(bias), _p(csum), _p(part),
-                                      _p(dg), _p(db), n, t, h, w, c, groups, eps, _dt(xr), _stream()), "vvae_gn_silu_pool_bwd")
-    return dx, dg, db
 
 
 class _GnSilu(torch.autograd.Function):
@@ -725,10 +699,6 @@ class _GnSilu(torch.autograd.Function):
         if ctx.pool:
             x, sums, s32, b32, y = ctx.saved_tensors
             if dpool is not None:
-                fused = gn_silu_pool_bwd_raw(x, dy, dpool, sums, s32, b32, ctx.groups, ctx.eps)
-                if fused is not None:                    # no dy tensor: both GroupNorm passes find the window maxima again from x
-                    dx, dg, db = fused
-                    return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None, None, None, None, None, None
                 dy = maxpool_bwd_raw(y, dpool.to(y.dtype), None if dy is None else dy.to(y.dtype))
         else:
             x, sums, s32, b32 = ctx.saved_tensors
