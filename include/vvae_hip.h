@@ -281,6 +281,8 @@ int vvae_spatial_attn_bwd(const void* qkv, int ld, const void* out, int ldo, con
  *      bwd writes per-workgroup partials part (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy]. ---- */
 int vvae_layernorm_supported(int C, int dtype);
 int vvae_layernorm_bwd_blocks(long rows, int C, int dtype);
+int vvae_layernorm_fwd_config(int fwd_cap);   /* tuning hook: workgroups of the bf16 forward kernel, default 1024 */
+int vvae_gn_config(int stream_blocks);         /* tuning hook: workgroups of the GroupNorm forward / backward-apply passes, default 4096 */
 int vvae_layernorm_config(int bwd_cap);   /* tuning hook: workgroups (= partial rows) of the backward kernel, default 384 (8 waves each) */
 int vvae_layernorm_fwd_mode(int late_stage);   /* test hook: 1 = round-1 forward variant (affine parked behind the first rows' loads, raw s_barrier) */
 int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,

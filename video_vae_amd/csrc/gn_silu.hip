@@ -372,7 +372,10 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restr
         }
 }
 
-inline int pick_vpb(long S, int N, int total_blocks = 4096) {
+int g_gn_blocks = 4096;      // workgroups of the streaming passes (forward, backward apply); tuning hook vvae_gn_config
+
+inline int pick_vpb(long S, int N, int total_blocks = 0) {
+    if (total_blocks == 0) total_blocks = g_gn_blocks;
     // ~total_blocks workgroups over the whole tensor, at least 128 voxels each.  The reducing kernels pay a fixed
     // epilogue per workgroup (cross-wave folds + fp64 atomics), so they take fewer, longer workgroups (~4 per CU).
     long want = total_blocks / (N > 0 ? N : 1);
@@ -518,5 +521,12 @@ extern "C" int vvae_gn_silu_bwd(const void* x, int ldx, const void* dy, int lddy
     GN_DISPATCH(gn_silu_bwd_apply_kernel, vok, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, sums, csum, gamma, beta, dgamma, dbeta, d,
                 vpb);
     VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tuning hook: workgroups over the whole tensor for the GroupNorm forward / backward-apply passes (default 4096; the reducing passes keep 1024).
+extern "C" int vvae_gn_config(int stream_blocks)
+{
+    g_gn_blocks = stream_blocks > 0 ? stream_blocks : 4096;
     return 0;
 }

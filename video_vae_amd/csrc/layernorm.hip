@@ -247,6 +247,7 @@ __global__ __launch_bounds__(64 * LN_BW) void layernorm_bwd_kernel(const T_* __r
 int g_ln_bwd_cap = 384;      // workgroups (= partial dgamma / dbeta rows) of the backward kernel.  Every row is 6 KB written here and read again by the grouped fold:
                              // 84 launches x 512 rows were 264 MB each way per step.  Whole step (tools/ab_hook.py, 5 alternating rounds): 256 -> 34.05 ms, 384 -> 33.96,
                              // 512 -> 34.03, 1024 -> 34.31
+int g_ln_fwd_cap = 1024;     // workgroups of the bf16 forward kernel (tuning hook vvae_layernorm_fwd_config)
 int g_ln_fwd_late = 0;        // forward kernel: 1 = stage the affine behind the first rows' loads (LDS-only wait + raw barrier)
 
 inline int ln_blocks(long rows, int lpr, int cap = 0)
@@ -344,7 +345,7 @@ extern "C" int vvae_layernorm_fwd(const void* x, void* y, const float* gamma, co
         else { LN_FWD_SWITCH(false, float, (const float*)x, (float*)y, gamma, beta, mean, rstd, (const float*)addend, (float*)xsum, d); }
     } else if (dtype == VVAE_DT_BF16) {
         if (!ln_ok<bf16_t>(d, x, lpr, vpl) || ((uintptr_t)y % 16)) return VVAE_ERR_BAD_ARG;
-        dim3 grid(ln_blocks(rows, lpr, 1024));          // 4096 waves: all resident at 6 waves/SIMD (2048 left a third-full second round)
+        dim3 grid(ln_blocks(rows, lpr, g_ln_fwd_cap));  // 1024 workgroups = 4096 waves: all resident at 6 waves/SIMD (2048 left a third-full second round)
         const int ln_threads = 256;
         if (g_ln_fwd_late) { LN_FWD_SWITCH(true, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d); }
         else { LN_FWD_SWITCH(false, bf16_t, (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, (const bf16_t*)addend, (bf16_t*)xsum, d); }
@@ -390,5 +391,12 @@ extern "C" int vvae_layernorm_config(int bwd_cap)
 extern "C" int vvae_layernorm_fwd_mode(int late_stage)
 {
     g_ln_fwd_late = late_stage ? 1 : 0;
+    return 0;
+}
+
+// Tuning hook: workgroups of the bf16 forward kernel (default 1024).
+extern "C" int vvae_layernorm_fwd_config(int fwd_cap)
+{
+    g_ln_fwd_cap = fwd_cap > 0 ? fwd_cap : 1024;
     return 0;
 }
