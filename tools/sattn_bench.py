@@ -1,5 +1,8 @@
-import torch, sys
+import os, torch, sys
 sys.path.insert(0, ".")
+import video_vae_amd._lib as _L
+if os.environ.get("VVAE_AB_LIB"):        # A/B against another build of the library
+    _L.LIB_PATH = os.environ["VVAE_AB_LIB"]
 from video_vae_amd import ops
 
 from video_vae_amd.layers import RotaryEmbedding

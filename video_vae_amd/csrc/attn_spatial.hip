@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
                     for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
             }
             m = mg;
+            const float mc2 = m * c2;                                // exp2((s - m) c2) as exp2(fma(s, c2, -m c2)): one VALU op per score less in a VALU-bound loop
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (kb0 + g < NKB) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16_t* __restr
                     for (int u = 0; u < 2; ++u) {
                         float pv[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { pv[e] = exp2_fast((s[g][8 * u + e] - m) * c2); l += pv[e]; }
+                        for (int e = 0; e < 8; ++e) { pv[e] = exp2_fast(__builtin_fmaf(s[g][8 * u + e], c2, -mc2)); l += pv[e]; }
                         const bf16x8 pf = pack8(pv);                 // the reference multiplies V by probabilities in the value dtype
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt)
