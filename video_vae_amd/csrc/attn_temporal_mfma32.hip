@@ -141,11 +141,12 @@ __global__ __launch_bounds__(256) void tattn32_fwd_kernel(const bf16_t* __restri
         }
         m = fmaxf(m, xor32(m));
         float l = 0.f;
+        const float mc2 = m * c2;                                       // one fma per score instead of a subtraction and a product
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pe = ((bits[kb] >> e) & 1u) ? exp2_fast((s[kb][e] - m) * c2) : 0.f;
+                const float pe = ((bits[kb] >> e) & 1u) ? exp2_fast(__builtin_fmaf(s[kb][e], c2, -mc2)) : 0.f;
                 s[kb][e] = pe;
                 l += pe;
             }
