@@ -1,5 +1,5 @@
 import os, torch, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import video_vae_amd._lib as _L
 if os.environ.get("VVAE_AB_LIB"):        # A/B against another build of the library
     _L.LIB_PATH = os.environ["VVAE_AB_LIB"]
