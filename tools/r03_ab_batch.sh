@@ -5,6 +5,6 @@ O=$R/gpurun_out/${1:-r03p}
 mkdir -p $O
 cd $R
 run() { echo "== $*"; timeout -k 10 300 python tools/ab_hook.py "$@" r=4 2>&1 | grep "ms/step" | cut -c1-200; }
-run vvae_gn_config 4096 2048 8192 1024 > $O/ab.log 2>&1
-run vvae_layernorm_fwd_config 1024 512 2048 768 >> $O/ab.log 2>&1
+run py:video_vae_amd.ops.GROUP_MIN_TILES 128 64 32 256 > $O/ab.log 2>&1
+run py:video_vae_amd.ops.FOLD_MAX 64 32 16 >> $O/ab.log 2>&1
 cat $O/ab.log
