@@ -414,7 +414,9 @@ def main():
                 dist.broadcast(go_on, 0)
             if not int(go_on.item()):
                 break
-    timer = ops.KernelTimer() if (rank == 0 and not args.no_kernel_timing) else None
+    # events inside the timed region of an eager run must not perturb it: no gate kernels there (the intervals then include the host's launch
+    # latency, as the whole eager step does); behind the region (graph mode) every timed launch sits behind a 25 us gate, see ops.KernelTimer
+    timer = ops.KernelTimer(gate_us=0 if (not graphed and args.settle_seconds > 0) else 25) if (rank == 0 and not args.no_kernel_timing) else None
     if not graphed and args.settle_seconds > 0:
         ops.TIMER = timer                      # eager: per-launch HIP events inside the (settled) timed region
     if args.settle_seconds > 0:
@@ -475,7 +477,8 @@ def main():
         }
         summ = timer.summary() if timer is not None else {}
         nsteps_timed = 3 if graphed_like else args.steps
-        timed_in = ("eager steps right after the timed region (graph replay cannot host events)" if graphed_like
+        timed_in = ("eager steps right after the timed region (graph replay cannot host events), every timed launch queued behind a 25 us gate kernel: "
+                    "the event pair reads the kernel, not kernel + host launch latency" if graphed_like
                     else "the timed region")
         if summ:
             # the dominant hand-written kernel = the kernel (all its tagged shapes together) with the largest total time per

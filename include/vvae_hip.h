@@ -281,6 +281,7 @@ int vvae_spatial_attn_bwd(const void* qkv, int ld, const void* out, int ldo, con
  *      bwd writes per-workgroup partials part (vvae_layernorm_bwd_blocks(...), 2, C): [sum dy*xhat | sum dy]. ---- */
 int vvae_layernorm_supported(int C, int dtype);
 int vvae_layernorm_bwd_blocks(long rows, int C, int dtype);
+int vvae_delay_us(int us, void* stream);   /* measurement aid: occupy the stream for ~us microseconds (1..1000), see ops.KernelTimer */
 int vvae_layernorm_fwd_config(int fwd_cap);   /* tuning hook: workgroups of the bf16 forward kernel, default 1024 */
 int vvae_gn_config(int stream_blocks);         /* tuning hook: workgroups of the GroupNorm forward / backward-apply passes, default 4096 */
 int vvae_layernorm_config(int bwd_cap);   /* tuning hook: workgroups (= partial rows) of the backward kernel, default 384 (8 waves each) */

@@ -750,3 +750,24 @@ extern "C" int vvae_transpose_grouped_bf16(const void* const* src, void* const* 
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+// Measurement aid (ops.KernelTimer): occupy the stream for ~us microseconds with one wave that watches the 100 MHz realtime counter.
+// bench.py brackets a tagged launch with two HIP events; on an idle stream the first event's timestamp is taken the moment it is
+// enqueued, microseconds before the host has finished enqueueing the kernel behind it, and the interval reads kernel + host launch
+// latency.  Behind this gate the event, the kernel and the closing event are all queued before the first of them executes, so the
+// interval is the kernel's (what rocprofv3 reports, and what a replayed graph's back-to-back launches see).
+namespace {
+__global__ void delay_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+extern "C" int vvae_delay_us(int us, void* stream)
+{
+    if (us <= 0 || us > 1000) return VVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)us * 100ull);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
