@@ -52,8 +52,8 @@ class Encoder(nn.Module):
 
     def _trunk(self, x, mask):
         x = self._features(x, mask)
-        mean = self.spatial_compression(x)
-        variance = F.softplus(self.variance_estimator(x))
+        mean, v = linear_pair(x, self.spatial_compression, self.variance_estimator)      # GPU: one node, the input gradients meet inside a product
+        variance = F.softplus(v)
         log_variance = torch.log(variance)
         si = rearrange(self.selection_layer1(mean), "b t hw 1 -> b t hw")
         return mean, log_variance, self.selection_layer2(si) + 1
