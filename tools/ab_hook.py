@@ -31,7 +31,7 @@ def set_value(v):
         import importlib
         mod, name = hook[3:].rsplit(".", 1)
         m = importlib.import_module(mod)
-        if isinstance(getattr(m, name), list):               # a one-element list switch (ops.GN_POOL_BWD_FUSED = [True])
+        if isinstance(getattr(m, name), list):               # a one-element list switch (ops.GN_POOL_FWD_FUSED = [True])
             getattr(m, name)[0] = type(getattr(m, name)[0])(v[0])
         else:
             setattr(m, name, v[0])
