@@ -1414,6 +1414,43 @@ def test_plain_loss_tail_sums_kl_partials(dev):
     assert torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("b,t", [(4, 16), (1, 5), (8, 32)])
+def test_rl_loss_tail_matches_the_framework_ops(dev, b, t):
+    """vvae_loss_tail_rl (the pair / REINFORCE end of loss.loss_fn, value + all gradients in one launch) against the same algebra as
+    framework ops (loss.rl_loss_tail_ops, reference train/rl_nonadversarial.py:130-186): ragged masks, an all-masked sample, probabilities at
+    and beyond the clip bounds, MSE / MAE as partial sums."""
+    from video_vae_amd import ops
+    from video_vae_amd.loss import HPARAMS, rl_loss_tail_ops
+    g = torch.Generator().manual_seed(b * 100 + t)
+    b2 = 2 * b
+    mask = (torch.rand(b2, t, generator=g) < 0.8).float()
+    mask[0] = 0.0
+    mask[-1] = 1.0
+    sel = torch.rand(b2, t, 1, 1, generator=g)
+    sel.view(-1)[1] = 0.0; sel.view(-1)[2] = 1.0                       # the clip bounds: no gradient there
+    act = (torch.rand(b2, t, 1, 1, generator=g) < sel).float()
+    cols = 3
+    mse_p = torch.rand(b2, cols, generator=g); mae_p = torch.rand(b2, cols, generator=g)
+    kl = torch.rand(b2, generator=g) * 20
+    leaves = [x.to(dev).requires_grad_(True) for x in (mse_p, mae_p, kl, sel)]
+    mk, ak = mask.to(dev), act.to(dev)
+    assert ops.rl_loss_tail_ok(leaves[0], leaves[1], leaves[2], leaves[3], ak, mk)
+    loss, aux = ops.rl_loss_tail(leaves[0], leaves[1], None, leaves[2], leaves[3], ak, mk, HPARAMS)
+    (loss * 2.0).backward()
+    got = [x.grad.clone() for x in leaves]
+    ref = [x.double().requires_grad_(True) for x in (mse_p, mae_p, kl, sel)]
+    mse_r, mae_r = ref[0].sum(1), ref[1].sum(1)
+    rl, ra = rl_loss_tail_ops(mse_r, mae_r, torch.zeros_like(mse_r), ref[2], ref[3], act.double(), mask.double(), HPARAMS)
+    (rl * 2.0).backward()
+    names = ("MSE", "perceptual_loss", "selection_loss", "kl_loss", "kept_frame_density", "mean_trajectory_prob", "rl_loss", "per_sample_MAE")
+    assert_close(loss, rl.detach(), rtol=1e-4, atol=1e-5, what="loss")
+    for a, n in zip(aux, names):
+        assert_close(a, ra[n].detach(), rtol=1e-4, atol=1e-5, what=n)
+    for a, w, what in zip(got, ref, ("d mse", "d mae", "d kl", "d selection")):
+        assert a.shape == w.grad.shape
+        assert_close_scaled(a, w.grad, rel=1e-4, what=what)
+
+
 def _heads_reference(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):
     """The unfused framework path of model.Encoder._trunk / GumbelSigmoidSTE / VideoVAE.forward on the same leaves (bf16 compute)."""
     import torch.nn.functional as F

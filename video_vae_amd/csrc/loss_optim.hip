@@ -249,6 +249,73 @@ __global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __res
     }
 }
 
+// The scalar end of the pair / REINFORCE loss of the rl flavour (reference train/rl_nonadversarial.py:130-186), value and gradients in ONE launch
+// (as framework ops: ~100 kernels on (2b,), (b, 2, t) and scalar tensors in every step).  Samples 2k, 2k + 1 are a pair.
+//   len_i = max(sum_t mask, 1); density_i = sum_t action * mask / len_i; d = density_i - 1 / max_rate; m = d < 0 ? R d : d; sel_loss_i = m^2
+//   psl_i = mse_i + g3 perc_i + g1 sel_loss_i + g2 kl_i + g4 mae_i
+//   pair: mean, population std + 1e-6 -> disadvantage_i = (psl_i - mean) / std                      (no gradient: stop_gradient)
+//   raw_it = clip(|sel_it + action_it - 1|, 1e-6, 1 - 1e-6); probs_i = prod_t raw_it / stop_gradient(raw_it) = 1 (its gradient is what counts)
+//   loss = mean_i psl_i + w mean_i (probs_i disadvantage_i)
+// out[9] = loss, MSE, perceptual, selection_loss, kl_loss, mean density, mean trajectory probability (prod_t of the masked raw_it), rl_loss, MAE.
+// grads = [d / d mse_i | d / d mae_i | d / d perc_i | d / d kl_i | d / d sel_it]  (B2 each, then B2 * T).
+// mse / mae arrive as (B2, cols) partial sums (cols >= 1); perc may be NULL (zeros).  One workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void loss_tail_rl_kernel(const float* __restrict__ mse, const float* __restrict__ mae, int cols,
+                                                          const float* __restrict__ perc, const float* __restrict__ kl,
+                                                          const float* __restrict__ sel, const float* __restrict__ act, const float* __restrict__ mask,
+                                                          int B2, int T, float inv_max_rate, float magnify, float g1, float g2, float g3, float g4,
+                                                          float w, float* __restrict__ out, float* __restrict__ grads)
+{
+    __shared__ float psl[TAIL_MAX_B], ms[TAIL_MAX_B], ma[TAIL_MAX_B], sq[TAIL_MAX_B], dens[TAIL_MAX_B], dis[TAIL_MAX_B], traj[TAIL_MAX_B];
+    const float invB = 1.f / (float)B2;
+    for (int i = threadIdx.x; i < B2; i += 256) {
+        float a = 0.f, c = 0.f;
+        for (int k = 0; k < cols; ++k) { a += mse[(long)i * cols + k]; c += mae[(long)i * cols + k]; }
+        ms[i] = a; ma[i] = c;
+        float len = 0.f, ssum = 0.f, tp = 1.f;
+        for (int t = 0; t < T; ++t) {
+            const float m = mask[i * T + t];
+            len += m; ssum += act[i * T + t] * m;
+            const float raw = fminf(fmaxf(fabsf(sel[i * T + t] + act[i * T + t] - 1.f), 1e-6f), 1.f - 1e-6f);
+            tp *= m != 0.f ? raw : 1.f;
+        }
+        len = fmaxf(len, 1.f);
+        const float density = ssum / len;
+        const float d = density - inv_max_rate;
+        const float mm = d < 0.f ? d * magnify : d;
+        sq[i] = mm * mm; dens[i] = density; traj[i] = tp;
+        psl[i] = a + g3 * (perc ? perc[i] : 0.f) + g1 * sq[i] + g2 * kl[i] + g4 * c;
+        grads[i] = invB; grads[B2 + i] = g4 * invB; grads[2 * B2 + i] = g3 * invB; grads[3 * B2 + i] = g2 * invB;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < B2 / 2; p += 256) {
+        const float x0 = psl[2 * p], x1 = psl[2 * p + 1];
+        const float mean = 0.5f * (x0 + x1);
+        const float sd = sqrtf(0.5f * ((x0 - mean) * (x0 - mean) + (x1 - mean) * (x1 - mean))) + 1e-6f;
+        dis[2 * p] = (x0 - mean) / sd; dis[2 * p + 1] = (x1 - mean) / sd;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B2; i += 256) {
+        const float gi = w * invB * dis[i];
+        for (int t = 0; t < T; ++t) {
+            const float x = sel[i * T + t] + act[i * T + t] - 1.f;
+            const float ax = fabsf(x);
+            const bool inside = ax >= 1e-6f && ax <= 1.f - 1e-6f;           // clamp passes the gradient on [min, max]
+            const float raw = fminf(fmaxf(ax, 1e-6f), 1.f - 1e-6f);
+            const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+            grads[4 * B2 + i * T + t] = (mask[i * T + t] != 0.f && inside) ? gi * sg / raw : 0.f;
+        }
+    }
+    if (threadIdx.x == 0) {
+        float a = 0.f, c = 0.f, pc = 0.f, q = 0.f, k = 0.f, dn = 0.f, tp = 0.f, rl = 0.f, ps = 0.f;
+        for (int i = 0; i < B2; ++i) {
+            a += ms[i]; c += ma[i]; pc += perc ? perc[i] : 0.f; q += sq[i]; k += kl[i]; dn += dens[i]; tp += traj[i]; rl += dis[i]; ps += psl[i];
+        }
+        out[0] = ps * invB + w * rl * invB;
+        out[1] = a * invB; out[2] = pc * invB; out[3] = q * invB; out[4] = k * invB; out[5] = dn * invB; out[6] = tp * invB; out[7] = rl * invB;
+        out[8] = c * invB;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- optimiser
 constexpr int SQN_MAX_BLOCKS = 1024;
 
@@ -401,6 +468,20 @@ extern "C" int vvae_loss_tail_plain(const float* mse_ps, int mse_cols, const flo
         return VVAE_ERR_BAD_ARG;
     hipLaunchKernelGGL(loss_tail_plain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_ps, mse_cols, kl_ps, kl_cols, selection, mask, B, T,
                        1.f / max_compression_rate, magnify_negatives_rate, gamma1, gamma2, out, grads);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// The rl flavour's loss tail (see loss_tail_rl_kernel).  mse, mae fp32 (B2, cols); perc fp32 [B2] or NULL; kl fp32 [B2]; sel (probabilities), act
+// (sampled actions), mask fp32 (B2, T) contiguous; B2 even, <= 1024.  out fp32 [9]; grads fp32 [4 B2 + B2 T].
+extern "C" int vvae_loss_tail_rl(const float* mse, const float* mae, int cols, const float* perc, const float* kl, const float* sel, const float* act,
+                                 const float* mask, int B2, int T, float max_compression_rate, float magnify_negatives_rate, float gamma1,
+                                 float gamma2, float gamma3, float gamma4, float rl_loss_weight, float* out, float* grads, void* stream)
+{
+    if (!mse || !mae || cols <= 0 || !kl || !sel || !act || !mask || !out || !grads || B2 <= 0 || (B2 & 1) || B2 > TAIL_MAX_B || T <= 0 ||
+        !(max_compression_rate > 0.f)) return VVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL(loss_tail_rl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse, mae, cols, perc, kl, sel, act, mask, B2, T,
+                       1.f / max_compression_rate, magnify_negatives_rate, gamma1, gamma2, gamma3, gamma4, rl_loss_weight, out, grads);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

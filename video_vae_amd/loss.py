@@ -49,27 +49,16 @@ def kl_from_model(model, mean, logvar, mask_bt):
     return ops.kl_per_sample(mean, logvar, mask_bt)
 
 
-def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn=None, vgg_params=None, train=True):
-    reconstruction, _comp, selection, selection_mask, logvar, mean = model(video, mask, rngs, train=train)
-    output_mask = original_mask.to(torch.float32).repeat_interleave(2, dim=0)
+def rl_loss_tail_ops(per_sample_error, per_sample_MAE, perceptual_loss, kl_loss, selection, selection_mask, output_mask, hparams):
+    """The scalar end of loss_fn as framework ops (reference train/rl_nonadversarial.py:130-186): the CPU / fallback path, and what
+    ops.rl_loss_tail is tested against."""
     sequence_lengths = torch.clamp(reduce(output_mask, "b time -> b 1", "sum"), min=1.0)
-
-    per_sample_error, per_sample_MAE = ops.masked_mse_mae(video, reconstruction, output_mask, video_div=2)
-    if perceptual_loss_fn is None:
-        perceptual_loss = torch.zeros_like(per_sample_error)
-    elif getattr(perceptual_loss_fn, "takes_target_div", False):
-        perceptual_loss = perceptual_loss_fn(vgg_params, reconstruction, video, target_div=2)      # features of each clip once
-    else:
-        perceptual_loss = perceptual_loss_fn(vgg_params, reconstruction, video.repeat_interleave(2, dim=0))
-
     kl_and_selection_mask = rearrange(output_mask, "b time -> b time 1 1")
     selection_sum = reduce(selection_mask * kl_and_selection_mask, "b time 1 1 -> b 1", "sum")
     kept_frame_density = selection_sum / sequence_lengths
     density_compression_difference = kept_frame_density - (1 / hparams["max_compression_rate"])
     selection_loss = per_sample_mean(torch.square(
         magnify_negatives(density_compression_difference, hparams["magnify_negatives_rate"])))
-
-    kl_loss = kl_from_model(model, mean, logvar, output_mask)
 
     per_sample_loss = (per_sample_error + hparams["gamma3"] * perceptual_loss + hparams["gamma1"] * selection_loss
                        + hparams["gamma2"] * kl_loss + hparams["gamma4"] * per_sample_MAE)
@@ -93,9 +82,36 @@ def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn
     loss = per_sample_loss.mean() + rl_loss.mean() * hparams["rl_loss_weight"]
     return loss, {
         "MSE": per_sample_error.mean(), "perceptual_loss": perceptual_loss.mean(), "selection_loss": selection_loss.mean(),
-        "kl_loss": kl_loss.mean(), "reconstruction": reconstruction, "kept_frame_density": kept_frame_density.mean(),
+        "kl_loss": kl_loss.mean(), "kept_frame_density": kept_frame_density.mean(),
         "mean_trajectory_prob": raw_trajectory_probs.mean(), "rl_loss": rl_loss.mean(), "per_sample_MAE": per_sample_MAE.mean(),
     }
+
+
+def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn=None, vgg_params=None, train=True):
+    reconstruction, _comp, selection, selection_mask, logvar, mean = model(video, mask, rngs, train=train)
+    output_mask = original_mask.to(torch.float32).repeat_interleave(2, dim=0)
+    kl_loss = kl_from_model(model, mean, logvar, output_mask)
+    if perceptual_loss_fn is None and reconstruction.is_cuda:
+        # GPU: the scalar end of this loss (and its backward) as ONE launch instead of ~100 framework kernels on (2b,) / (b, 2, t) tensors; the
+        # per-workgroup partial sums of the MSE / MAE go straight to it (ops.rl_loss_tail adds a sample's up itself)
+        mse_p, mae_p = ops.masked_mse_mae(video, reconstruction, output_mask, video_div=2, partials=True)
+        if ops.rl_loss_tail_ok(mse_p, mae_p, kl_loss, selection, selection_mask, output_mask):
+            loss, (MSE, perc, sel_l, kl_m, dens, traj, rl_m, MAE) = ops.rl_loss_tail(mse_p, mae_p, None, kl_loss, selection, selection_mask, output_mask,
+                                                                                     hparams)
+            return loss, {"MSE": MSE, "perceptual_loss": perc, "selection_loss": sel_l, "kl_loss": kl_m, "reconstruction": reconstruction,
+                          "kept_frame_density": dens, "mean_trajectory_prob": traj, "rl_loss": rl_m, "per_sample_MAE": MAE}
+        per_sample_error, per_sample_MAE = mse_p.sum(1), mae_p.sum(1)
+    else:
+        per_sample_error, per_sample_MAE = ops.masked_mse_mae(video, reconstruction, output_mask, video_div=2)
+    if perceptual_loss_fn is None:
+        perceptual_loss = torch.zeros_like(per_sample_error)
+    elif getattr(perceptual_loss_fn, "takes_target_div", False):
+        perceptual_loss = perceptual_loss_fn(vgg_params, reconstruction, video, target_div=2)      # features of each clip once
+    else:
+        perceptual_loss = perceptual_loss_fn(vgg_params, reconstruction, video.repeat_interleave(2, dim=0))
+    loss, aux = rl_loss_tail_ops(per_sample_error, per_sample_MAE, perceptual_loss, kl_loss, selection, selection_mask, output_mask, hparams)
+    aux["reconstruction"] = reconstruction
+    return loss, aux
 
 
 def loss_fn_plain(model, video, mask, original_mask, rngs, hparams, train=True):

@@ -1392,6 +1392,59 @@ def plain_loss_tail(mse_ps, kl_ps, selection, mask, hparams):
     return loss, aux.unbind(0)
 
 
+class _RlLossTail(torch.autograd.Function):
+    """The scalar end of loss.loss_fn (the rl flavour's pair / REINFORCE loss) in one launch, gradients included (vvae_loss_tail_rl)."""
+
+    @staticmethod
+    def forward(ctx, mse, mae, perc, kl, selection, actions, mask, max_rate, magnify, g1, g2, g3, g4, w):
+        b2, t = mask.shape
+        out = torch.empty((9,), dtype=torch.float32, device=mask.device)
+        grads = torch.empty((4 * b2 + b2 * t,), dtype=torch.float32, device=mask.device)
+        sel = selection.reshape(b2, t).to(torch.float32).contiguous()
+        act = actions.reshape(b2, t).to(torch.float32).contiguous()
+        cols = mse.numel() // b2
+        pc = perc.to(torch.float32).contiguous() if perc is not None else None
+        check(lib().vvae_loss_tail_rl(_p(mse.contiguous()), _p(mae.contiguous()), cols, _p(pc), _p(kl.to(torch.float32).contiguous()), _p(sel), _p(act),
+                                      _p(mask), b2, t, float(max_rate), float(magnify), float(g1), float(g2), float(g3), float(g4), float(w), _p(out),
+                                      _p(grads), _stream()), "vvae_loss_tail_rl")
+        ctx.save_for_backward(grads)
+        ctx.meta = (b2, t, mse.shape, mae.shape, perc is not None, selection.shape, selection.dtype)
+        aux = out[1:]
+        ctx.mark_non_differentiable(aux)
+        ctx.set_materialize_grads(False)
+        return out[0], aux
+
+    @staticmethod
+    def backward(ctx, go, _gaux):
+        if go is None:
+            return (None,) * 14
+        (grads,) = ctx.saved_tensors
+        b2, t, mse_shape, mae_shape, has_perc, sel_shape, sel_dtype = ctx.meta
+        unit = _UNIT_GRAD.get((go.device.type, go.device.index))
+        g = grads if (unit is not None and go.data_ptr() == unit.data_ptr() and go.numel() == 1) else grads * go
+        gmse, gmae = g[:b2], g[b2:2 * b2]
+        if len(mse_shape) == 2:
+            gmse = gmse.unsqueeze(1).expand(mse_shape)
+        if len(mae_shape) == 2:
+            gmae = gmae.unsqueeze(1).expand(mae_shape)
+        return (gmse, gmae, g[2 * b2:3 * b2] if has_perc else None, g[3 * b2:4 * b2], g[4 * b2:].view(sel_shape).to(sel_dtype), None, None,
+                None, None, None, None, None, None, None)
+
+
+def rl_loss_tail_ok(mse, mae, kl, selection, actions, mask):
+    return (mse.is_cuda and all(x.dtype == torch.float32 for x in (mse, mae, kl, mask)) and mask.dim() == 2 and mask.is_contiguous()
+            and mask.shape[0] % 2 == 0 and mask.shape[0] <= 1024 and selection.numel() == mask.numel() and actions.numel() == mask.numel()
+            and mse.dim() in (1, 2) and mse.shape == mae.shape and mse.shape[0] == mask.shape[0] and kl.shape == (mask.shape[0],))
+
+
+def rl_loss_tail(mse, mae, perc, kl, selection, actions, mask, hparams):
+    """-> (loss, (MSE, perceptual_loss, selection_loss, kl_loss, kept_frame_density, mean_trajectory_prob, rl_loss, per_sample_MAE)) of loss.loss_fn from
+    the per-sample sums (``mse`` / ``mae`` may be (2b, chunks) partial sums), the selection probabilities, the sampled actions and the mask."""
+    loss, aux = _RlLossTail.apply(mse, mae, perc, kl, selection, actions, mask, hparams["max_compression_rate"], hparams["magnify_negatives_rate"],
+                                  hparams["gamma1"], hparams["gamma2"], hparams["gamma3"], hparams["gamma4"], hparams["rl_loss_weight"])
+    return loss, aux.unbind(0)
+
+
 # --------------------------------------------------------------------------------------------- encoder heads + latent gate
 class _EncoderHead(torch.autograd.Function):
     """log-variance, selection logits, Gumbel-sigmoid STE, reparameterisation, per-frame KL and the latent gate of the model.py flavour in
