@@ -101,6 +101,15 @@ int vvae_colsum_blocks(long V);   /* rows of vvae_colsum's partial buffer */
 /* out[c] = sum over V rows of x[v][c]; part: fp32 scratch, vvae_colsum_blocks(V) x C floats; two stages, no atomics: bitwise reproducible */
 int vvae_colsum(const void* x, int ld, long V, int C, float* out, float* part, int dtype, void* stream);
 
+/* ---- the rl flavour's latent gate (train/rl_model.py:136-145): pair doubling + Bernoulli frame masks + fill (1 - mask) + z mask, one launch each way.
+ *      z fp32 (B2/2, T, per), prob fp32 (B2/2, T), u fp32 (B2, T), fill fp32 (LD) -> comp bf16 (B2, T, per), mask fp32 (B2, T);
+ *      bwd: dcomp bf16 -> dz fp32 (B2/2, T, per) and vvae_rl_gate_blocks(...) partial rows of d fill (LD floats each).  per = hw * LD. ---- */
+int vvae_rl_gate_ok(int B2, int T, long per, int LD);
+int vvae_rl_gate_blocks(int B2, int T, long per);
+int vvae_rl_gate_fwd(const float* z, const float* prob, const float* u, const float* fill, void* comp, float* mask, int B2, int T, long per,
+                     int LD, void* stream);
+int vvae_rl_gate_bwd(const void* dcomp, const float* mask, float* dz, float* part, int B2, int T, long per, int LD, void* stream);
+
 /* ---- zero-pad (unpad = 0) / cut back (unpad = 1) the last two dims of n <= 8 small contiguous fp32 tensors in one launch: the UNet's
  *      12-channel weights on the 16-channel matrix-core kernels (train/unet.py:98-104).  pad: src (rows, s0, s1) -> dst (rows, d0, d1);
  *      unpad: src (rows, d0, d1) -> dst (rows, s0, s1).  Host arrays of device pointers / ints. ---- */

@@ -1451,6 +1451,33 @@ def test_rl_loss_tail_matches_the_framework_ops(dev, b, t):
         assert_close_scaled(a, w.grad, rel=1e-4, what=what)
 
 
+@pytest.mark.parametrize("b,t,hw,ld", [(2, 3, 16, 96), (1, 4, 256, 96), (3, 2, 10, 8), (2, 2, 4, 64)])
+def test_rl_gate_matches_the_framework_ops(dev, b, t, hw, ld):
+    """ops.rl_gate (pair doubling + Bernoulli frame masks + fill (1 - mask) + z mask of the rl flavour, one launch each way) against the
+    framework ops of rl_model.VideoVAE.forward: the same mask, the same values rounded to the decoder's dtype, the same gradients."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(b * 7 + hw)
+    z = torch.randn(b, t, hw, ld, generator=g).to(dev)
+    prob = torch.rand(b, t, 1, generator=g).to(dev)
+    u = torch.rand(2 * b, t, 1, 1, generator=g).to(dev)
+    fill = (torch.randn(1, 1, 1, ld, generator=g) * 0.02).to(dev)
+    gc = torch.randn(2 * b, t, hw, ld, generator=g).to(dev, torch.bfloat16)
+    assert ops.rl_gate_ok(z, prob, fill)
+    z1, f1 = z.clone().requires_grad_(True), fill.clone().requires_grad_(True)
+    comp1, m1 = ops.rl_gate(z1, prob, u, f1)
+    g1 = torch.autograd.grad(comp1, [z1, f1], gc)
+    z0, f0 = z.clone().requires_grad_(True), fill.clone().requires_grad_(True)
+    sel = prob[..., None].repeat_interleave(2, dim=0)
+    m0 = (u < sel).to(torch.float32)
+    comp0 = (f0 * (1 - m0) + z0.repeat_interleave(2, dim=0) * m0).to(torch.bfloat16)
+    g0 = torch.autograd.grad(comp0, [z0, f0], gc)
+    assert comp1.dtype == torch.bfloat16 and m1.shape == (2 * b, t, 1, 1) and torch.equal(m1, m0)
+    assert 0 < float(m1.sum()) < 2 * b * t
+    assert torch.equal(comp1, comp0)
+    assert_close_scaled(g1[0], g0[0], rel=1e-6, what="dz")
+    assert_close_scaled(g1[1], g0[1], rel=1e-4, what="d fill")
+
+
 def _heads_reference(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):
     """The unfused framework path of model.Encoder._trunk / GumbelSigmoidSTE / VideoVAE.forward on the same leaves (bf16 compute)."""
     import torch.nn.functional as F

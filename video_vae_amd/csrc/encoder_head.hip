@@ -319,3 +319,130 @@ extern "C" int vvae_encoder_head_bwd(const void* mean, const void* v, const void
     VVAE_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- the rl flavour's latent gate (reference train/rl_model.py:136-145): every clip is doubled into a pair (samples 2k, 2k + 1 share z), each
+// member draws its own Bernoulli frame mask from the selection probabilities, and comp = fill (1 - mask) + z mask.  As framework ops:
+// repeat_interleave of the fp32 latent, a comparison, a cast and four elementwise launches over (2b, t, hw, ld) fp32 tensors (50 MB each).
+//   fwd: mask[i][t] = u[i][t] < prob[i / 2][t];  comp[i][t][tok][c] = mask ? z[i / 2][t][tok][c] : fill[c]      (bf16, what the decoder reads)
+//   bwd: dz[k][t][tok][c] = sum_p mask[2k + p][t] dcomp[2k + p][t][tok][c];  d fill[c] = sum over everything of (1 - mask) dcomp
+namespace {
+
+// per = hw * ld elements of a frame (a multiple of 8); grid-stride over the 8-element pieces of comp
+__global__ __launch_bounds__(256) void rl_gate_fwd_kernel(const float* __restrict__ z, const float* __restrict__ prob, const float* __restrict__ u,
+                                                          const float* __restrict__ fill, bf16_t* __restrict__ comp, float* __restrict__ mask_out,
+                                                          int B2, int T, long per, int LD)
+{
+    const long pieces = (long)B2 * T * (per / 8);
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < pieces; it += (long)gridDim.x * 256) {
+        const long e = it * 8, f = e / per, r = e - f * per;                  // frame f = i * T + t of the doubled batch
+        const int i = (int)(f / T), t = (int)(f - (long)i * T);
+        const bool keep = u[f] < prob[(long)(i >> 1) * T + t];
+        if (r == 0) mask_out[f] = keep ? 1.f : 0.f;
+        float o[8];
+        if (keep) {
+            const float* zp = z + ((long)(i >> 1) * T + t) * per + r;
+            const float4 a = *reinterpret_cast<const float4*>(zp), b = *reinterpret_cast<const float4*>(zp + 4);
+            o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+        } else {
+            const int c = (int)(r % LD);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fill[c + k];
+        }
+        VecIO<bf16_t, 8>::store(comp + e, o);
+    }
+}
+
+// grid (blocks, B = B2 / 2): a block walks 8-element pieces of one clip's (t, tok, c) volume; part (gridDim.y * gridDim.x, LD) = its d fill sums.
+// blockDim = the largest multiple of LD / 8 that is <= 256 (252 threads for LD = 96): a thread keeps its channel group.
+__global__ __launch_bounds__(256) void rl_gate_bwd_kernel(const bf16_t* __restrict__ dcomp, const float* __restrict__ mask, float* __restrict__ dz,
+                                                          float* __restrict__ part, int T, long per, int LD, long pieces_per_block)
+{
+    __shared__ float red[256][8];
+    const int k = blockIdx.y;
+    const long pieces = (long)T * (per / 8);
+    const long pbeg = (long)blockIdx.x * pieces_per_block;
+    long pend = pbeg + pieces_per_block;
+    if (pend > pieces) pend = pieces;
+    const int cg = LD / 8;
+    float df[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) df[j] = 0.f;
+    for (long it = pbeg + threadIdx.x; it < pend; it += blockDim.x) {
+        const long e = it * 8;
+        const int t = (int)(e / per);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const long i = 2L * k + p;
+            float g[8];
+            VecIO<bf16_t, 8>::load(dcomp + (i * T) * per + e, g);
+            const bool keep = mask[i * T + t] != 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { if (keep) acc[j] += g[j]; else df[j] += g[j]; }
+        }
+        float* zp = dz + ((long)k * T) * per + e;
+        *reinterpret_cast<float4*>(zp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(zp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    // per-channel sums over the threads that share a channel group (threadIdx.x % cg), fixed order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = df[j];
+    __syncthreads();
+    if ((int)threadIdx.x < cg) {
+        float* pr = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * LD + threadIdx.x * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = 0.f;
+            for (int r = threadIdx.x; r < (int)blockDim.x; r += cg) a += red[r][j];
+            pr[j] = a;
+        }
+    }
+}
+
+inline bool rl_gate_shape(int B2, int T, long per, int LD) { return B2 > 0 && (B2 & 1) == 0 && T > 0 && LD > 0 && LD % 8 == 0 && LD / 8 <= 256 && per > 0 && per % LD == 0; }
+
+}  // namespace
+
+// 1 if the rl gate kernels take the shape (LD a multiple of 8, at most 2048).
+extern "C" int vvae_rl_gate_ok(int B2, int T, long per, int LD) { return rl_gate_shape(B2, T, per, LD) ? 1 : 0; }
+
+// Rows of the d fill partial buffer vvae_rl_gate_bwd writes (each LD floats).
+extern "C" int vvae_rl_gate_blocks(int B2, int T, long per)
+{
+    if (B2 <= 0 || T <= 0 || per <= 0) return 0;
+    long pieces = (long)T * (per / 8), nb = (pieces + 2047) / 2048;
+    const long cap = 2048 / (B2 / 2 > 0 ? B2 / 2 : 1);
+    if (nb > cap) nb = cap > 0 ? cap : 1;
+    return (int)(nb * (B2 / 2));
+}
+
+// z fp32 (B2/2, T, per); prob fp32 (B2/2, T); u fp32 (B2, T) uniform; fill fp32 (LD) -> comp bf16 (B2, T, per), mask fp32 (B2, T).
+extern "C" int vvae_rl_gate_fwd(const float* z, const float* prob, const float* u, const float* fill, void* comp, float* mask, int B2, int T, long per,
+                                int LD, void* stream)
+{
+    if (!z || !prob || !u || !fill || !comp || !mask || !rl_gate_shape(B2, T, per, LD) || ((uintptr_t)z % 16) || ((uintptr_t)comp % 16)) return VVAE_ERR_BAD_ARG;
+    const long pieces = (long)B2 * T * (per / 8);
+    long blocks = (pieces + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rl_gate_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, prob, u, fill, (bf16_t*)comp, mask, B2, T, per, LD);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dcomp bf16 (B2, T, per); mask fp32 (B2, T) from the forward -> dz fp32 (B2/2, T, per), part fp32 (vvae_rl_gate_blocks(...), LD): d fill partial rows.
+extern "C" int vvae_rl_gate_bwd(const void* dcomp, const float* mask, float* dz, float* part, int B2, int T, long per, int LD, void* stream)
+{
+    if (!dcomp || !mask || !dz || !part || !rl_gate_shape(B2, T, per, LD) || ((uintptr_t)dcomp % 16) || ((uintptr_t)dz % 16)) return VVAE_ERR_BAD_ARG;
+    const int B = B2 / 2;
+    const int nbx = vvae_rl_gate_blocks(B2, T, per) / B;
+    const long pieces = (long)T * (per / 8);
+    const int cg = LD / 8, nth = 256 / cg * cg;                     // whole channel-group runs per pass: a thread's channel group stays put
+    long ppb = (pieces + nbx - 1) / nbx;
+    ppb = (ppb + nth - 1) / nth * nth;
+    hipLaunchKernelGGL(rl_gate_bwd_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(nth), 0, (hipStream_t)stream, (const bf16_t*)dcomp, mask, dz, part, T, per,
+                       LD, ppb);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}

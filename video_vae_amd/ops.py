@@ -1525,6 +1525,52 @@ def encoder_head(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):
     return _EncoderHead.apply(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt)
 
 
+# --------------------------------------------------------------------------------------------- the rl flavour's latent gate
+class _RlGate(torch.autograd.Function):
+    """Pair doubling + Bernoulli frame masks + fill * (1 - mask) + z * mask of rl_model.VideoVAE (reference train/rl_model.py:136-145) in one
+    launch each way (vvae_rl_gate_fwd / _bwd) -> (compressed_representation bf16 (2b, t, hw, ld), selection_mask fp32 (2b, t, 1, 1))."""
+
+    @staticmethod
+    def forward(ctx, z, prob, u, fill):
+        b, t, hw, ld = z.shape
+        z = z.contiguous()
+        pr = prob.reshape(b, t).to(torch.float32).contiguous()
+        uu = u.reshape(2 * b, t).to(torch.float32).contiguous()
+        ff = _f32(fill).reshape(-1)
+        comp = torch.empty((2 * b, t, hw, ld), dtype=torch.bfloat16, device=z.device)
+        mask = torch.empty((2 * b, t, 1, 1), dtype=torch.float32, device=z.device)
+        check(lib().vvae_rl_gate_fwd(_p(z), _p(pr), _p(uu), _p(ff), _p(comp), _p(mask), 2 * b, t, hw * ld, ld, _stream()), "vvae_rl_gate_fwd")
+        ctx.save_for_backward(mask)
+        ctx.fill = fill
+        ctx.zshape = z.shape
+        ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)
+        return comp, mask
+
+    @staticmethod
+    def backward(ctx, dcomp, _dmask):
+        if dcomp is None:
+            return None, None, None, None
+        (mask,) = ctx.saved_tensors
+        b, t, hw, ld = ctx.zshape
+        dcomp = dcomp.to(torch.bfloat16).contiguous()
+        dz = torch.empty(ctx.zshape, dtype=torch.float32, device=dcomp.device)
+        part = torch.empty((lib().vvae_rl_gate_blocks(2 * b, t, hw * ld), ld), dtype=torch.float32, device=dcomp.device)
+        check(lib().vvae_rl_gate_bwd(_p(dcomp), _p(mask), _p(dz), _p(part), 2 * b, t, hw * ld, ld, _stream()), "vvae_rl_gate_bwd")
+        dfill, _ = fold_partials(part, ctx.fill, None, ld)
+        return dz, None, None, (None if dfill is None else dfill.reshape(ctx.fill.shape).to(ctx.fill.dtype))
+
+
+def rl_gate_ok(z, prob, fill):
+    return (z.is_cuda and z.dim() == 4 and z.dtype == torch.float32 and fill.numel() == z.shape[-1] and fill.dtype == torch.float32
+            and prob.numel() == z.shape[0] * z.shape[1] and lib().vvae_rl_gate_ok(2 * z.shape[0], z.shape[1], z.shape[2] * z.shape[3], z.shape[3]) == 1)
+
+
+def rl_gate(z, prob, u, fill):
+    """-> (comp bf16 (2b, t, hw, ld), selection_mask fp32 (2b, t, 1, 1)): samples 2k, 2k + 1 share z[k]; mask = u < prob[k]."""
+    return _RlGate.apply(z, prob, u, fill)
+
+
 # --------------------------------------------------------------------------------------------- LayerNorm
 def _rows2(x):
     """x (..., C) as rows with two-level strides: row r at (r // inner) * outer_pitch + (r % inner) * inner_pitch.

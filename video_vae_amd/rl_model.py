@@ -44,15 +44,23 @@ class VideoVAE(nn.Module):
             sampled_latent, kl = ops.reparameterise_kl(mean, log_variance, noise, frame_mask(mask, mean.shape[0], mean.shape[1]))
         else:
             sampled_latent = mean
+        prob = selection
         selection = rearrange(selection, "b t 1 -> b t 1 1").repeat_interleave(2, dim=0)
-        sampled_latent = sampled_latent.repeat_interleave(2, dim=0)
+        fused = (self.decoder.dtype == torch.bfloat16 and ops.rl_gate_ok(sampled_latent, prob, self.fill_token))
+        if not fused:
+            sampled_latent = sampled_latent.repeat_interleave(2, dim=0)
         mean = mean.repeat_interleave(2, dim=0)
         log_variance = log_variance.repeat_interleave(2, dim=0)
         if kl is not None:                                  # both members of a pair share mean / log-variance / mask: same KL term
             self._kl = (mean, log_variance, kl.repeat_interleave(2, dim=0))
         mask = mask.repeat_interleave(2, dim=0)
         u = rngs.draw("bernoulli_u", "uniform", selection.shape, selection.device)
-        selection_mask = (u < selection).to(sampled_latent.dtype)
-        compressed_representation = self.fill_token * (1 - selection_mask) + sampled_latent * selection_mask
+        if fused:
+            # GPU train step: doubling, the Bernoulli masks and the gate in one launch; comp holds the decoder's compute dtype (the
+            # reference's fp32 sum rounded once, which is what its decoder's first Linear does to it)
+            compressed_representation, selection_mask = ops.rl_gate(sampled_latent, prob, u, self.fill_token)
+        else:
+            selection_mask = (u < selection).to(sampled_latent.dtype)
+            compressed_representation = self.fill_token * (1 - selection_mask) + sampled_latent * selection_mask
         reconstruction = self.decoder(compressed_representation, mask, rngs, train=train)
         return reconstruction, compressed_representation, selection, selection_mask, log_variance, mean
