@@ -105,6 +105,8 @@ class GraphedTrainStep:
             self.bucket_stage = [max(pstage[i] for i in members) for members in optimizer.bucket_params]
         self.video = video.clone()
         self.mask = mask.clone()
+        if video.is_cuda:
+            ops.unit_grad(video)                 # the constant root gradient exists before anything is captured (never allocated from a graph's pool)
         self.rl = L._is_rl(model)
         self.noise = {}
         self.graph = None
