@@ -127,6 +127,9 @@ int vvae_conv_pointwise_fwd_add(const void* x, int ldx, const float* w, const fl
                                 long V, int Cin, int Cout, int dtype, void* stream);
 int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, long V, int Cin, int Cout, int dtype,
                               void* stream);
+/* dx = addend + dy W^T (addend: V rows of Cin channels, pitch ldadd, or NULL): the gradient of the tensor's other consumer joins inside the launch */
+int vvae_conv_pointwise_dgrad_add(const void* dy, int lddy, const float* w, const void* addend, int ldadd, void* dx, int lddx, long V, int Cin,
+                                  int Cout, int dtype, void* stream);
 int vvae_conv_pointwise_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, long V, int Cin, int Cout,
                               int dtype, void* ws, size_t ws_bytes, void* stream);
 

@@ -1642,6 +1642,33 @@ def test_pointwise_conv_with_addend(dev):
         assert_close_scaled(a.float(), w.float(), rel=1e-5, what=what)
 
 
+def test_pointwise_conv_fork_adds_the_other_gradient(dev):
+    """ops.conv3d_pointwise_fork: (conv1x1x1(x), x) from one node; the gradient of x's other consumer is added inside the projection's
+    input-gradient launch.  Against the plain conv + autograd's own accumulation."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(12)
+    bf = torch.bfloat16
+    x = torch.randn(2, 3, 16, 24, 16, generator=g).to(dev, bf)
+    k = (torch.randn(1, 1, 1, 16, 3, generator=g) * 0.3).to(dev).requires_grad_(True)
+    b = torch.randn(3, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(2, 3, 16, 24, 3, generator=g).to(dev, bf)
+    go = torch.randn(2, 3, 16, 24, 16, generator=g).to(dev, bf)
+    x1 = x.clone().requires_grad_(True)
+    assert ops.conv3d_pointwise_fork_ok(x1, k)
+    y1, xa = ops.conv3d_pointwise_fork(x1, k, b)
+    g1 = torch.autograd.grad([y1, xa * 1.0], [x1, k, b], [gy, go])
+    x0 = x.clone().requires_grad_(True)
+    y0 = ops.conv3d(x0, k, b)
+    g0 = torch.autograd.grad([y0, x0 * 1.0], [x0, k, b], [gy, go])
+    assert torch.equal(y1, y0) and torch.equal(xa, x)
+    assert torch.equal(g1[0], g0[0])                                # round(dy W^T) + other, rounded: the same two roundings
+    assert torch.equal(g1[1], g0[1]) and torch.equal(g1[2], g0[2])
+    # only one consumer's gradient arrives: the other side is None
+    (gx,) = torch.autograd.grad(ops.conv3d_pointwise_fork(x1, k, b)[0], x1, gy)
+    (gx0,) = torch.autograd.grad(ops.conv3d(x0, k, b), x0, gy)
+    assert torch.equal(gx, gx0)
+
+
 def test_conv_transpose_prepacked_weights(dev):
     """ops.convt_prepack (both packings of every up-conv kernel in one launch, once per step) gives bitwise the results of the per-call
     packing, forward and input gradient, at the three decoder shapes."""

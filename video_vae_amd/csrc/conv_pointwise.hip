@@ -65,8 +65,11 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const T_* __restrict__ x, c
     }
 }
 
+// addend (row pitch ldadd) != nullptr: dx = addend + dy W^T -- the gradient arriving at the same tensor from its other consumer (the features feed
+// the UNet AND the coarse projection, reference train/layers.py:60-79 / train/model.py:95-97) joins here instead of in a 134 MB add launch.
 template <typename T_, int CIN, int COUT>
-__global__ __launch_bounds__(256) void pw_dgrad_kernel(const T_* __restrict__ dy, const float* __restrict__ w, T_* __restrict__ dx, PwDims d)
+__global__ __launch_bounds__(256) void pw_dgrad_kernel(const T_* __restrict__ dy, const float* __restrict__ w, T_* __restrict__ dx, PwDims d,
+                                                       const T_* __restrict__ addend = nullptr, int ldadd = 0)
 {
     float wr[CIN][COUT];
 #pragma unroll
@@ -83,6 +86,12 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const T_* __restrict__ dy
 #pragma unroll
             for (int co = 0; co < COUT; ++co) a += g[co] * wr[ci][co];
             o[ci] = a;
+        }
+        if (addend) {
+            float ad[CIN];
+            load_vox<T_, CIN>(addend + v * ldadd, ad);
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) o[ci] = round_to<T_>(o[ci]) + ad[ci];          // as the separate add saw the rounded input gradient
         }
         store_vox<T_, CIN>(dx + v * d.ldx, o);
     }
@@ -171,22 +180,30 @@ extern "C" int vvae_conv_pointwise_fwd(const void* x, int ldx, const float* w, c
     return vvae_conv_pointwise_fwd_add(x, ldx, w, bias, nullptr, 0, y, ldy, V, Cin, Cout, dtype, stream);
 }
 
-extern "C" int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, long V, int Cin, int Cout, int dtype,
-                                         void* stream)
+// addend (V rows of Cin channels, row pitch ldadd, same dtype) may be NULL; otherwise dx = addend + dy W^T.
+extern "C" int vvae_conv_pointwise_dgrad_add(const void* dy, int lddy, const float* w, const void* addend, int ldadd, void* dx, int lddx, long V, int Cin,
+                                             int Cout, int dtype, void* stream)
 {
-    if (!dy || !w || !dx || V <= 0 || lddy < Cout || !vvae_conv_pointwise_supported(Cin, Cout, 1, 1, 1, lddx, dtype, dx)) return VVAE_ERR_BAD_ARG;
+    if (!dy || !w || !dx || V <= 0 || lddy < Cout || (addend && (ldadd < Cin || ldadd % 4 || ((uintptr_t)addend % 8))) ||
+        !vvae_conv_pointwise_supported(Cin, Cout, 1, 1, 1, lddx, dtype, dx)) return VVAE_ERR_BAD_ARG;
     PwDims d{V, lddx, lddy};
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pw_blocks(V) * 4 > (V + 255) / 256 ? (unsigned)((V + 255) / 256) : (unsigned)(pw_blocks(V) * 4));
     if (dtype == VVAE_DT_F32) {
-        if (Cin == 16) hipLaunchKernelGGL((pw_dgrad_kernel<float, 16, 3>), grid, dim3(256), 0, s, (const float*)dy, w, (float*)dx, d);
-        else hipLaunchKernelGGL((pw_dgrad_kernel<float, 12, 3>), grid, dim3(256), 0, s, (const float*)dy, w, (float*)dx, d);
+        if (Cin == 16) hipLaunchKernelGGL((pw_dgrad_kernel<float, 16, 3>), grid, dim3(256), 0, s, (const float*)dy, w, (float*)dx, d, (const float*)addend, ldadd);
+        else hipLaunchKernelGGL((pw_dgrad_kernel<float, 12, 3>), grid, dim3(256), 0, s, (const float*)dy, w, (float*)dx, d, (const float*)addend, ldadd);
     } else {
-        if (Cin == 16) hipLaunchKernelGGL((pw_dgrad_kernel<bf16_t, 16, 3>), grid, dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, d);
-        else hipLaunchKernelGGL((pw_dgrad_kernel<bf16_t, 12, 3>), grid, dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, d);
+        if (Cin == 16) hipLaunchKernelGGL((pw_dgrad_kernel<bf16_t, 16, 3>), grid, dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, d, (const bf16_t*)addend, ldadd);
+        else hipLaunchKernelGGL((pw_dgrad_kernel<bf16_t, 12, 3>), grid, dim3(256), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, d, (const bf16_t*)addend, ldadd);
     }
     VVAE_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vvae_conv_pointwise_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, long V, int Cin, int Cout, int dtype,
+                                         void* stream)
+{
+    return vvae_conv_pointwise_dgrad_add(dy, lddy, w, nullptr, 0, dx, lddx, V, Cin, Cout, dtype, stream);
 }
 
 // dw: (Cin, Cout) fp32 overwritten; dbias (Cout) fp32 or NULL.  ws: vvae_conv_pointwise_ws_bytes(V, Cin, Cout) bytes.

@@ -406,7 +406,13 @@ class PatchUnEmbedding(nn.Module):
         ds = self.downsample
         extra_t, extra_s = more_pads if more_pads is not None else ([], [])
         kd, *extra = ops.pad_last2_group([ds.kernel] + list(extra_t), [(cu + pad, ds.kernel.shape[1])] + list(extra_s))   # one launch each way
-        coarse = ops.conv3d(feat.to(ds.dtype), kd.view(1, 1, 1, *kd.shape), ds.bias)
+        feat = feat.to(ds.dtype)
+        k5 = kd.view(1, 1, 1, *kd.shape)
+        if ops.conv3d_pointwise_fork_ok(feat, k5):
+            # the features go on to the UNet through this node: the UNet's gradient joins the projection's inside one launch
+            coarse, feat = ops.conv3d_pointwise_fork(feat, k5, ds.bias)
+        else:
+            coarse = ops.conv3d(feat, k5, ds.bias)
         return (feat, coarse) if more_pads is None else (feat, coarse, tuple(extra))
 
     def forward(self, x):

@@ -466,6 +466,51 @@ class _PointwiseAdd(torch.autograd.Function):
         return dx, dw, db, dy
 
 
+class _PointwiseFork(torch.autograd.Function):
+    """(conv1x1x1(x), x) from one node, for a tensor with a second consumer (the un-patchified features feed the coarse projection AND the
+    UNet, reference train/layers.py:60-79, train/model.py:95-97): the other consumer's gradient reaches THIS backward and is added inside
+    the input-gradient launch (vvae_conv_pointwise_dgrad_add) instead of by the engine's 134 MB accumulation launch."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        k32 = _f32(kernel)
+        b32 = _f32(bias) if bias is not None else None
+        ctx.save_for_backward(x, k32)
+        ctx.has_bias = bias is not None
+        ctx.kdtype = kernel.dtype
+        ctx.set_materialize_grads(False)
+        return conv3d_fwd_raw(x, k32, b32), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dother):
+        x, k32 = ctx.saved_tensors
+        if dy is None:
+            return dother, None, None
+        dy = dy.to(x.dtype)
+        xr, ldx = rows(x)
+        dyr, lddy = rows(dy)
+        cin, cout = k32.shape[-2], k32.shape[-1]
+        vox = xr.numel() // cin
+        dx = torch.empty(xr.shape, dtype=xr.dtype, device=xr.device)
+        ad, lda = (None, 0) if dother is None else rows(dother.to(x.dtype))
+        check(lib().vvae_conv_pointwise_dgrad_add(_p(dyr), lddy, _p(k32), _p(ad), lda, _p(dx), dx.stride(-2), vox, cin, cout, _dt(xr), _stream()),
+              "vvae_conv_pointwise_dgrad_add")
+        dw, db = conv3d_wgrad_raw(x, dy, tuple(k32.shape), ctx.has_bias)
+        return dx, dw.to(ctx.kdtype), db
+
+
+def conv3d_pointwise_fork_ok(x, kernel):
+    kt, kh, kw, cin, cout = kernel.shape
+    return (x.is_cuda and not _FORCE_GENERIC[0] and x.dtype in DT and x.shape[-1] == cin and x.is_contiguous()
+            and lib().vvae_conv_pointwise_supported(cin, cout, kt, kh, kw, x.stride(-2), DT[x.dtype], _p(x)) == 1)
+
+
+def conv3d_pointwise_fork(x, kernel, bias):
+    """-> (conv3d(x, kernel (1,1,1,Cin,Cout), bias), x): use the returned x for the tensor's other consumer, whose gradient then joins inside
+    the projection's input-gradient launch."""
+    return _PointwiseFork.apply(x, kernel, bias)
+
+
 def conv3d_pointwise_add_ok(x, kernel, addend):
     kt, kh, kw, cin, cout = kernel.shape
     return (x.is_cuda and not _FORCE_GENERIC[0] and x.dtype == addend.dtype and x.dtype in DT and x.shape[-1] == cin
