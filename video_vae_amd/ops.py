@@ -1357,7 +1357,11 @@ class _MaskedMseMae(torch.autograd.Function):
             return None, None, None, None, None
         b, t = recon.shape[0], recon.shape[1]
         p = recon.numel() // (b * t)
-        # partial-sum outputs: every partial of a sample carries the sample's gradient (a stride-0 expansion): column 0 is it
+        # partial-sum outputs: every partial of a sample carries the sample's gradient (a stride-0 expansion, what a plain sum over the
+        # partials or the loss tails hand back): column 0 is it.  Anything else (partials weighted differently) is not what this op supports.
+        for gg in (gmse, gmae):
+            if gg is not None and gg.dim() == 2 and gg.shape[1] > 1 and gg.stride(1) != 0:
+                raise VvaeError("masked_mse_mae(partials=True): the partial sums of a sample must enter the loss through their plain sum")
         gmse = (gmse[:, 0] if gmse.dim() == 2 else gmse).to(torch.float32).contiguous() if gmse is not None else None
         gmae = (gmae[:, 0] if gmae.dim() == 2 else gmae).to(torch.float32).contiguous() if gmae is not None else None
         dr = torch.empty_like(recon)
