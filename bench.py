@@ -117,6 +117,10 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-launch HIP-event leg (roofline / kernels / conv_stack): for profiler passes over this script, where "
                          "every extra step is minutes of serialised dispatches")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the secondary block `also` (short runs of the reference driver's own flavour -- rl_model -- and of config C5's per-GPU "
+                         "shape, after the headline's timed region)")
+    ap.add_argument("--also-steps", type=int, default=8, help="timed steps of each secondary run")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames per clip of the bounded CPU sample")
     ap.add_argument("--cpu-clips", type=int, default=1, help="clips of the bounded CPU sample")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the CPU baseline leg may take (steps are cut to fit)")
@@ -247,6 +251,51 @@ def cpu_baseline(args):
                       f"{s}x{s}x3, median {t_vae:.2f} s/step on {threads} threads",
             "unet_only": {"value": nb * t / t_unet, "unit": "frames/s", "protocol": f"{proto_unet} steps, median",
                           "sample": f"oracle UNet fwd+bwd, fp32, {nb} clip(s) x {t} frames x {s}x{s}x12 features, median {t_unet:.2f} s/step"}}
+
+
+def also_runs(args, dev, dtype):
+    """The secondary block of the JSON line: what the headline does not show but the reference driver runs.
+      rl_flavour -- train/rl_nonadversarial.py:6 builds rl_model.VideoVAE (pair-doubled decoder, Bernoulli frame masks, REINFORCE term), not
+                    the model.py flavour the metric is quoted on: same shape as the headline, the rl loss;
+      c5_shape   -- BASELINE.json configs[4] per GPU: B=2 clips of 3x32x256x256 (temporal attention over T=32), model.py flavour.
+    Short runs (2 warm-up + --also-steps timed graph replays, median of per-step HIP events), started only after the headline's timed
+    region and kernel-timing leg are over and its model is freed, so they cannot perturb it.  A failure is reported, never raised."""
+    import copy
+    import gc
+    import statistics
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, optim
+    from video_vae_amd.graph import GraphedTrainStep
+    out = {}
+    for name, flavour, B, T in (("rl_flavour", "rl", args.batch, args.frames), ("c5_shape", "model", 2, 32)):
+        try:
+            a = copy.copy(args)
+            a.flavour, a.batch, a.frames, a.workload = flavour, B, T, "vae"
+            model, cfg = build_model(a, dev, dtype)
+            opt = optim.Optimizer(model, optim.reference_schedule(batch_size=B))
+            g = torch.Generator().manual_seed(0)
+            video = torch.rand((B, T, a.size, a.size, 3), generator=g).to(dev, dtype)
+            mask = torch.ones((B, T), device=dev)
+            step = GraphedTrainStep(model, opt, video, mask, L.HPARAMS, (a.size // cfg["patch_size"]) ** 2, V.Rngs(3), warmup=1)
+            for _ in range(2):
+                loss, _aux = step()
+            torch.cuda.synchronize()
+            k = max(1, args.also_steps)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+            for i in range(k):
+                evs[i].record()
+                loss, _aux = step()
+            evs[k].record()
+            torch.cuda.synchronize()
+            ms = statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(k))
+            out[name] = {"ms_per_step": ms, "frames_per_s": B * T / (ms * 1e-3), "graph_nodes": step.census, "steps": k, "finite": bool(torch.isfinite(loss)),
+                         "workload": f"{'rl_model' if flavour == 'rl' else 'model'}.VideoVAE train step, B={B} x 3x{T}x{a.size}x{a.size}, {args.dtype}, graph replay"}
+            del step, opt, model, video, mask, loss, _aux
+        except Exception as e:                                   # secondary figures: never take the headline down with them
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(n):
@@ -531,6 +580,13 @@ def main():
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                     print(f"# {k:44s} n={v['n']:3d} avg {v['avg_ms']:8.3f} ms  {v['bytes'] / v['avg_ms'] / 1e6:8.1f} GB/s "
                           f"{v['flops'] / v['avg_ms'] / 1e9:8.1f} TF/s", file=sys.stderr)
+        if world == 1 and not ddp_on and not args.no_also and args.workload == "vae" and graphed and (args.flavour, B, T, S) == ("model", 4, 16, 256):
+            # free the headline's model first: the secondary runs start from an empty card and after everything the headline measures
+            import gc
+            step = eager_step = gstep = model = opt = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["also"] = also_runs(args, dev, dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

@@ -165,6 +165,8 @@ int vvae_loss_tail_rl(const float* mse, const float* mae, int cols, const float*
  *      -> dmean, dv bf16; one partial row per frame of part1 (B T, LD) = dW1, part2 (B T, HW) = dW2, part3 (B T, LD) = d fill and
  *      partb (2, B T, 4) = [db1 0 0 0] rows, then [db2 0 0 0] rows.  HW % 4 == 0, LD % 8 == 0; mask_pitch 0 = one mask row for all samples. ---- */
 int vvae_encoder_head_ok(int B, int T, int HW, int LD);
+/* attribution hook (tests / tools): bit 0 keeps d logits, bit 1 keeps d s1 in fp32 instead of the backward's bf16 rounding points; 0 = shipped */
+int vvae_encoder_head_debug(int flags);
 int vvae_encoder_head_fwd(const void* mean, const void* v, const float* w1, const float* b1, const float* w2, const float* b2,
                           const float* u, const float* eps, const float* mask, long mask_pitch, const float* fill, void* logvar,
                           void* comp, float* sel, float* y, float* s1, float* kl_frame, int B, int T, int HW, int LD, void* stream);

@@ -44,12 +44,9 @@ class VAEConfig:
         return self.last_dim // self.spatial_compression_rate
 
 
-def encoder(p, cfg, x, mask, gumbel_u=None, train=True, flavour="model", dtype=O.F32):
-    """Encoder.__call__.  model.py:49-60 (Gumbel-STE gate) | rl_model.py:50-60 (sigmoid prob)."""
-    x = L.patch_embedding(sub(p, "patch_embedding"), x, cfg.patch_size, dtype)
-    for i in range(cfg.encoder_depth):
-        x = L.factored_attention(sub(p, f"layers.{i}"), x, mask, cfg.num_heads,
-                                 cfg.max_temporal_len, cfg.hw, dtype)
+def encoder_heads(p, x, gumbel_u=None, train=True, flavour="model", dtype=O.F32):
+    """What Encoder.__call__ does behind its last block: the mean / variance heads and the two selection layers.
+    model.py:53-59 (Gumbel-STE gate) | rl_model.py:53-59 (sigmoid probability).  ``x`` (b, t, hw, c) -> (mean, log_variance, selection)."""
     mean = O.linear(x, p["spatial_compression.kernel"], p["spatial_compression.bias"], dtype)
     variance = O.softplus(O.linear(x, p["variance_estimator.kernel"], p["variance_estimator.bias"], dtype))
     log_variance = O.q(torch.log(O.q(variance, dtype)), dtype)
@@ -64,6 +61,15 @@ def encoder(p, cfg, x, mask, gumbel_u=None, train=True, flavour="model", dtype=O
     return mean, log_variance, sel
 
 
+def encoder(p, cfg, x, mask, gumbel_u=None, train=True, flavour="model", dtype=O.F32):
+    """Encoder.__call__.  model.py:49-60 (Gumbel-STE gate) | rl_model.py:50-60 (sigmoid prob)."""
+    x = L.patch_embedding(sub(p, "patch_embedding"), x, cfg.patch_size, dtype)
+    for i in range(cfg.encoder_depth):
+        x = L.factored_attention(sub(p, f"layers.{i}"), x, mask, cfg.num_heads,
+                                 cfg.max_temporal_len, cfg.hw, dtype)
+    return encoder_heads(p, x, gumbel_u, train, flavour, dtype)
+
+
 def decoder(p, cfg, x, mask, dtype=O.F32):
     """Decoder.__call__: Linear -> N x FactoredAttention -> un-patchify -> coarse + UNet(feat).  model.py:90-97."""
     x = O.linear(x, p["spatial_decompression.kernel"], p["spatial_decompression.bias"], dtype)
@@ -75,18 +81,31 @@ def decoder(p, cfg, x, mask, dtype=O.F32):
     return O.q(coarse + U.unet(sub(p, "unet"), feat, dtype), dtype)
 
 
-def reparameterise(mean, log_variance, eps, train=True):
-    """z = mean + eps * exp(log_var / 2) if train else mean.  model.py:124-131."""
+def reparameterise(mean, log_variance, eps, train=True, dtype=O.F32):
+    """z = mean + eps * exp(log_var / 2) if train else mean.  model.py:124-131.
+
+    Mixed precision: ``std = jnp.exp(log_variance / 2)`` is an array of the compute dtype (log_variance is; the halving is exact),
+    ``noise`` is jax.random.normal's default float32, so ``noise * std`` and the sum promote to float32 (model.py:124-126)."""
     if not train:
         return mean
-    return mean + eps * torch.exp(log_variance / 2)
+    return mean + eps * O.q(torch.exp(log_variance / 2), dtype)
+
+
+def latent_gate(fill_token, selection, z):
+    """compressed_representation = fill_token * (1 - selection) + sampled_latent * selection.  model.py:133 | rl_model.py:144."""
+    return fill_token * (1 - selection) + z * selection
+
+
+def bernoulli_mask(selection, u):
+    """jax.random.bernoulli(key, p=selection) with the uniform draw handed in: u < p.  rl_model.py:141-142."""
+    return u < selection
 
 
 def video_vae(p, cfg, x, mask, noise, train=True, dtype=O.F32):
     """VideoVAE.__call__ of train/model.py:119-136 -> 5-tuple."""
     mean, logvar, sel = encoder(sub(p, "encoder"), cfg, x, mask, noise.get("gumbel_u"), train, "model", dtype)
-    z = reparameterise(mean, logvar, noise.get("reparam_eps"), train)
-    comp = p["fill_token"] * (1 - sel) + z * sel                          # model.py:133
+    z = reparameterise(mean, logvar, noise.get("reparam_eps"), train, dtype)
+    comp = latent_gate(p["fill_token"], sel, z)                           # model.py:133
     recon = decoder(sub(p, "decoder"), cfg, comp, mask, dtype)
     return recon, comp, sel, logvar, mean
 
@@ -94,14 +113,14 @@ def video_vae(p, cfg, x, mask, noise, train=True, dtype=O.F32):
 def video_vae_rl(p, cfg, x, mask, noise, train=True, dtype=O.F32):
     """VideoVAE.__call__ of train/rl_model.py:119-147 -> 6-tuple (pair-doubled batch)."""
     mean, logvar, sel = encoder(sub(p, "encoder"), cfg, x, mask, None, train, "rl", dtype)
-    z = reparameterise(mean, logvar, noise.get("reparam_eps"), train)
+    z = reparameterise(mean, logvar, noise.get("reparam_eps"), train, dtype)
     sel = rearrange(sel, "b t 1 -> b t 1 1").repeat_interleave(2, dim=0)  # :136
     z = z.repeat_interleave(2, dim=0)                                    # :137
     mean = mean.repeat_interleave(2, dim=0)
     logvar = logvar.repeat_interleave(2, dim=0)
     mask = mask.repeat_interleave(2, dim=0)                              # :140
-    sel_mask = (noise["bernoulli_u"] < sel).to(z.dtype)                  # :142 bernoulli(p=selection)
-    comp = p["fill_token"] * (1 - sel_mask) + z * sel_mask               # :144
+    sel_mask = bernoulli_mask(sel, noise["bernoulli_u"]).to(z.dtype)     # :142 bernoulli(p=selection)
+    comp = latent_gate(p["fill_token"], sel_mask, z)                     # :144
     recon = decoder(sub(p, "decoder"), cfg, comp, mask, dtype)
     return recon, comp, sel, sel_mask, logvar, mean
 

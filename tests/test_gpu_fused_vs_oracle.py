@@ -1,0 +1,190 @@
+"""The round-3 fusion kernels against the ORACLE (VERDICT r03 weak #5 / next #3e): tests/test_gpu_ops.py compares them with the framework
+ops they replaced on the GPU (`..._matches_the_framework_ops`); here the same four kernels meet oracle.model / oracle.loss on the CPU.
+
+  * vvae_loss_tail_plain behind masked MSE + KL    vs  oracle.loss.loss_fn_plain   (legacy/training_loop_adversarial.py:90-124)
+  * vvae_loss_tail_rl behind masked MSE/MAE + KL   vs  oracle.loss.loss_fn_rl      (train/rl_nonadversarial.py:100-186)
+  * vvae_rl_gate_fwd / _bwd                        vs  oracle.model.bernoulli_mask + latent_gate (train/rl_model.py:136-144)
+  * vvae_encoder_head_fwd / _bwd                   vs  oracle.model.encoder_heads + reparameterise + latent_gate + oracle.loss.kl_per_sample
+                                                       (train/model.py:53-59,121-133; train/layers.py:226-252)
+"""
+import pytest
+import torch
+
+from oracle import loss as OLoss
+from oracle import model as OM
+from test_gpu_parity_r2 import BF16_FACTOR, BF16_FLOOR, rel_l2
+from util import assert_close, assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+ONE_BF16_ROUNDING = 2.0 ** -8      # largest relative error of rounding ONE number to bf16 (8 significant bits, round to nearest)
+
+
+def _masks(b, t, g):
+    mask = (torch.rand(b, t, generator=g) < 0.75).float()
+    mask[:, 0] = 1.0
+    mask[-1] = 1.0
+    return mask
+
+
+@pytest.mark.parametrize("b,t", [(4, 16), (3, 5)])
+def test_plain_loss_path_vs_oracle(dev, b, t):
+    """ops.masked_mse_mae(partials) -> ops.kl_per_sample -> ops.plain_loss_tail (what loss.loss_fn_plain launches) on fp32 tensors against
+    oracle.loss.loss_fn_plain: loss, the three logged terms, density, and the gradients at recon / mean / log_variance / selection."""
+    from video_vae_amd import ops
+    from video_vae_amd.loss import HPARAMS
+    g = torch.Generator().manual_seed(31 + b)
+    video = torch.rand(b, t, 8, 12, 3, generator=g)
+    recon = video + 0.2 * torch.randn(b, t, 8, 12, 3, generator=g)
+    mean = 0.5 * torch.randn(b, t, 6, 16, generator=g)
+    lv = 0.3 * torch.randn(b, t, 6, 16, generator=g)
+    sel = torch.rand(b, t, 1, 1, generator=g)
+    mask = _masks(b, t, g)
+    ro, mo, lo, so = (x.clone().requires_grad_(True) for x in (recon, mean, lv, sel))
+    loss_o, aux_o = OLoss.loss_fn_plain((ro, None, so, lo, mo), video, mask)
+    loss_o.backward()
+    rg, mg, lg, sg = (x.to(dev).requires_grad_(True) for x in (recon, mean, lv, sel))
+    mk = mask.to(dev)
+    mse_p, _ = ops.masked_mse_mae(video.to(dev), rg, mk, 1, True)
+    kl = ops.kl_per_sample(mg, lg, mk)
+    assert ops.plain_loss_tail_ok(mse_p, kl, sg, mk)
+    loss_g, (MSE, sl, klm, dens) = ops.plain_loss_tail(mse_p, kl, sg, mk, HPARAMS)
+    loss_g.backward()
+    assert_close(loss_g, loss_o, rtol=1e-5, atol=1e-6, what="loss")
+    for a, k in ((MSE, "MSE"), (sl, "selection_loss"), (klm, "kl_loss"), (dens, "kept_frame_density")):
+        assert_close(a, aux_o[k], rtol=1e-5, atol=1e-6, what=k)
+    for a, w, what in ((rg, ro, "d recon"), (mg, mo, "d mean"), (lg, lo, "d log_variance"), (sg, so, "d selection")):
+        assert_close_scaled(a.grad, w.grad, rel=1e-5, what=what)
+
+
+@pytest.mark.parametrize("b,t", [(2, 16), (3, 4)])
+def test_rl_loss_path_vs_oracle(dev, b, t):
+    """ops.masked_mse_mae(video_div=2, partials) -> ops.kl_per_sample -> ops.rl_loss_tail (what loss.loss_fn launches for the pair-doubled
+    outputs) against oracle.loss.loss_fn_rl: every logged term and the gradients at recon / mean / log_variance / selection."""
+    from video_vae_amd import ops
+    from video_vae_amd.loss import HPARAMS
+    g = torch.Generator().manual_seed(77 + b)
+    b2 = 2 * b
+    video = torch.rand(b, t, 8, 8, 3, generator=g)
+    recon = video.repeat_interleave(2, 0) + 0.2 * torch.randn(b2, t, 8, 8, 3, generator=g)
+    mean = (0.5 * torch.randn(b, t, 5, 8, generator=g)).repeat_interleave(2, 0)
+    lv = (0.3 * torch.randn(b, t, 5, 8, generator=g)).repeat_interleave(2, 0)
+    sel = torch.rand(b, t, 1, 1, generator=g).clamp(0.05, 0.95).repeat_interleave(2, 0)
+    act = (torch.rand(b2, t, 1, 1, generator=g) < sel).float()
+    act[0::2, 0], act[1::2, 0] = 1.0, 0.0                       # the members of a pair differ: a well-conditioned (loss - mean) / std
+    mask = _masks(b, t, g)
+    ro, mo, lo, so = (x.clone().requires_grad_(True) for x in (recon, mean, lv, sel))
+    loss_o, aux_o = OLoss.loss_fn_rl((ro, None, so, act, lo, mo), video, mask)
+    loss_o.backward()
+    rg, mg, lg, sg = (x.to(dev).requires_grad_(True) for x in (recon, mean, lv, sel))
+    mk2 = mask.repeat_interleave(2, 0).to(dev).contiguous()
+    mse_p, mae_p = ops.masked_mse_mae(video.to(dev), rg, mk2, 2, True)
+    kl = ops.kl_per_sample(mg, lg, mk2)
+    ak = act.to(dev)
+    assert ops.rl_loss_tail_ok(mse_p, mae_p, kl, sg, ak, mk2)
+    loss_g, aux_g = ops.rl_loss_tail(mse_p, mae_p, None, kl, sg, ak, mk2, HPARAMS)
+    loss_g.backward()
+    names = ("MSE", "perceptual_loss", "selection_loss", "kl_loss", "kept_frame_density", "mean_trajectory_prob", "rl_loss", "per_sample_MAE")
+    assert_close(loss_g, loss_o, rtol=1e-4, atol=1e-6, what="loss")
+    for a, k in zip(aux_g, names):
+        assert_close(a, aux_o[k], rtol=1e-4, atol=1e-6, what=k)
+    for a, w, what in ((rg, ro, "d recon"), (mg, mo, "d mean"), (lg, lo, "d log_variance"), (sg, so, "d selection")):
+        assert_close_scaled(a.grad, w.grad, rel=1e-4, what=what)
+
+
+@pytest.mark.parametrize("b,t,hw,ld", [(2, 3, 16, 96), (1, 4, 256, 96)])
+def test_rl_gate_vs_oracle(dev, b, t, hw, ld):
+    """ops.rl_gate against oracle.model.bernoulli_mask + latent_gate on the pair-doubled latent (train/rl_model.py:136-144): the same frame
+    masks, comp = the oracle's fp32 values rounded once to the decoder's compute dtype, the same gradients at z and fill_token."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(b * 7 + hw)
+    z = torch.randn(b, t, hw, ld, generator=g)
+    prob = torch.rand(b, t, 1, generator=g)
+    u = torch.rand(2 * b, t, 1, 1, generator=g)
+    fill = torch.randn(1, 1, 1, ld, generator=g) * 0.02
+    gc = torch.randn(2 * b, t, hw, ld, generator=g).to(torch.bfloat16)
+    zo, fo = z.clone().requires_grad_(True), fill.clone().requires_grad_(True)
+    sel2 = prob[..., None].repeat_interleave(2, dim=0)
+    m_o = OM.bernoulli_mask(sel2, u).float()
+    comp_o = OM.latent_gate(fo, m_o, zo.repeat_interleave(2, dim=0))
+    comp_o.backward(gc.float())
+    zg, fg = z.to(dev).requires_grad_(True), fill.to(dev).requires_grad_(True)
+    assert ops.rl_gate_ok(zg, prob.to(dev), fg)
+    comp_g, m_g = ops.rl_gate(zg, prob.to(dev), u.to(dev), fg)
+    comp_g.backward(gc.to(dev))
+    assert torch.equal(m_g.cpu(), m_o) and 0 < float(m_o.sum()) < 2 * b * t
+    assert torch.equal(comp_g.cpu(), comp_o.detach().to(torch.bfloat16))
+    assert_close_scaled(zg.grad, zo.grad, rel=1e-6, what="dz")
+    assert_close_scaled(fg.grad, fo.grad, rel=1e-4, what="d fill_token")
+
+
+@pytest.mark.parametrize("b,t,hw,ld", [(2, 3, 16, 96), (1, 4, 256, 96), (2, 2, 40, 8)])
+def test_encoder_head_vs_oracle(dev, b, t, hw, ld):
+    """ops.encoder_head (bf16) against oracle.model.encoder_heads + reparameterise + latent_gate + oracle.loss.kl_per_sample, fp32 (``ref``)
+    and with the reference's mixed-precision rules emulated (``emu``).  The oracle's heads start from the block features x; they are given
+    x = [mean_in | v_in] with selector kernels ([I; 0], [0; I]: exact in every precision), so both sides see the same mean and pre-softplus v.
+    Identical selections; log_variance, compressed representation, per-sample KL and every gradient within 3 x the emulation's own error
+    (+ 2e-3; a tensor of ONE element -- the two selection biases -- is granted the error of one bf16 rounding of itself, which is what the
+    emulated reference commits on it as its last step: tests/test_gpu_parity_r3.py, profiles/r04_sel1_attribution.txt)."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(100 + hw)
+    bf = torch.bfloat16
+    mean_in = (torch.randn(b, t, hw, ld, generator=g) * 0.5).to(bf).float()
+    v_in = (torch.randn(b, t, hw, ld, generator=g) * 1.5).to(bf).float()
+    eye = torch.eye(ld)
+    p = {"spatial_compression.kernel": torch.cat([eye, torch.zeros(ld, ld)]), "spatial_compression.bias": torch.zeros(ld),
+         "variance_estimator.kernel": torch.cat([torch.zeros(ld, ld), eye]), "variance_estimator.bias": torch.zeros(ld),
+         "selection_layer1.kernel": torch.randn(ld, 1, generator=g) * ld ** -0.5, "selection_layer1.bias": torch.randn(1, generator=g) * 0.1,
+         "selection_layer2.kernel": torch.randn(hw, 1, generator=g) * hw ** -0.5, "selection_layer2.bias": torch.randn(1, generator=g) * 0.1}
+    fill = torch.randn(1, 1, 1, ld, generator=g) * 0.02
+    r = torch.rand(b, t, 1, generator=g)
+    u = torch.where(torch.rand(b, t, 1, generator=g) < 0.5, 0.02 + 0.08 * r, 0.9 + 0.08 * r)       # far from the gate's threshold
+    u.view(-1)[0], u.view(-1)[-1] = 0.02, 0.98
+    eps = torch.randn(b, t, hw, ld, generator=g)
+    mask = torch.ones(b, t)
+    mask[0, -1] = 0.0
+    gcomp = torch.randn(b, t, hw, ld, generator=g).to(bf)
+    gsel = torch.randn(b, t, 1, 1, generator=g)
+    gkl = torch.randn(b, generator=g)
+    learn = ("selection_layer1.kernel", "selection_layer1.bias", "selection_layer2.kernel", "selection_layer2.bias")
+
+    def oracle(dtype):
+        x = torch.cat([mean_in, v_in], dim=-1).requires_grad_(True)
+        po = {k: (v.clone().requires_grad_(True) if k in learn else v) for k, v in p.items()}
+        fo = fill.clone().requires_grad_(True)
+        mean, lv, sel = OM.encoder_heads(po, x, u, True, "model", dtype)
+        z = OM.reparameterise(mean, lv, eps, True, dtype)
+        comp = OM.latent_gate(fo, sel, z)
+        kl = OLoss.kl_per_sample(mean, lv, mask, dtype)
+        ((comp * gcomp.float()).sum() + (sel * gsel).sum() + (kl * gkl).sum()).backward()
+        grads = {"d mean": x.grad[..., :ld], "d v": x.grad[..., ld:], "d fill": fo.grad}
+        grads.update({"d " + k: po[k].grad for k in learn})
+        return {"log_variance": lv.detach(), "comp": comp.detach(), "sel": sel.detach(), "kl": kl.detach()}, grads
+    (o_ref, g_ref), (o_emu, g_emu) = oracle(torch.float32), oracle(bf)
+
+    leaves = {"d mean": mean_in.to(dev, bf), "d v": v_in.to(dev, bf), "d selection_layer1.kernel": p["selection_layer1.kernel"].to(dev),
+              "d selection_layer1.bias": p["selection_layer1.bias"].to(dev), "d selection_layer2.kernel": p["selection_layer2.kernel"].to(dev),
+              "d selection_layer2.bias": p["selection_layer2.bias"].to(dev), "d fill": fill.to(dev)}
+    leaves = {k: v.requires_grad_(True) for k, v in leaves.items()}
+    L = leaves
+    assert ops.encoder_head_ok(L["d mean"], L["d v"], L["d selection_layer1.kernel"], L["d selection_layer1.bias"], L["d selection_layer2.kernel"],
+                               L["d selection_layer2.bias"], L["d fill"])
+    lv, comp, sel, klf = ops.encoder_head(L["d mean"], L["d v"], L["d selection_layer1.kernel"], L["d selection_layer1.bias"],
+                                          L["d selection_layer2.kernel"], L["d selection_layer2.bias"], L["d fill"], u.to(dev), eps.to(dev), mask.to(dev))
+    kl = klf.sum(1)
+    ((comp.float() * gcomp.to(dev).float()).sum() + (sel * gsel.to(dev)).sum() + (kl * gkl.to(dev)).sum()).backward()
+    assert torch.equal(sel.cpu(), o_ref["sel"]) and torch.equal(o_emu["sel"], o_ref["sel"])
+    assert 0 < float(o_ref["sel"].sum()) < b * t
+    bad = []
+
+    def bar(name, got, emu, ref):
+        e_got, e_emu = rel_l2(got, ref), rel_l2(emu, ref)
+        allowed = BF16_FACTOR * max(e_emu, ONE_BF16_ROUNDING if ref.numel() == 1 else 0.0) + BF16_FLOOR
+        if not e_got <= allowed:
+            bad.append(f"{name}: gpu vs fp32 oracle {e_got:.3e}, emulated oracle {e_emu:.3e}, allowed {allowed:.3e}")
+    bar("log_variance", lv, o_emu["log_variance"], o_ref["log_variance"])
+    bar("comp", comp, o_emu["comp"], o_ref["comp"])
+    bar("kl", kl, o_emu["kl"], o_ref["kl"])
+    for k, leaf in leaves.items():
+        assert leaf.grad is not None and leaf.grad.shape == g_ref[k].shape, k
+        bar(k, leaf.grad, g_emu[k], g_ref[k])
+    assert not bad, "\n".join(bad)

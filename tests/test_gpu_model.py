@@ -12,6 +12,8 @@ from oracle import optim as OOpt
 from util import assert_close, assert_close_scaled, grad_floor, rnd
 
 pytestmark = pytest.mark.gpu
+GRAD_REL = 1e-3          # fp32 gradients: within 1e-3 of the tensor's scale, element-wise (the generic path is exact-fp32 MFMA: the
+                         # same bar as the forward's rtol)
 
 TINY = dict(height=32, width=32, channels=3, patch_size=8, encoder_depth=1, decoder_depth=1, mlp_dim=64, num_heads=4,
             qkv_features=32, max_temporal_len=8, spatial_compression_rate=4, unembedding_upsample_rate=4)
@@ -46,10 +48,10 @@ def test_unet_fwd_bwd_fp32(dev, shape, levels, base):
     yg = m(xg)
     yg.backward(gy.to(dev))
     assert_close(yg, yo, what="unet out")
-    assert_close_scaled(xg.grad, xo.grad, rel=2e-3, what="dx")
+    assert_close_scaled(xg.grad, xo.grad, rel=GRAD_REL, what="dx")
     ref = {k: v.grad for k, v in po.items()}
     for k, prm in m.named_parameters():
-        assert_close_scaled(prm.grad, ref[k], rel=2e-3, what=f"d{k}", floor=grad_floor(k, ref))
+        assert_close_scaled(prm.grad, ref[k], rel=GRAD_REL, what=f"d{k}", floor=grad_floor(k, ref))
 
 
 def test_unet_bf16_close_to_emulated_oracle(dev):
@@ -122,10 +124,16 @@ def test_video_vae_loss_and_grads_fp32(dev, flavour):
         if k != "reconstruction":
             assert_close(aux_g[k], aux_o[k], rtol=1e-3, atol=1e-5, what=k)
     assert_close(loss_g, loss_o, rtol=1e-3, atol=1e-5, what="loss")
+    ref = {n: v.grad for n, v in po.items()}
+    bad = []
     for k, prm in m.named_parameters():
         assert prm.grad is not None, k
         assert torch.isfinite(prm.grad).all(), k
-        assert_close_scaled(prm.grad, po[k].grad, rel=5e-3, what=f"d{k}", floor=grad_floor(k, {n: v.grad for n, v in po.items()}))
+        try:                                   # every tensor is checked before the test fails: the message lists all that miss the bar
+            assert_close_scaled(prm.grad, ref[k], rel=GRAD_REL, what=f"d{k}", floor=grad_floor(k, ref))
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad)
 
 
 def test_rl_outputs_contract(dev):

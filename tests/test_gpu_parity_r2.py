@@ -25,7 +25,7 @@ from oracle import loss as OLoss
 from oracle import model as OM
 from oracle import optim as OOpt
 from oracle import unet as OU
-from util import assert_close, assert_close_scaled, rnd
+from util import assert_close, assert_close_scaled, grad_floor, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -330,11 +330,17 @@ def test_c2_full_depth_fp32_128(dev):
         assert_close(aux_g[k], aux_o[k], rtol=1e-3, atol=1e-5, what=k)
     assert_close(loss_g, loss_o, rtol=1e-3, atol=1e-5, what="loss")
     names = [k for k, _ in m.named_parameters()]
-    picked = names[::max(1, len(names) // 60)]
+    picked = set(names[::max(1, len(names) // 60)]) | {k for k in names if "unet" in k or "layers" not in k}
+    ref = {k: v.grad for k, v in po.items()}
+    bad = []
     for k, prm in m.named_parameters():
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
-        if k in picked and not k.endswith("conv.bias"):
-            assert_close_scaled(prm.grad, po[k].grad, rel=1e-2, what=f"d{k}")
+        if k in picked:                        # fp32 bar: 1e-3 of the tensor's scale, conv biases included (grad_floor: zero in exact arithmetic)
+            try:
+                assert_close_scaled(prm.grad, ref[k], rel=1e-3, what=f"d{k}", floor=grad_floor(k, ref))
+            except AssertionError as e:
+                bad.append(str(e))
+    assert not bad, "\n".join(bad)
     del po, loss_o, aux_o, loss_g, aux_g
     # (b) full extent of the config
     opt = optim.Optimizer(m, 1e-4)

@@ -7,10 +7,12 @@ that (two blocks at production width, a 64^2 UNet, the full depth in fp32 at 128
 as a ``GraphedTrainStep`` REPLAY -- graph vs oracle, not graph vs eager.
 
 Bar (as tests/test_gpu_parity_r2.py): the oracle runs twice on the CPU, in fp32 (``ref``) and with the reference's mixed-precision rules
-emulated (``emu``); the product's error against ``ref`` may not exceed 3 x the emulation's own + 2e-3.  Tensors of at most SMALL elements
-(the selection heads' scalars) get a floor of 1e-2 instead of 2e-3: the relative error of ONE number is one draw of the rounding noise on
-either side, and the ratio of two such draws exceeds 3 one time in five.  Every tensor is checked before the test fails, and the ones
-that needed more than 3 x the emulation's own error (i.e. passed on the floor) are printed by name.
+emulated (``emu``); the product's error against ``ref`` may not exceed 3 x the emulation's own + 2e-3.  A tensor of ONE element (the two
+selection biases) is priced against max(emulation's error, 2^-8): the emulated reference rounds that scalar gradient to bf16 as its last
+step (the bias gradient of a bf16 Linear is a bf16 array), so its own error on it is a single draw from [0, 2^-8] -- one rounding of the
+number itself -- and the bound must not depend on how lucky that draw was.  (Round 3 passed `encoder.selection_layer1.bias` on an ad-hoc
+1e-2 floor; tools/r04_sel1_attribution.py names the rounding points that make up its 7e-3 -- profiles/r04_sel1_attribution.txt.)  Every
+tensor is checked before the test fails, and the ones that needed more than 3 x the emulation's own error are printed by name.
 """
 import pytest
 import torch
@@ -21,18 +23,20 @@ from test_gpu_parity_r2 import BF16_FACTOR, BF16_FLOOR, PROD, _load, check_bf16,
 from util import rnd
 
 pytestmark = pytest.mark.gpu
-SMALL, SMALL_FLOOR = 16, 1e-2
+SMALL = 16                         # B = 4 test: tensors this small are left out of the automatic spread
+ONE_BF16_ROUNDING = 2.0 ** -8      # largest relative error of rounding one number to bf16
 
 
-def _case():
+def _case(b=1):
     kw = dict(PROD, height=256, width=256)
     cfg = OM.VAEConfig(**kw)
     p = OM.init_video_vae(cfg, seed=3, zero_final=False)                 # final_conv non-zero: the UNet takes part
-    b, t = 1, 16
+    t = 16
     g = torch.Generator().manual_seed(0)
     video = torch.rand((b, t, 256, 256, 3), generator=g)
     mask = torch.ones(b, t)
-    mask[0, 13:] = 0                                                      # masked tail
+    for i, tail in enumerate((13, 16, 9, 15)[:b]):
+        mask[i, tail:] = 0                                                # masked tails, a different one per clip
     # Gumbel uniforms far from the gate's threshold (a last-bit difference in the logits cannot flip a frame, which would be a discrete
     # O(1) change and not a parity question); frame 0 is kept
     u = torch.where(torch.rand((b, t, 1), generator=g) < 0.6, torch.full((), 0.9), torch.full((), 0.02))
@@ -45,7 +49,7 @@ def _oracle(cfg, p, video, mask, noise, dtype):
     po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     emask = OLoss.expand_mask(mask.bool(), cfg.hw)
     v = video if dtype == torch.float32 else video.to(dtype).float()      # the driver casts the clip to bf16 (rl_nonadversarial.py:330)
-    loss, aux = OLoss.loss_fn_plain(OM.video_vae(po, cfg, v, emask, noise, dtype=dtype), v, mask)
+    loss, aux = OLoss.loss_fn_plain(OM.video_vae(po, cfg, v, emask, noise, dtype=dtype), v, mask, dtype=dtype)
     loss.backward()
     out = {"loss": loss.detach(), "recon": aux["reconstruction"].detach(), "MSE": aux["MSE"].detach(), "kl_loss": aux["kl_loss"].detach(),
            "selection_loss": aux["selection_loss"].detach(), "density": aux["kept_frame_density"].detach()}
@@ -61,9 +65,10 @@ def oracle_runs():
     return kw, cfg, p, video, mask, noise, ref, emu
 
 
-def _check_grads(tag, grads, g_ref, g_emu, names, report):
+def _check_grads(tag, grads, g_ref, g_emu, names, report, picked=None):
     """A spread of >= 60 parameter gradients over the whole depth + every UNet / head / embedding tensor; -> list of failures."""
-    picked = set(names[::max(1, len(names) // 60)]) | {k for k in names if "unet" in k or "layers" not in k}
+    if picked is None:
+        picked = set(names[::max(1, len(names) // 60)]) | {k for k in names if "unet" in k or "layers" not in k}
     failures, on_floor = [], []
     for k in sorted(picked):
         floor = None
@@ -74,8 +79,8 @@ def _check_grads(tag, grads, g_ref, g_emu, names, report):
             check_bf16(f"{tag} d{k}", grads[k], g_emu[k], g_ref[k], report, floor_scale=floor)
         except AssertionError as e:
             e_got, e_emu = report[-1][1:] if len(report) > n0 else (float("nan"), float("nan"))
-            if g_ref[k].numel() <= SMALL and e_got <= BF16_FACTOR * e_emu + SMALL_FLOOR:
-                on_floor.append((k, f"{e_got:.2e}", f"{e_emu:.2e}", "small-tensor floor"))
+            if g_ref[k].numel() == 1 and e_got <= BF16_FACTOR * max(e_emu, ONE_BF16_ROUNDING) + BF16_FLOOR:
+                on_floor.append((k, f"{e_got:.2e}", f"{e_emu:.2e}", "scalar: one bf16 rounding of itself"))
                 continue
             failures.append(str(e).splitlines()[0])
             continue
@@ -180,7 +185,7 @@ def test_production_model_bf16_256_rl_flavour_vs_oracle(dev):
         po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
         emask = OLoss.expand_mask(mask.bool(), cfg.hw)
         v = video if dtype == torch.float32 else video.to(dtype).float()
-        loss, aux = OLoss.loss_fn_rl(OM.video_vae_rl(po, cfg, v, emask, noise, dtype=dtype), v, mask)
+        loss, aux = OLoss.loss_fn_rl(OM.video_vae_rl(po, cfg, v, emask, noise, dtype=dtype), v, mask, dtype=dtype)
         loss.backward()
         return ({k: (aux[k].detach() if k != "reconstruction" else aux[k].detach()) for k in aux} | {"loss": loss.detach()},
                 {k: v.grad for k, v in po.items()})
@@ -212,3 +217,39 @@ def test_production_model_bf16_256_rl_flavour_vs_oracle(dev):
     assert set(grads) == set(g_ref)
     failures += _check_grads("rl", grads, g_ref, g_emu, sorted(grads), report)
     assert len(report) >= 60 and not failures, "\n".join(failures)
+
+
+def test_c3_at_b4_bf16_vs_oracle(dev):
+    """Config C3 at its STATED batch (B = 4 clips of 3 x 16 x 256 x 256, bf16, production depth -- the shape bench.py times: 16 384 tokens per
+    Linear product, 64 frames per conv launch) against the oracle, eagerly: reconstruction, loss terms and 24 gradient tensors spread over
+    encoder, decoder, heads and UNet.  Four clips with four different masked tails; same bar as the B = 1 tests above."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, ops, optim
+    kw, cfg, p, video, mask, noise = _case(b=4)
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    (o_ref, g_ref) = _oracle(cfg, p, video, mask, noise, torch.float32)
+    (o_emu, g_emu) = _oracle(cfg, p, video, mask, noise, torch.bfloat16)
+    m = _load(V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **kw), p, dev)
+    opt = optim.Optimizer(m, 0.0)
+    rngs = V.Rngs(3)
+    for k, v in noise.items():
+        rngs.inject(k, v)
+    vg, mg = video.to(dev, torch.bfloat16), mask.to(dev)
+    opt.zero_grad()
+    loss, aux = L.loss_fn_plain(m, vg, L.expand_mask(mg, cfg.hw), mg, rngs, L.HPARAMS)
+    with ops.deferred_wgrad(opt):
+        loss.backward()
+    for bk in range(len(opt.buckets)):
+        if not opt.landed[bk]:
+            opt._land(bk)
+    torch.cuda.synchronize()
+    got = {"loss": loss, "recon": aux["reconstruction"], "MSE": aux["MSE"], "kl_loss": aux["kl_loss"], "density": aux["kept_frame_density"]}
+    grads = {n: g.clone() for n, g in zip(opt.names, opt.gviews)}
+    names = sorted(grads)
+    big = [k for k in names if g_ref[k].numel() > SMALL]
+    picked = set(big[::max(1, len(big) // 20)]) | {"encoder.spatial_compression.kernel", "decoder.unet.patch_mixer.kernel",
+                                                     "decoder.unet.final_conv.kernel", "encoder.selection_layer1.bias"}
+    report = []
+    check_bf16("B=4 reconstruction", got["recon"], o_emu["recon"], o_ref["recon"], report)
+    failures = _check_scalars("B=4", got, o_ref, o_emu) + _check_grads("B=4", grads, g_ref, g_emu, names, report, picked)
+    assert len(report) >= 21 and not failures, "\n".join(failures)

@@ -25,6 +25,14 @@ static inline bool pointwise_shape(int Cin, int Cout, int kt, int kh, int kw)
 
 static int g_force_generic = 0;
 
+// The bf16 kernels address through buffer descriptors (32-bit byte offsets): a tensor spanning 2 GB or more is the generic path's
+// (conv3d_bf16.hip launch_roll returns VVAE_ERR_BAD_ARG for it; ops._bf16_fast says once that this happened).
+static inline bool fits32(int N, int T, int H, int W, int ld_a, int Ca, int ld_b, int Cb)
+{
+    const long vox = (long)N * T * H * W;
+    return ((vox - 1) * ld_a + Ca) * 2 < (1L << 31) && ((vox - 1) * ld_b + Cb) * 2 < (1L << 31);
+}
+
 // Test hook: 1 = always take the generic path (used to cross-check the fast path on the GPU).
 extern "C" void vvae_conv3d_force_generic(int on) { g_force_generic = on; }
 
@@ -50,7 +58,7 @@ extern "C" int vvae_conv3d_fwd(const void* x, int ldx, const float* w, const flo
 {
     if (!g_force_generic && vvae_conv_pointwise_supported(Cin, Cout, kt, kh, kw, ldx, dtype, x))
         return vvae_conv_pointwise_fwd(x, ldx, w, bias, y, ldy, (long)N * T * H * W, Cin, Cout, dtype, stream);
-    if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, ldy, 0, 0))
+    if (dtype == VVAE_DT_BF16 && !g_force_generic && fits32(N, T, H, W, ldx, Cin, ldy, Cout) && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, ldy, 0, 0))
         return vvae_conv3d_fwd_bf16(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, 0, 0, ws, ws_bytes, stream);
     return vvae_conv3d_fwd_generic(x, ldx, w, bias, y, ldy, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
 }
@@ -62,7 +70,7 @@ extern "C" int vvae_conv3d_dgrad(const void* dy, int lddy, const float* w, void*
 {
     if (!g_force_generic && vvae_conv_pointwise_supported(Cin, Cout, kt, kh, kw, lddx, dtype, dx))
         return vvae_conv_pointwise_dgrad(dy, lddy, w, dx, lddx, (long)N * T * H * W, Cin, Cout, dtype, stream);
-    if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, lddx, lddy, 1, 0))
+    if (dtype == VVAE_DT_BF16 && !g_force_generic && fits32(N, T, H, W, lddx, Cin, lddy, Cout) && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, lddx, lddy, 1, 0))
         return vvae_conv3d_fwd_bf16(dy, lddy, w, nullptr, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, 1, 0, ws, ws_bytes, stream);
     return vvae_conv3d_dgrad_generic(dy, lddy, w, dx, lddx, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, stream);
 }
@@ -74,7 +82,7 @@ extern "C" int vvae_conv3d_wgrad(const void* x, int ldx, const void* dy, int ldd
 {
     if (!g_force_generic && vvae_conv_pointwise_supported(Cin, Cout, kt, kh, kw, ldx, dtype, x))
         return vvae_conv_pointwise_wgrad(x, ldx, dy, lddy, dw, dbias, (long)N * T * H * W, Cin, Cout, dtype, ws, ws_bytes, stream);
-    if (dtype == VVAE_DT_BF16 && !g_force_generic && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, lddy, 2, 0))
+    if (dtype == VVAE_DT_BF16 && !g_force_generic && fits32(N, T, H, W, ldx, Cin, lddy, Cout) && vvae_conv3d_bf16_supported(Cin, Cout, kt, kh, kw, ldx, lddy, 2, 0))
         return vvae_conv3d_wgrad_bf16(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, ws, ws_bytes, stream);
     return vvae_conv3d_wgrad_generic(x, ldx, dy, lddy, dw, dbias, N, T, H, W, Cin, Cout, kt, kh, kw, dtype, ws, ws_bytes, stream);
 }

@@ -22,7 +22,9 @@ constexpr int EH_MAX_THREADS = 1024;
 constexpr int EH_MAX_HW = 4096;              // w2 / s1 rows in LDS
 constexpr int EH_MAX_LD = 1024;
 
-struct EhDims { int T, HW, LD, CG, TY; long mask_pitch; };
+struct EhDims { int T, HW, LD, CG, TY; long mask_pitch; int dbg; };
+
+int g_eh_debug = 0;        // vvae_encoder_head_debug: attribution builds of the backward's rounding points (tests / tools only)
 
 __device__ __forceinline__ float bfr(float v) { return bf2f(f2bf(v)); }
 
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
     // round_ste: identity; sigmoid'; the .float() of the logits casts the gradient back to the compute dtype
     const float yy = y_in[f];
     const float sg = 1.f / (1.f + expf(-yy));
-    const float dl = bfr((dsg + (dsel ? dsel[f] : 0.f)) * sg * (1.f - sg));
+    const float dl_f = (dsg + (dsel ? dsel[f] : 0.f)) * sg * (1.f - sg);
+    const float dl = (d.dbg & 1) ? dl_f : bfr(dl_f);
 
     // ---- phase 2: token / element gradients ----
     const float* mrow = mask + (long)b * d.mask_pitch;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
     if (active)
         for (int j = ty; j < d.HW; j += d.TY) {
             const long g = base + (long)j * d.LD;
-            const float dsi = bfr(dl * w2b[j]);
+            const float dsi = (d.dbg & 2) ? dl * w2b[j] : bfr(dl * w2b[j]);
             float m[8], vv[8], lvv[8], dc[8], dm[8], dvv[8], dx[8];
             VecIO<bf16_t, 8>::load(mean + g, m);
             VecIO<bf16_t, 8>::load(v + g, vv);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
 bool eh_dims(int B, int T, int HW, int LD, long mask_pitch, EhDims& d, int& threads)
 {
     if (B <= 0 || T <= 0 || HW <= 0 || HW > EH_MAX_HW || HW % 4 || LD <= 0 || LD > EH_MAX_LD || LD % 8 || (mask_pitch != 0 && mask_pitch < T)) return false;
-    d.T = T; d.HW = HW; d.LD = LD; d.CG = LD / 8; d.mask_pitch = mask_pitch;
+    d.T = T; d.HW = HW; d.LD = LD; d.CG = LD / 8; d.mask_pitch = mask_pitch; d.dbg = g_eh_debug;
     d.TY = EH_MAX_THREADS / d.CG;
     if (d.TY > HW) d.TY = HW;
     threads = ((d.CG * d.TY + 63) / 64) * 64;
@@ -277,6 +280,16 @@ extern "C" int vvae_encoder_head_ok(int B, int T, int HW, int LD)
     if (!eh_dims(B, T, HW, LD, T, d, th)) return 0;
     const size_t fwd = ((size_t)HW + (size_t)HW * d.CG + 20) * 4, bwd = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
     return fwd <= 64 * 1024 && bwd <= 64 * 1024;
+}
+
+// Test / attribution hook (tools/r04_sel1_attribution.py): which of the backward kernel's chosen bf16 rounding points are SKIPPED (kept fp32).
+// bit 0: d logits (the gradient handed to selection_layer2, a bf16 array in the reference's mixed-precision run); bit 1: d s1 = d logits * w2
+// (the gradient handed to selection_layer1).  0 (default) = the shipped kernel.
+extern "C" int vvae_encoder_head_debug(int flags)
+{
+    if (flags < 0 || flags > 3) return VVAE_ERR_BAD_ARG;
+    g_eh_debug = flags;
+    return 0;
 }
 
 // mean, v (pre-softplus) bf16 (B, T, HW, LD) contiguous; w1 (LD), b1 (1), w2 (HW), b2 (1), fill (LD) fp32 masters; u fp32 (B*T) uniform;

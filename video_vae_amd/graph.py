@@ -1,7 +1,7 @@
 """hipGraph capture of the train step's forward + backward (launch-bound inner loop -> one graph replay).
 
-The production step issues ~5 400 kernels; enqueueing them from Python costs about as much wall time as the GPU needs to
-run them, so the step is host-bound in eager mode.  ``GraphedTrainStep`` captures loss forward + backward (including the
+The production step issues ~800 kernels (796 graph nodes at the end of round 3; eager mode adds the framework's own small launches);
+enqueueing them from Python costs more wall time than the GPU needs to run them, so the step is host-bound in eager mode.  ``GraphedTrainStep`` captures loss forward + backward (including the
 bucketed landing of the gradients in the optimizer's flat buffer) once into a ``torch.cuda.CUDAGraph`` and replays it; the
 optimizer update (global-norm reduction + fused clip/Adam, 2 launches) and, under data parallelism, the bucketed all-reduce
 stay eager after the replay.  Everything captured runs on hand-written HIP kernels / hipBLASLt exactly as in eager mode --
@@ -201,6 +201,27 @@ class GraphedTrainStep:
         self.opt.land_all(grads)
         return loss.detach(), {k: v.detach() for k, v in aux.items() if k != "reconstruction"}
 
+    def _check_one_stream(self):
+        """Refuse a capture the autograd engine would crash in.  An eager backward leaves every parameter's AccumulateGrad node pinned to
+        the stream it ran on for as long as anything keeps that pass's graph alive (a kept ``loss`` is enough); Optimizer's hooks wrote
+        that stream onto the node.  Capturing on another stream makes the engine insert a cross-stream sync inside the capture: a
+        segmentation fault on ROCm 7.2 (round 3: tools/r03_second.sh, `python -m video_vae_amd.train`), not an exception -- so raise one."""
+        from .optim import STREAM_TAG, accumulate_grad_node
+        from ._lib import VvaeError
+        if not self.video.is_cuda:
+            return
+        want = self.stream.cuda_stream
+        with torch.cuda.stream(self.stream):            # nodes that do not exist yet are born on the capture stream, where they belong
+            for name, prm in zip(self.opt.names, self.opt.params):
+                node = accumulate_grad_node(prm)
+                have = node.metadata.get(STREAM_TAG) if node is not None else None
+                if have is not None and have != want:
+                    raise VvaeError(
+                        f"GraphedTrainStep: parameter {name!r} has already taken part in an eager backward on stream {have:#x} and that pass's "
+                        f"autograd graph is still alive, but the capture would run on stream {want:#x}.  One stream for the whole run: build the "
+                        "model, run the eager steps and capture on the same non-default stream (pass it as stream=..., as train.py does), or drop "
+                        "every tensor of the eager passes (loss, aux) before capturing.")
+
     def _refill(self):
         for name, (kind, buf) in self.noise.items():
             buf.normal_(generator=self.gen) if kind == "normal" else buf.uniform_(generator=self.gen)
@@ -217,6 +238,7 @@ class GraphedTrainStep:
         self.stream = self.capture_stream if self.capture_stream is not None else torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         gc.collect()
+        self._check_one_stream()
         # per-rank noise stream for the static buffers (eager mode draws from Rngs(seed) keys; same distributions here)
         self.gen = torch.Generator(device=self.video.device)
         self.gen.manual_seed((0x9E3779B97F4A7C15 * (self.rngs.seed + 1)) & 0x7FFFFFFFFFFFFFFF)

@@ -316,6 +316,9 @@ class LayerNorm(nn.Module):
         x = x.to(self.dtype)
         if ops.layer_norm_supported(x):
             return ops.layer_norm(x, self.scale, self.bias, 1e-6)          # HIP kernel, fp32 statistics and affine
+        if x.is_cuda:
+            ops.note_fallback(("layer_norm", x.shape[-1], x.dtype), f"LayerNorm over {x.shape[-1]} features of {x.dtype}: not a shape the HIP kernel "
+                              "takes, the framework's layer_norm runs")
         b = self.bias.to(self.dtype) if self.bias is not None else None
         return F.layer_norm(x, (x.shape[-1],), self.scale.to(self.dtype), b, 1e-6)
 
@@ -515,6 +518,9 @@ class Attention(nn.Module):
             o = ops.spatial_attention_core(qkv, self.q_norm.scale, self.k_norm.scale, self.ROPE.cos_cached, self.ROPE.sin_cached,
                                            self.num_heads, 1e-6)
         else:
+            if qkv.is_cuda and qkv.dtype == torch.bfloat16:
+                ops.note_fallback(("sdpa", s, mask is not None), f"attention over sequence {s} ({'masked' if mask is not None else 'unmasked'}, bf16): "
+                                  "neither fused HIP core takes it, the framework's scaled_dot_product_attention runs")
             q, k, v = torch.chunk(qkv, 3, dim=-1)
             q = rearrange(q, "b s (h d) -> b s h d", h=self.num_heads)
             k = rearrange(k, "b s (h d) -> b s h d", h=self.num_heads)

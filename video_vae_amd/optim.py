@@ -49,6 +49,17 @@ def _copy_all(dsts, srcs):
         torch._foreach_copy_([d for d, _ in rest], [s for _, s in rest])
 
 
+STREAM_TAG = "vvae_accumulate_stream"
+
+
+def accumulate_grad_node(param):
+    """The live AccumulateGrad node of a leaf parameter (made on the current stream if none is alive), or None."""
+    with torch.enable_grad():
+        fn = param.expand_as(param).grad_fn
+    nxt = fn.next_functions if fn is not None else ()
+    return nxt[0][0] if nxt and nxt[0][0] is not None else None
+
+
 class Optimizer:
     """Counterpart of ``nnx.Optimizer(model, optax.chain(clip_by_global_norm(max_norm), adam(schedule)))``.
 
@@ -131,7 +142,17 @@ class Optimizer:
 
     # ---- gradient landing -------------------------------------------------------------------------------
     def _make_hook(self, i):
+        tagged = [False]
+
         def hook(param):
+            if not tagged[0] and param.is_cuda:
+                # Remember, ON the parameter's AccumulateGrad node, which stream it is pinned to (the engine runs the node -- and this
+                # hook -- on the stream that was current when the node was made).  graph.GraphedTrainStep reads the tag back: a capture
+                # on another stream while such a node is alive crashes the autograd engine (the r03b incident).
+                tagged[0] = True
+                node = accumulate_grad_node(param)
+                if node is not None:
+                    node.metadata.setdefault(STREAM_TAG, torch.cuda.current_stream(param.device).cuda_stream)
             if param.grad is None:               # the engine also runs the hook for an undefined gradient (a backward that returned
                 return                           # None: parked weight gradients) -- those arrive through mark_external instead
             b = self.param_bucket[i]
