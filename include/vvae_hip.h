@@ -360,6 +360,15 @@ int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 int vvae_gemm_nt_supported(int M, int N, int K, int lda, int ldb, int ldc);
 int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* res,
                       int ldr, void* C2, int ldc2, int epi, int M, int N, int K, void* stream);
+/* The same product on the second kernel form (csrc/gemm_pp.hip: the DMA pieces of the k-tile stream spread between the MFMAs of the issuing
+ * wave, each half of the workgroup staging its own token rows one segment early, the epilogue straight from the accumulators under the partner
+ * wave's MFMA phase).  Arguments and results as vvae_gemm_nt_bf16 (bit for bit); additionally K >= 128 and N <= 2048 (the bias vector of the
+ * launch is staged in LDS); C, res, C2 8-byte aligned with pitches that are multiples of 4. */
+int vvae_gemm_pp_supported(int M, int N, int K, int lda, int ldb, int ldc);
+int vvae_gemm_pp_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* res,
+                      int ldr, void* C2, int ldc2, int epi, int M, int N, int K, void* stream);
+/* Timing A/B hook of vvae_gemm_pp_bf16: 1 = DMA pieces between the MFMAs (default), 0 = all in front of them. */
+int vvae_gemm_pp_spread(int on);
 /* Test / tuning hook: start-time stagger between the two workgroup cohorts of vvae_gemm_nt_bf16, in units of 2048 cycles (default 0 = off: a gain on
  * back-to-back copies of one product, none inside the train step). */
 int vvae_gemm_nt_stagger(int units);

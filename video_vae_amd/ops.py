@@ -615,7 +615,6 @@ def conv3d_cat2_wgrad_raw(xa, xb, dy, kshape, want_bias=True, dw_out=None, db_ou
     wsb = lib().vvae_conv3d_wgrad_bf16_ws_bytes(n, t, h, w, cin, cout, kt, kh, kw)
     ws, wsb = _ws(wsb, xa.device)
     vox = n * t * h * w
-    _bf16_fast(cin, cout, kt, kh, kw, ldx, lddy, 2, dt, vox)        # says so once if the launch is too large for the bf16 kernels (the dispatcher then goes generic)
     tag = f"conv3d_wgrad {cin}->{cout} k{kt}{kh}{kw} @{h}x{w}"
     check(_launch(tag, vox * (cin + cout) * 2, 2 * vox * kt * kh * kw * cin * cout, "conv3d_wgrad",
                   lambda: lib().vvae_conv3d_wgrad_bf16_cat2(_p(xa), lda, _p(xb), ldb, ca, _p(dy), lddy, _p(dw), _p(db), n, t, h, w, cin, cout, kt,
@@ -1838,9 +1837,12 @@ def gemm_nt_supported(a, b):
             and lib().vvae_gemm_nt_supported(a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), b.shape[0]) == 1)
 
 
-def gemm_nt(a, b, bias=None, res=None, epi=EPI_NONE):
+GEMM_PP = [1]           # 1: the products of gemm_nt run on the second kernel form (csrc/gemm_pp.hip) where it takes the shape; 0: gemm_nt.hip
+
+
+def gemm_nt(a, b, bias=None, res=None, epi=EPI_NONE, form=None):
     """epi(a (M, K) @ b (N, K)^T + bias) in bf16 with fp32 accumulation (no autograd).  epi = EPI_RES adds ``res`` (M, N);
-    EPI_SILU returns (silu(h), h); EPI_MUL_DSILU multiplies by silu'(res)."""
+    EPI_SILU returns (silu(h), h); EPI_MUL_DSILU multiplies by silu'(res).  ``form``: "nt" / "pp" forces a kernel form (tests, A/B)."""
     m, k = a.shape
     n = b.shape[0]
     c = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
@@ -1850,6 +1852,15 @@ def gemm_nt(a, b, bias=None, res=None, epi=EPI_NONE):
         if res.stride(1) != 1:
             res = res.contiguous()
     nbytes = (m * k + n * k + m * n * (1 + (epi != EPI_NONE))) * 2
+    use_pp = (form == "pp" or (form is None and GEMM_PP[0])) and lib().vvae_gemm_pp_supported(m, n, k, a.stride(0), b.stride(0), n) == 1
+    if form == "pp" and not use_pp:
+        raise VvaeError(f"gemm_pp does not take {m} x {n} x {k}")
+    if use_pp:
+        check(_launch(f"gemm_pp {m}x{n} K{k} epi{epi}", nbytes, 2 * m * n * k, "gemm_pp_kernel",
+                      lambda: lib().vvae_gemm_pp_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), n, _p(bias), _p(res),
+                                                      res.stride(0) if res is not None else 0, _p(c2), n, epi, m, n, k, _stream())),
+              "vvae_gemm_pp_bf16")
+        return (c, c2) if epi == EPI_SILU else c
     check(_launch(f"gemm_nt {m}x{n} K{k} epi{epi}", nbytes, 2 * m * n * k, "gemm_nt_kernel",
                   lambda: lib().vvae_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), n, _p(bias), _p(res),
                                                   res.stride(0) if res is not None else 0, _p(c2), n, epi, m, n, k, _stream())),
