@@ -30,8 +30,12 @@ def main():
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     (o_ref, g_ref) = T._oracle(cfg, p, video, mask, noise, torch.float32)
     (o_emu, g_emu) = T._oracle(cfg, p, video, mask, noise, torch.bfloat16)
-    key = "encoder.selection_layer1.bias"
+    key, key2 = "encoder.selection_layer1.bias", "encoder.selection_layer2.bias"
     ref, emu = float(g_ref[key]), float(g_emu[key])
+    r2, e2 = float(g_ref[key2]), float(g_emu[key2])
+    print("identity: d selection_layer1.bias = sum_f sum_j d_logits[f] w2[j] = (d selection_layer2.bias) x (sum_j w2[j]): the two scalars carry the SAME relative")
+    print("          error up to the roundings on the way; the second one is the cleaner read of what arrives from upstream (the decoder's bf16 gradient)")
+    print(f"d selection_layer2.bias: fp32 oracle {r2:+.7f}   bf16-emulated {e2:+.7f} (rel err {abs(e2 - r2) / abs(r2):.3e})")
     print(f"fp32 oracle       {ref:+.7f}")
     print(f"bf16-emulated     {emu:+.7f}   rel err {abs(emu - ref) / abs(ref):.3e}   (its last step rounds the scalar to bf16: grid {2.0 ** (torch.tensor(abs(ref)).log2().floor().item() - 7):.3e})")
     m = _load(V.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **kw), p, dev)
@@ -53,7 +57,9 @@ def main():
         grads = dict(zip(opt.names, opt.gviews))
         got = float(grads[key])
         w2g = float(T.rel_l2(grads["encoder.selection_layer2.kernel"], g_ref["encoder.selection_layer2.kernel"]))
-        print(f"gpu flags={flags}       {got:+.7f}   rel err {abs(got - ref) / abs(ref):.3e}   [{what}]   (d selection_layer2.kernel rel-l2 {w2g:.3e})")
+        g2 = float(grads[key2])
+        print(f"gpu flags={flags}       {got:+.7f}   rel err {abs(got - ref) / abs(ref):.3e}   [{what}]   d selection_layer2.bias {g2:+.7f} (rel err {abs(g2 - r2) / abs(r2):.3e}; "
+              f".kernel rel-l2 {w2g:.3e})")
     lib().vvae_encoder_head_debug(0)
     # host side: the same sum from the ORACLE's exact per-frame d_logits under each rounding policy (isolates the two rounding points from
     # everything upstream: decoder gradient, bf16 weights)

@@ -29,6 +29,7 @@
 namespace pp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 64, ROWB = BK * 2;
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SILU = 2, EPI_MUL_DSILU = 3 };
@@ -66,7 +67,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f
 
 int g_pp_spread = 1;      // vvae_gemm_pp_spread: 1 = DMA pieces between the MFMAs (default), 0 = in front of them (timing A/B only)
 
-template <typename C, int EPI>
+template <typename C, int EPI, int ABL = 0>
 __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ Cout,
                                                            const float* __restrict__ bias, const bf16_t* __restrict__ res, bf16_t* __restrict__ C2,
                                                            Dims d, int spread)
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN, grp = wave >> 2;
     constexpr int MB16 = C::MB16, NB16 = C::NB16, PA = C::PA, PB = C::PB;
+    constexpr int abl = ABL;            // timing-only ablation bits (builds with -DPP_ABLATION, vvae_gemm_pp_spread bits 1-3): 1 no DMA behind the prologue, 2 no fragment reads, 4 no MFMAs
 
     // tiles of one row block (they share the token panel) on one XCD: blockIdx round-robins over the 8 XCDs, each gets a contiguous run
     const int tn_count = d.N / C::BN, ntiles = d.tiles;
@@ -113,9 +115,11 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
     }
     int ia = 0, ib = 0;                                      // stream indices of the next token / weight k-tile to stage
     auto issue_a_piece = [&](int i) {
+        if ((abl & 1) && ia > 1) return;
         glds16(abase + ga_kt * BK + aoff[i], smem + (ia & 1) * C::STAGE + (wave * PA + i) * 1024);
     };
     auto issue_b_piece = [&](int i) {
+        if ((abl & 1) && ib > 1) return;
         glds16(bbase + gb_kt * BK + boff[i], smem + (ib & 1) * C::STAGE + C::A_BYTES + (wave * PB + i) * 1024);
     };
     auto advance_a = [&]() {
@@ -154,6 +158,16 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
     f32x4 acc[NB16][MB16];
     bf16x8 tf[2][MB16], wf[2][NB16];
     auto read_frags = [&](int g) {
+        if (abl & 2) {                                       // timing-only: fragments of unknown content the compiler cannot fold away
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < MB16; ++j) { u32x4 u; asm volatile("" : "=v"(u)); tf[ks][j] = __builtin_bit_cast(bf16x8, u); }
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) { u32x4 u; asm volatile("" : "=v"(u)); wf[ks][i] = __builtin_bit_cast(bf16x8, u); }
+            }
+            return;
+        }
         const unsigned char* cur = smem + (g & 1) * C::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -188,7 +202,8 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             for (int i = 0; i < NB16; ++i)
 #pragma unroll
                 for (int j = 0; j < MB16; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
+                    if (!(abl & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
+                    else { const u32x4 ua = __builtin_bit_cast(u32x4, wf[ks][i]), ub = __builtin_bit_cast(u32x4, tf[ks][j]); asm volatile("" :: "v"(ua), "v"(ub)); }   // keeps the reads alive
                     // piece p goes out behind MFMA number (2 p + 1) NMFMA / (2 NP) - 1: evenly spread, none behind the last MFMAs
                     if (NP > 0) {
 #pragma unroll
@@ -330,19 +345,31 @@ inline int pick(int M, int N, int K)
 template <typename C, int EPI>
 int launch_epi(const void* A, const void* B, void* Cout, const float* bias, const void* res, void* C2, const Dims& d, hipStream_t s)
 {
-    auto k = gemm_pp_kernel<C, EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    void (*k)(const bf16_t*, const bf16_t*, bf16_t*, const float*, const bf16_t*, bf16_t*, Dims, int) = gemm_pp_kernel<C, EPI>;
+#ifdef PP_ABLATION
+    if (EPI == EPI_NONE) {
+        switch (g_pp_spread >> 1) {
+        case 1: k = gemm_pp_kernel<C, EPI_NONE, 1>; break;
+        case 2: k = gemm_pp_kernel<C, EPI_NONE, 2>; break;
+        case 3: k = gemm_pp_kernel<C, EPI_NONE, 3>; break;
+        case 4: k = gemm_pp_kernel<C, EPI_NONE, 4>; break;
+        case 5: k = gemm_pp_kernel<C, EPI_NONE, 5>; break;
+        case 6: k = gemm_pp_kernel<C, EPI_NONE, 6>; break;
+        case 7: k = gemm_pp_kernel<C, EPI_NONE, 7>; break;
+        default: break;
+        }
+    }
+#endif
+    {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     Dims dd = d;
     dd.tiles = (d.M / C::BM) * (d.N / C::BN);
     // one workgroup per CU walking tiles b, b + 256, ... when they divide evenly, else one tile per workgroup
     const int grid = (dd.tiles > 256 && dd.tiles % 256 == 0) ? 256 : dd.tiles;
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::NT), C::LDS, s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)Cout, bias, (const bf16_t*)res, (bf16_t*)C2, dd,
-                       g_pp_spread);
+                       g_pp_spread & 1);
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -360,10 +387,11 @@ int launch(const void* A, const void* B, void* Cout, const float* bias, const vo
 
 }  // namespace pp
 
-// Timing A/B hook: 1 = DMA pieces between the MFMAs (default), 0 = all in front of them.
+// Timing A/B hook: 1 = DMA pieces between the MFMAs (default), 0 = all in front of them; bits 1-3 switch the DMA, the fragment reads and the
+// MFMAs of the main loop off (tools/pp_ablation.py: which two of the three serialise).
 extern "C" int vvae_gemm_pp_spread(int on)
 {
-    pp::g_pp_spread = on ? 1 : 0;
+    pp::g_pp_spread = on;               // bit 0: spread; bits 1-3: timing-only ablation (no DMA / no fragment reads / no MFMAs): wrong results
     return 0;
 }
 

@@ -237,6 +237,8 @@ class GraphedTrainStep:
         # cross-stream sync.  Such a driver runs everything -- model construction, eager steps, captures, replays -- on that one stream.
         self.stream = self.capture_stream if self.capture_stream is not None else torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
+        if getattr(self.model, "_kl", None) is not None:
+            self.model._kl = None           # the last forward's (mean, log_variance, kl): tensors that keep that pass's autograd graph alive
         gc.collect()
         self._check_one_stream()
         # per-rank noise stream for the static buffers (eager mode draws from Rngs(seed) keys; same distributions here)

@@ -110,6 +110,7 @@ class _LinearBf16(torch.autograd.Function):
         ctx.two = bool(with_silu)
         wt = getattr(kernel, "bf16_t", None)                         # (out, in) shadow: the own NT GEMM's operand (optim.Optimizer)
         wl = wt if WT_LIBRARY else None
+        own = wt is not None and bias.dtype == torch.float32 and x2.stride(-1) == 1 and ops.gemm_nt_supported(x2, wt)
         if with_silu:
             # -> (h, silu(h)) from ONE product (ops.gemm_nt, EPI_SILU): the activation between the MLP's Linear layers costs no pass
             a, h = ops.gemm_nt(x2, wt, bias.detach(), None, ops.EPI_SILU)
@@ -118,7 +119,11 @@ class _LinearBf16(torch.autograd.Function):
             ctx.set_materialize_grads(False)                        # no zero-filled gradient tensor for ``a`` in backward
             return h, a
         if res is not None:
+            if own and OWN_RES:                                      # the add in the own product's epilogue (on the rounded Linear output, as the reference adds)
+                return ops.gemm_nt(x2, wt, bias.detach(), res.reshape(-1, wb.shape[1]), ops.EPI_RES).view(res.shape)
             return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1]), wl).view(res.shape)
+        if own and OWN_PLAIN:
+            return ops.gemm_nt(x2, wt, bias.detach()).view(*x.shape[:-1], wb.shape[1])
         if wl is not None:                                           # the library's K-contiguous-both-sides kernel: 8 % faster on qkv
             return torch.addmm(bb, x2, wl.t()).view(*x.shape[:-1], wb.shape[1])
         return torch.addmm(bb, x2, wb).view(*x.shape[:-1], wb.shape[1])
@@ -130,7 +135,11 @@ class _LinearBf16(torch.autograd.Function):
         if dy2.dtype != torch.bfloat16:
             dy2 = dy2.to(torch.bfloat16)
         dres = dy if ctx.has_res else None               # the residual edge: identity
-        dx = torch.mm(dy2, wb.t()).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dy (M, out) . W (in, out)^T: the weight as stored is the K-contiguous (N, K) operand of the own NT GEMM
+            dy2c = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+            dx = (ops.gemm_nt(dy2c, wb) if (OWN_DGRAD and ops.gemm_nt_supported(dy2c, wb)) else torch.mm(dy2, wb.t())).view(ctx.xshape)
         # parked (multiplied after backward in a grouped launch, straight into the optimizer's flat gradient buffer), the split-K HIP kernel
         # (bias gradient rides along: K = tokens >> M, N), or the batched library product
         dw, db = _linear_param_grads(x2, dy2, ctx.kparam, ctx.bparam, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
@@ -209,6 +218,9 @@ class _SiluLinearBf16(torch.autograd.Function):
         ctx.kparam, ctx.bparam = kernel, bias
         ctx.has_res = res is not None
         wt = getattr(kernel, "bf16_t", None) if WT_LIBRARY else None
+        wo = getattr(kernel, "bf16_t", None)
+        if res is not None and OWN_RES and wo is not None and bias.dtype == torch.float32 and ops.gemm_nt_supported(a, wo):
+            return ops.gemm_nt(a, wo, bias.detach(), res.reshape(-1, wb.shape[1]), ops.EPI_RES).view(res.shape)
         if res is not None:                                          # x_skip + linear2(silu(h)): the add rides in the library product
             return ops.linear_residual(a, wb, bb, res.reshape(-1, wb.shape[1]), wt).view(res.shape)
         return torch.addmm(bb, a, wb if wt is None else wt.t()).view(*h.shape[:-1], wb.shape[1])
@@ -252,6 +264,9 @@ def silu_linear(h, linear):
     return linear(F.silu(h))
 
 
+OWN_PLAIN = 0          # qkv forward on the own NT GEMM (0: the library through the transposed shadow); switches for tools/ab_hook.py
+OWN_RES = 0            # out-projection / fc2 + residual on the own NT GEMM's residual epilogue (0: the library product with the residual as C)
+OWN_DGRAD = 0          # plain input gradients (fc1, qkv, out-projection) on the own NT GEMM (0: library)
 NT_SILU = 1            # fc1 + SiLU as one own NT product (0: library product + SiLU stream kernel); a switch for tools/ab_hook.py
 WT_LIBRARY = 1         # qkv / fc2 on the library's K-contiguous kernels through the transposed shadows (0: the (in, out) operand)
 
@@ -471,6 +486,7 @@ class Attention(nn.Module):
         self.qkv_projection = Linear(in_features, qkv_features * 3, rngs, dtype, param_dtype)
         self.qkv_projection.kernel.want_t = True   # (out, in) bf16 shadow: the library's K-contiguous kernel for the forward product
         self.out_projection = Linear(qkv_features, in_features, rngs, dtype, param_dtype, kernel_scale=1e-2)
+        self.out_projection.kernel.want_t = True   # (out, in) shadow: the own NT GEMM's weight operand (residual epilogue)
         self.input_norm = LayerNorm(in_features, dtype, param_dtype)
         self.ROPE = RotaryEmbedding(head_dim=head_dim, max_len=max_len)
         self.use_qk_norm = use_qk_norm      # legacy flag in the reference; q/k norm is always applied
