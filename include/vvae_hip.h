@@ -360,15 +360,16 @@ int vvae_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 int vvae_gemm_nt_supported(int M, int N, int K, int lda, int ldb, int ldc);
 int vvae_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* res,
                       int ldr, void* C2, int ldc2, int epi, int M, int N, int K, void* stream);
-/* The same product on the second kernel form (csrc/gemm_pp.hip: the DMA pieces of the k-tile stream spread between the MFMAs of the issuing
- * wave, each half of the workgroup staging its own token rows one segment early, the epilogue straight from the accumulators under the partner
- * wave's MFMA phase).  Arguments and results as vvae_gemm_nt_bf16 (bit for bit); additionally K >= 128 and N <= 2048 (the bias vector of the
- * launch is staged in LDS); C, res, C2 8-byte aligned with pitches that are multiples of 4. */
+/* The same product on the second kernel form (csrc/gemm_pp.hip: all LDS-DMA staging issued from the read phases -- the token operand through a
+ * ring of three slots by waves 4-7, the weight operand through two by waves 0-3 -- so that the MFMA phases are bare MFMAs; one stream of k-tiles over
+ * the tiles a workgroup walks; a per-wave epilogue under the partner wave's MFMA phase).  Arguments and results as vvae_gemm_nt_bf16 (bit for
+ * bit); additionally K >= 128 and N <= 1536 (N a multiple of 192) or 2048 (of 128): the bias vector of the launch is staged in LDS. */
 int vvae_gemm_pp_supported(int M, int N, int K, int lda, int ldb, int ldc);
 int vvae_gemm_pp_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* res,
                       int ldr, void* C2, int ldc2, int epi, int M, int N, int K, void* stream);
-/* Timing A/B hook of vvae_gemm_pp_bf16: 1 = DMA pieces between the MFMAs (default), 0 = all in front of them. */
-int vvae_gemm_pp_spread(int on);
+/* Timing-only hook of the -DPP_ABLATION build of vvae_gemm_pp_bf16 (tools/pp_ablation.py): bit 0 no DMA, bit 1 no fragment reads, bit 2 no MFMAs
+ * in the plain product's main loop (wrong results); the shipped library ignores it. */
+int vvae_gemm_pp_ablate(int bits);
 /* Test / tuning hook: start-time stagger between the two workgroup cohorts of vvae_gemm_nt_bf16, in units of 2048 cycles (default 0 = off: a gain on
  * back-to-back copies of one product, none inside the train step). */
 int vvae_gemm_nt_stagger(int units);

@@ -20,8 +20,8 @@ for N, K in [(768, 1536), (1536, 768), (512, 768)]:
     bias = torch.randn(N, device=dev)
     row = []
     for bits, nm in names.items():
-        lib().vvae_gemm_pp_spread(1 | bits)
+        lib().vvae_gemm_pp_ablate(bits >> 1)
         t = tmg(lambda: ops.gemm_nt(a, b, bias, form="pp"))
         row.append(f"{nm} {t:5.1f}")
-    lib().vvae_gemm_pp_spread(1)
+    lib().vvae_gemm_pp_ablate(0)
     print(f"N{N} K{K} ({K // 64} k-steps x {M * N // (256 * (192 if N % 192 == 0 else 128)) // 256 or 1} tiles per CU): " + " | ".join(row), flush=True)

@@ -36,8 +36,7 @@ for N, K in [(1536, 768), (768, 1536), (768, 512), (512, 768), (768, 768), (1536
     bias = torch.randn(N, device=dev)
     res = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
     bad = []
-    for spread in (1, 0):
-        lib().vvae_gemm_pp_spread(spread)
+    for spread in (1,):
         for epi, kw in ((0, dict(bias=bias)), (0, dict()), (1, dict(bias=bias, res=res)), (2, dict(bias=bias)), (3, dict(res=res))):
             want = ops.gemm_nt(a, b, epi=epi, form="nt", **kw)
             got = ops.gemm_nt(a, b, epi=epi, form="pp", **kw)
@@ -46,7 +45,7 @@ for N, K in [(1536, 768), (768, 1536), (768, 512), (512, 768), (768, 768), (1536
                 if not torch.equal(w, g_):
                     nb = int((w != g_).sum())
                     bad.append((spread, epi, bool(kw.get("bias") is not None), nb, float((w.float() - g_.float()).abs().max())))
-    lib().vvae_gemm_pp_spread(1)
+    lib().vvae_gemm_pp_ablate(0)
     ref = (a.float() @ b.float().t() + bias)
     err = (ops.gemm_nt(a, b, bias, form="pp").float() - ref).abs().max().item()
     print(f"N{N} K{K}: pp vs fp32 max err {err:.3e}; bitwise mismatches vs gemm_nt: {bad if bad else 'none'}", flush=True)
@@ -58,8 +57,7 @@ for N, K in [(1536, 768), (768, 1536), (768, 512), (512, 768), (768, 768), (1536
         ts = [tmg(lambda: ops.gemm_nt(a, b, bias, form=form)), tmg(lambda: ops.gemm_nt(a, b, bias, res, ops.EPI_RES, form=form)),
               tmg(lambda: ops.gemm_nt(a, b, bias, None, ops.EPI_SILU, form=form)), tmg(lambda: ops.gemm_nt(a, b, None, res, ops.EPI_MUL_DSILU, form=form))]
         row.append(f"{form}: plain {ts[0]:6.1f} ({fl / ts[0] / 1e6:5.0f} TF) +res {ts[1]:6.1f} silu-pair {ts[2]:6.1f} *dsilu {ts[3]:6.1f}")
-    lib().vvae_gemm_pp_spread(0)
     t0 = tmg(lambda: ops.gemm_nt(a, b, bias, form="pp"))
-    lib().vvae_gemm_pp_spread(1)
+    lib().vvae_gemm_pp_ablate(0)
     row.append(f"pp pieces in front: plain {t0:6.1f}")
     print("   " + " | ".join(row), flush=True)
