@@ -24,7 +24,7 @@ for f in files:
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             wg = int(r["Workgroup_Size_X"]) if "Workgroup_Size_X" in r else int(r.get("Workgroup_Size", 0))
             grid = int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0))
-            short = name.split("(")[0]
+            short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             short = short if len(short) <= 100 else short[:60] + ".." + short[-38:]
             groups[(short, grid // max(wg, 1), wg)].append(dur)
 steps = max(steps, 1)

@@ -52,6 +52,17 @@ template <> __device__ __forceinline__ void round2<bf16_t>(float& a, float& b) {
     b = __uint_as_float(w & 0xffff0000u);
 }
 
+// s_barrier that hipcc's scheduler may not move instructions across.  MFMAs are register-only instructions and nothing in the language orders
+// them against a barrier: in the ping-pong GEMM kernels (two wave groups alternating a read phase and an MFMA phase between raw s_barriers)
+// hipcc sank most of a phase's MFMAs BELOW the barrier that closes the phase -- 2 of 36 above / 34 below in gemm_tn256, 4 / 44 in gemm_pp --
+// so both groups' MFMAs met on the matrix pipe in one segment and the other segment had none (round 4, tools/pp_ablation.py).
+__device__ __forceinline__ void vvae_phase_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- vector access: VEC channels per lane (VEC*sizeof(T) = 16 B when aligned) -------------
 template <typename T, int VEC> struct VecIO;
 

@@ -199,11 +199,11 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
         // that tile's stores: those (NIT per thread, twice that with the SiLU pair) may stay in flight.
         if (first) wait_vm0();
         else wait_vm<(EPI == EPI_SILU ? 2 : 1) * NIT>();
-        __builtin_amdgcn_s_barrier();             // tile 0 visible to all; every wave is done with the C image
+        vvae_phase_barrier();             // tile 0 visible to all; every wave is done with the C image
         NT_STAMP(stamp); ++stamp;                 // k-tile 0 landed
         if (grp) {
             if (nk > 1) issue(1, 1);              // this half's pieces of tile 1 (the other half issues its own in L0)
-            __builtin_amdgcn_s_barrier();         // the stagger
+            vvae_phase_barrier();         // the stagger
         }
         for (int t = 0; t < nk; ++t) {
             const unsigned char* cur = smem + (t & 1) * C::STAGE;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
                 if (pf_now) prefetch(t + pfd, m0, nm0, more);
             } else if (pfd > 0 && (t & 1)) wait_vm<1>();          // waves 4-7: their pieces of tile t+1 (issued a step ago) have landed;
             else wait_vm0();                                      //            the prefetch issued behind them may still be in flight
-            __builtin_amdgcn_s_barrier();
+            vvae_phase_barrier();
             // ---- C_t
             if (grp) {
                 if (t + 2 < nk) issue(t + 2, t & 1);
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_nt_kernel(const bf16_t* __restr
 #pragma unroll
                     for (int j = 0; j < MB16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], tf[ks][j], acc[i][j], 0, 0, 0);
             if (!grp && t + 1 < nk) { if (pf_now) wait_vm<1>(); else wait_vm0(); }   // waves 0-3: their pieces of tile t+1 have landed
-            __builtin_amdgcn_s_barrier();
+            vvae_phase_barrier();
         }
-        if (!grp) __builtin_amdgcn_s_barrier();
+        if (!grp) vvae_phase_barrier();
         __syncthreads();                          // every wave is done with the operand buffers
         NT_STAMP(stamp); ++stamp;                 // main loop done
 

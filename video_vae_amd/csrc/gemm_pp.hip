@@ -209,8 +209,17 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
         const long row0 = (long)(m0 + wm * C::WTM + (lane >> 2));
         const int col0 = n0 + wn * C::WTN + (lane & 3) * 8;
         const int bcol = n0 + wn * C::WTN + kg * 4;
+        // the second operand of the tail (residual / saved pre-activation) does not depend on the product: a whole channel pair's four units
+        // are requested at once, one pair ahead of their use (two sets of four 16-byte registers)
+        uint4 rq[2][MB16];
+        auto request = [&](int ip, int set) {
+#pragma unroll
+            for (int j = 0; j < MB16; ++j) rq[set][j] = *reinterpret_cast<const uint4*>(res + (row0 + j * 16) * d.ldr + col0 + ip * 32);
+        };
+        if (has_res) request(0, 0);
 #pragma unroll
         for (int ip = 0; ip < NB16 / 2; ++ip) {
+            if (has_res && ip + 1 < NB16 / 2) request(ip + 1, (ip + 1) & 1);
             float4 bv[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -219,8 +228,6 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             for (int j = 0; j < MB16; ++j) {
                 const long gm = row0 + j * 16;
                 const int gn = col0 + ip * 32;
-                uint4 rp;
-                if (has_res) rp = *reinterpret_cast<const uint4*>(res + gm * d.ldr + gn);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const f32x4 a = acc[2 * ip + h][j];
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
 #pragma unroll
                         for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
                     } else {
+                        const uint4 rp = rq[ip & 1][j];
                         const uint32_t rw[4] = {rp.x, rp.y, rp.z, rp.w};
                         float r[8];
 #pragma unroll
@@ -267,10 +275,11 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
         // ================= waves 0-3: L(g) at segment 2g, C(g) at 2g + 1; they stage the weight rows of k-tile g + 1 in L(g) =================
         int tile = blockIdx.x, kt = 0;
         for (int g = 0; g < G; ++g) {
-            read_frags();
             const bool ep = kt == 0 && g > 0;                // the previous tile's accumulators are still in the registers
+            if (!has_res) read_frags();
             if (g + 1 < G) stage_next();                     // ahead of the epilogue's stores: see the wait below
             if (ep) epilogue(tile - (int)gridDim.x);
+            if (has_res) read_frags();                       // tails with a second operand: its prefetch registers and the fragments are not live together
             wait_lgkm0();                                    // fragments in registers: the slots may be overwritten behind the barrier
             phase_barrier();
             if (kt == 0) zero_acc();
@@ -287,11 +296,12 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
         int tile = blockIdx.x, kt = 0;
         bool ep_prev = false;
         for (int g = 0; g < G; ++g) {
-            read_frags();
             const bool ep = kt == 0 && g > 0;
             const bool st = g + 2 < G;
+            if (!has_res) read_frags();
             if (st) stage_next();
             if (ep) epilogue(tile - (int)gridDim.x);
+            if (has_res) read_frags();
             // tokens of k-tile g + 1 (staged in L(g-1), or the prologue) have landed; younger: an epilogue's stores of L(g-1) or of this phase
             // (never both: a tile has at least two k-tiles) and the pieces just staged
             if (ep || ep_prev) { if (st) wait_vm<NST + PA>(); else wait_vm<NST>(); }

@@ -114,8 +114,8 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
     const int npro = nk < S ? nk : S;
     for (int t = 0; t < npro; ++t) issue(t, t);
     wait_tiles(npro - 1);
-    __builtin_amdgcn_s_barrier();
-    if (grp) __builtin_amdgcn_s_barrier();
+    vvae_phase_barrier();
+    if (grp) vvae_phase_barrier();
     int st = 0;
     for (int t = 0; t < nk; ++t) {
         const unsigned char* cur = smem + st * STAGE;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
         if (t >= 1 && t - 1 + S < nk) issue(t - 1 + S, st == 0 ? S - 1 : st - 1);
         const int issued = t + S < nk ? t + S : nk;
         wait_tiles(issued - t - 2);
-        __builtin_amdgcn_s_barrier();
+        vvae_phase_barrier();
 #pragma unroll
         for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
@@ -136,10 +136,10 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) accb[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[jb], accb[jb], 0, 0, 0);
         }
-        __builtin_amdgcn_s_barrier();
+        vvae_phase_barrier();
         st = st + 1 == S ? 0 : st + 1;
     }
-    if (!grp) __builtin_amdgcn_s_barrier();
+    if (!grp) vvae_phase_barrier();
 
     // ---- tile -> memory.  acc[ib][jb][j]: m = 128 wm + 16 ib + 4 g + j, n = 64 wn + 16 jb + (lane & 15)
     const int nl = lane & 15;

@@ -119,10 +119,10 @@ class _LinearBf16(torch.autograd.Function):
             ctx.set_materialize_grads(False)                        # no zero-filled gradient tensor for ``a`` in backward
             return h, a
         if res is not None:
-            if own and OWN_RES:                                      # the add in the own product's epilogue (on the rounded Linear output, as the reference adds)
+            if own and (OWN & 2):                                      # the add in the own product's epilogue (on the rounded Linear output, as the reference adds)
                 return ops.gemm_nt(x2, wt, bias.detach(), res.reshape(-1, wb.shape[1]), ops.EPI_RES).view(res.shape)
             return ops.linear_residual(x2, wb, bb, res.reshape(-1, wb.shape[1]), wl).view(res.shape)
-        if own and OWN_PLAIN:
+        if own and (OWN & 1):
             return ops.gemm_nt(x2, wt, bias.detach()).view(*x.shape[:-1], wb.shape[1])
         if wl is not None:                                           # the library's K-contiguous-both-sides kernel: 8 % faster on qkv
             return torch.addmm(bb, x2, wl.t()).view(*x.shape[:-1], wb.shape[1])
@@ -139,7 +139,7 @@ class _LinearBf16(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dy (M, out) . W (in, out)^T: the weight as stored is the K-contiguous (N, K) operand of the own NT GEMM
             dy2c = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
-            dx = (ops.gemm_nt(dy2c, wb) if (OWN_DGRAD and ops.gemm_nt_supported(dy2c, wb)) else torch.mm(dy2, wb.t())).view(ctx.xshape)
+            dx = (ops.gemm_nt(dy2c, wb) if ((OWN & 4) and ops.gemm_nt_supported(dy2c, wb)) else torch.mm(dy2, wb.t())).view(ctx.xshape)
         # parked (multiplied after backward in a grouped launch, straight into the optimizer's flat gradient buffer), the split-K HIP kernel
         # (bias gradient rides along: K = tokens >> M, N), or the batched library product
         dw, db = _linear_param_grads(x2, dy2, ctx.kparam, ctx.bparam, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
@@ -219,7 +219,7 @@ class _SiluLinearBf16(torch.autograd.Function):
         ctx.has_res = res is not None
         wt = getattr(kernel, "bf16_t", None) if WT_LIBRARY else None
         wo = getattr(kernel, "bf16_t", None)
-        if res is not None and OWN_RES and wo is not None and bias.dtype == torch.float32 and ops.gemm_nt_supported(a, wo):
+        if res is not None and (OWN & 2) and wo is not None and bias.dtype == torch.float32 and ops.gemm_nt_supported(a, wo):
             return ops.gemm_nt(a, wo, bias.detach(), res.reshape(-1, wb.shape[1]), ops.EPI_RES).view(res.shape)
         if res is not None:                                          # x_skip + linear2(silu(h)): the add rides in the library product
             return ops.linear_residual(a, wb, bb, res.reshape(-1, wb.shape[1]), wt).view(res.shape)
@@ -264,9 +264,9 @@ def silu_linear(h, linear):
     return linear(F.silu(h))
 
 
-OWN_PLAIN = 0          # qkv forward on the own NT GEMM (0: the library through the transposed shadow); switches for tools/ab_hook.py
-OWN_RES = 0            # out-projection / fc2 + residual on the own NT GEMM's residual epilogue (0: the library product with the residual as C)
-OWN_DGRAD = 0          # plain input gradients (fc1, qkv, out-projection) on the own NT GEMM (0: library)
+# Which Linear products run on the own NT GEMM (ops.gemm_nt: csrc/gemm_pp.hip) instead of the library -- a bit mask so that tools/ab_hook.py can
+# A/B the routes in situ: 1 = plain forward (qkv), 2 = forward + residual (out-projection, fc2), 4 = plain input gradients (fc1, qkv, out-projection).
+OWN = 7
 NT_SILU = 1            # fc1 + SiLU as one own NT product (0: library product + SiLU stream kernel); a switch for tools/ab_hook.py
 WT_LIBRARY = 1         # qkv / fc2 on the library's K-contiguous kernels through the transposed shadows (0: the (in, out) operand)
 
