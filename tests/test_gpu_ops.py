@@ -822,6 +822,47 @@ def test_gemm_nt_linear_forms(dev, m, n, k):
             lib().vvae_gemm_nt_prefetch(3)
 
 
+@pytest.mark.parametrize("m,n,k", [(16384, 1536, 768), (16384, 768, 1536), (16384, 512, 768), (16384, 768, 512), (512, 384, 128), (256, 1536, 192),
+                                     (1024, 2048, 256), (768, 192, 832), (16384, 1536, 192)])
+def test_gemm_pp_matches_gemm_nt_bitwise_and_fp32(dev, m, n, k):
+    """The second NT GEMM form (csrc/gemm_pp.hip: staging from the read phases, three-slot token ring, per-wave epilogue) against the first
+    (gemm_nt.hip) BIT FOR BIT on all four epilogues, with and without bias, and against the fp32 product: the trunk's shapes (two tiles per
+    workgroup in one k-tile stream at N = 1536; one tile at 768 / 512), the smallest K (two k-tiles), K an odd number of k-tiles (the three-slot
+    ring wraps out of step with the two-slot one), a tile count that is not a multiple of 256 (one tile per workgroup), N = 2048 (the whole
+    LDS bias buffer of the 128-column form), pitched A / residual / output views, and twice (deterministic)."""
+    ops = _ops()
+    a_full = rnd((m, k + 64), 195).to(dev, torch.bfloat16)
+    a = a_full[:, :k]                                              # row pitch k + 64
+    b = (rnd((n, k), 196) / k ** 0.5).to(dev, torch.bfloat16)
+    bias = rnd((n,), 197).to(dev)
+    res = rnd((m, n), 198).to(dev, torch.bfloat16)
+    assert ops.gemm_nt_supported(a, b) and ops.lib().vvae_gemm_pp_supported(m, n, k, a.stride(0), b.stride(0), n) == 1
+    ref = a.float() @ b.float().t() + bias
+    for epi, kw in ((ops.EPI_NONE, dict(bias=bias)), (ops.EPI_NONE, dict()), (ops.EPI_RES, dict(bias=bias, res=res)), (ops.EPI_SILU, dict(bias=bias)),
+                    (ops.EPI_MUL_DSILU, dict(res=res))):
+        want = ops.gemm_nt(a, b, epi=epi, form="nt", **kw)
+        got = ops.gemm_nt(a, b, epi=epi, form="pp", **kw)
+        again = ops.gemm_nt(a, b, epi=epi, form="pp", **kw)
+        for w, g_, g2 in zip(*[x if isinstance(x, tuple) else (x,) for x in (want, got, again)]):
+            assert torch.equal(w, g_), (epi, sorted(kw), int((w != g_).sum()))
+            assert torch.equal(g_, g2)
+    c = ops.gemm_nt(a, b, bias, form="pp")
+    assert_close(c, ref, rtol=1e-2, atol=1e-2, what="linear")
+    assert float((c != ref.to(torch.bfloat16)).float().mean()) < 5e-3, "only accumulation-order flips of the last bf16 bit"
+
+
+def test_gemm_pp_declines_what_it_cannot_take(dev):
+    ops = _ops()
+    L = ops.lib()
+    assert L.vvae_gemm_pp_supported(16384, 1536, 64, 64, 64, 1536) == 0          # one k-tile: the stream needs two
+    assert L.vvae_gemm_pp_supported(16384, 1728, 768, 768, 768, 1728) == 0        # N = 9 x 192 > 1536: the bias vector would not fit the LDS left over
+    assert L.vvae_gemm_pp_supported(16384, 2176, 768, 768, 768, 2176) == 0        # N = 17 x 128 > 2048
+    assert L.vvae_gemm_pp_supported(16380, 768, 768, 768, 768, 768) == 0
+    a = torch.zeros((256, 128), device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ops.VvaeError):
+        ops.gemm_nt(a, torch.zeros((100, 128), device=dev, dtype=torch.bfloat16), form="pp")
+
+
 @pytest.mark.parametrize("ci,co,shape", [(32, 16, (2, 3, 6, 10)), (64, 32, (1, 2, 5, 7)), (128, 64, (1, 2, 4, 8))])
 def test_conv_transpose_bf16_fast_path(dev, ci, co, shape):
     """bf16 MFMA ConvTranspose fwd/dgrad (weights in registers) vs the generic fp32-matrix-core path and the oracle."""

@@ -1,8 +1,8 @@
 """GPU parity above the single-op level for the kernels the benchmark actually runs ("next round" item 1).
 
 * production-shaped bf16 FactoredAttention blocks (C = 768, 8 heads x 64, MLP 1536, hw = 256, T = 16, masked tail) -- forward
-  and EVERY gradient against the CPU oracle: reaches tattn_*_fast<64>, sattn_*, gemm_nt's silu' epilogue, the deferred
-  gemm_tn256_grouped launch, the residual-accumulating library product, LayerNorm at C = 768 and the pending/defer residual protocol;
+  and EVERY gradient against the CPU oracle: reaches tattn16_*_mfma, sattn_*, all four epilogues of the own NT GEMM (gemm_pp: plain, + residual, SiLU pair, * silu'), the deferred
+  gemm_tn256_grouped launch, LayerNorm at C = 768 and the pending/defer residual protocol;
 * bf16 UNet at C1 size: forward and every parameter gradient against the oracle's bf16 emulation (conv3d_bf16_roll / wgrad /
   GroupNorm-statistics epilogue / ConvTranspose MFMA kernels);
 * loss-curve parity (north_star: "recon+KL loss curve matching the CPU reference"; property source
@@ -136,8 +136,12 @@ def test_factored_attention_production_shape_bf16_vs_oracle(dev):
     # the production instantiations were the ones that ran
     seen = " | ".join(sorted(set(names)))
     for must in ("temporal_attn_fwd T16 D64", "temporal_attn_bwd T16 D64", "spatial_attn_fwd S256 D64", "spatial_attn_bwd S256 D64",
-                 "gemm_tn_grouped", "linear+residual", "layernorm_fwd C768", "layernorm_bwd C768+skip"):
+                 "gemm_tn_grouped", "layernorm_fwd C768", "layernorm_bwd C768+skip",
+                 # every forward / input-gradient product of the Linear stack on the own NT GEMM (csrc/gemm_pp.hip), all four epilogues:
+                 "gemm_pp 4096x1536 K768 epi0", "gemm_pp 4096x768 K512 epi1", "gemm_pp 4096x768 K1536 epi1", "gemm_pp 4096x1536 K768 epi2",
+                 "gemm_pp 4096x1536 K768 epi3", "gemm_pp 4096x768 K1536 epi0", "gemm_pp 4096x512 K768 epi0"):
         assert must in seen, (must, seen)
+    assert "linear+residual" not in seen and not any(n.startswith("gemm_nt ") for n in names), seen
     report = []
     check_bf16("out", yg, y_emu, y_ref, report)
     check_bf16("dx", xg.grad, dx_emu, dx_ref, report)

@@ -209,17 +209,18 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
         const long row0 = (long)(m0 + wm * C::WTM + (lane >> 2));
         const int col0 = n0 + wn * C::WTN + (lane & 3) * 8;
         const int bcol = n0 + wn * C::WTN + kg * 4;
-        // the second operand of the tail (residual / saved pre-activation) does not depend on the product: a whole channel pair's four units
-        // are requested at once, one pair ahead of their use (two sets of four 16-byte registers)
-        uint4 rq[2][MB16];
-        auto request = [&](int ip, int set) {
+        // the second operand of the tail (residual / saved pre-activation) does not depend on the product: all of the wave's units are requested
+        // at once, before anything else (one memory latency per tile, not one per unit; the fragments of the next k-tile are read behind the
+        // epilogue in these variants, so the 48 registers are free)
+        uint4 rq[has_res ? NB16 / 2 : 1][MB16];
+        if (has_res) {
 #pragma unroll
-            for (int j = 0; j < MB16; ++j) rq[set][j] = *reinterpret_cast<const uint4*>(res + (row0 + j * 16) * d.ldr + col0 + ip * 32);
-        };
-        if (has_res) request(0, 0);
+            for (int ip = 0; ip < NB16 / 2; ++ip)
+#pragma unroll
+                for (int j = 0; j < MB16; ++j) rq[ip][j] = *reinterpret_cast<const uint4*>(res + (row0 + j * 16) * d.ldr + col0 + ip * 32);
+        }
 #pragma unroll
         for (int ip = 0; ip < NB16 / 2; ++ip) {
-            if (has_res && ip + 1 < NB16 / 2) request(ip + 1, (ip + 1) & 1);
             float4 bv[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
 #pragma unroll
                         for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
                     } else {
-                        const uint4 rp = rq[ip & 1][j];
+                        const uint4 rp = rq[has_res ? ip : 0][j];
                         const uint32_t rw[4] = {rp.x, rp.y, rp.z, rp.w};
                         float r[8];
 #pragma unroll
