@@ -1,40 +1,49 @@
-"""Re-flow a markdown file to a column limit: paragraphs and list items are wrapped (continuation lines indented under the item), fenced code
-is left alone, and a table whose rows exceed the limit is turned into one small section per row (first cell = heading, the other cells =
-bullets labelled with their column names) -- a 3 000-character table cell cannot be read in any viewer.   python tools/wrap_md.py IN OUT [120]"""
+"""Re-flow a markdown file to a column limit: paragraphs and list items are joined and wrapped (continuation lines indented under the
+item), fenced code, headings and short tables are left alone; with no --keep-tables a table whose rows exceed the limit is turned into one
+small section per row (first cell = heading, the other cells = bullets labelled with their column names) -- a 3 000-character table cell
+cannot be read in any viewer.   python tools/wrap_md.py IN OUT [120] [--keep-tables]"""
 import re
 import sys
 import textwrap
 
-src, dst = sys.argv[1], sys.argv[2]
-width = int(sys.argv[3]) if len(sys.argv) > 3 else 120
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+src, dst = args[0], args[1]
+width = int(args[2]) if len(args) > 2 else 120
+keep_tables = "--keep-tables" in sys.argv
 lines = open(src).read().split("\n")
-out, i, in_code = [], 0, False
+out, i = [], 0
 
 
 def wrap(text, first, rest):
     return textwrap.wrap(text, width=width, initial_indent=first, subsequent_indent=rest, break_long_words=False, break_on_hyphens=False) or [first.rstrip()]
 
 
-def cells(row):
-    return [c.strip() for c in row.strip().strip("|").split("|")]
+LIST = re.compile(r"^(\s*(?:[-*]|\d+\.)\s+)(.*)$")
+
+
+def special(l):
+    return (not l.strip()) or l.lstrip().startswith("```") or l.startswith("|") or l.startswith("#") or LIST.match(l) or l.startswith("<!--")
 
 
 while i < len(lines):
     l = lines[i]
-    if l.lstrip().startswith("```"):
-        in_code = not in_code
-        out.append(l); i += 1; continue
-    if in_code or len(l) <= width and not l.startswith("|"):
+    if l.lstrip().startswith("```"):                       # fenced code: verbatim
+        out.append(l); i += 1
+        while i < len(lines) and not lines[i].lstrip().startswith("```"):
+            out.append(lines[i]); i += 1
+        if i < len(lines):
+            out.append(lines[i]); i += 1
+        continue
+    if not l.strip() or l.startswith("#") or l.startswith("<!--"):
         out.append(l); i += 1; continue
     if l.startswith("|"):
         j = i
         while j < len(lines) and lines[j].startswith("|"):
             j += 1
         block = lines[i:j]
-        if all(len(b) <= width for b in block):
+        if keep_tables or all(len(b) <= width for b in block):
             out += block
         else:
-            # cells may contain escaped or code-quoted pipes: split on " | " only
             split = lambda row: [c.strip() for c in re.split(r"\s\|\s", row.strip().strip("|").strip())]
             head = split(block[0])
             for row in block[2:]:
@@ -48,12 +57,19 @@ while i < len(lines):
             out.append("")
         i = j
         continue
-    m = re.match(r"^(\s*(?:[-*]|\d+\.)\s+)(.*)$", l)
+    m = LIST.match(l)
     if m:
-        out += wrap(m.group(2), m.group(1), " " * len(m.group(1)))
-    else:
-        ind = re.match(r"^\s*", l).group(0)
-        out += wrap(l.strip(), ind, ind)
+        first, text = m.group(1), m.group(2)
+        i += 1
+        while i < len(lines) and not special(lines[i]) and lines[i].startswith(" "):      # continuation lines of the item
+            text += " " + lines[i].strip(); i += 1
+        out += wrap(text, first, " " * len(first))
+        continue
+    ind = re.match(r"^\s*", l).group(0)
+    text = l.strip()
     i += 1
+    while i < len(lines) and not special(lines[i]):
+        text += " " + lines[i].strip(); i += 1
+    out += wrap(text, ind, ind)
 open(dst, "w").write("\n".join(out))
 print(max(len(x) for x in out), "max columns;", len(out), "lines")
