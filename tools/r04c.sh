@@ -1,2 +1,1 @@
-cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r04c && timeout -k 10 600 python -m pytest tests/test_gpu_ops.py -q -k "gemm_pp or gemm_nt" 2>&1 | tail -4 && timeout -k 10 900 python -m pytest tests/test_gpu_parity_r2.py tests/test_gpu_parity_r3.py -q -x -k "factored or production_model or c3_at" 2>&1 | tail -4 && timeout -k 10 600 python bench.py --no-cpu-baseline --no-also 2>gpurun_out/r04c/bench.err > gpurun_out/r04c/bench_line.json; python -c "
-import json; d=json.load(open('gpurun_out/r04c/bench_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['conv_stack']['ms_per_step']); [print(k['launch'], k['per_step'], k['avg_ms'], k['ms_per_step']) for k in d['kernels']]"
+cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r04c && timeout -k 10 300 python tools/pp_clock.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04c/pp_clock.txt

@@ -77,6 +77,11 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 __device__ __forceinline__ float dsilu_f(float x) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 
+#ifdef PP_ABLATION
+// diagnostic build only: shader-clock and 100 MHz wall stamps around the main loop of wave 0 of every workgroup (MI355X_MICROARCH.md, DVFS
+// give-back item 6: in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz); the values go to a buffer nothing else reads
+__device__ unsigned long long g_pp_stamps[256 * 4];
+#endif
 int g_pp_ablate = 0;      // builds with -DPP_ABLATION only (tools/pp_ablation.py): 1 no DMA behind the prologue, 2 no fragment reads, 4 no MFMAs
 
 template <typename C, int EPI, int ABL = 0>
@@ -272,6 +277,9 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
     if (grp && G > 1) stage_next();
     wait_vm<0>();
     phase_barrier();
+#ifdef PP_ABLATION
+    if (tid == 0 && blockIdx.x < 256) { g_pp_stamps[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); g_pp_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (!grp) {
         // ================= waves 0-3: L(g) at segment 2g, C(g) at 2g + 1; they stage the weight rows of k-tile g + 1 in L(g) =================
         int tile = blockIdx.x, kt = 0;
@@ -289,6 +297,9 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             phase_barrier();
             if (++kt == nk) { kt = 0; tile += gridDim.x; }
         }
+#ifdef PP_ABLATION
+        if (tid == 0 && blockIdx.x < 256) { g_pp_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); g_pp_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
         epilogue(tile - (int)gridDim.x);
         phase_barrier();                        // waves 4-7 run one segment longer
     } else {
@@ -387,6 +398,13 @@ extern "C" int vvae_gemm_pp_ablate(int bits)
     pp::g_pp_ablate = bits & 7;
     return 0;
 }
+
+#ifdef PP_ABLATION
+extern "C" int vvae_gemm_pp_stamps(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pp::g_pp_stamps), sizeof(unsigned long long) * 256 * 4, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // 1 if vvae_gemm_pp_bf16 takes this shape (M % 256 == 0, K % 64 == 0, K >= 128, N % 192 == 0 or N % 128 == 0, N <= 1536 resp. 2048 (the bias
 // vector lives in LDS), 16-byte aligned pitches that keep a tile's panels inside 32-bit element offsets).

@@ -309,6 +309,8 @@ class Linear(nn.Module):
         self.kernel = nn.Parameter(k.to(param_dtype))
         self.bias = nn.Parameter(torch.zeros(out_features, dtype=param_dtype))
         self.dtype = dtype
+        # (out, in) bf16 shadow kept by the optimizer: the weight operand of the own NT GEMM's forward product (csrc/gemm_pp.hip)
+        self.kernel.want_t = in_features % 64 == 0 and out_features % 64 == 0
 
     def forward(self, x):
         x = x.to(self.dtype)
