@@ -40,12 +40,12 @@ PROD = dict(height=256, width=256, channels=3, patch_size=16, encoder_depth=9, d
             qkv_features=512, max_temporal_len=64, spatial_compression_rate=8, unembedding_upsample_rate=4)
 
 
-TRAFFIC_FILE = "r03_traffic.json"
+TRAFFIC_FILE = "r04_traffic.json"
 
 
 def measured_traffic(kernel, key="hbm_bytes_per_launch"):
     """HBM bytes per launch of ``kernel`` (or, with key="mfma_busy", the busy fraction of the matrix pipes during its launches) from
-    the committed rocprofv3 PMC passes (profiles/r03_traffic.json: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
+    the committed rocprofv3 PMC passes (profiles/r04_traffic.json: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950; a third pass with SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE) -- or None, with the
     reason, when there is no figure or the kernel's sources have changed since the passes were taken (the file carries the
     sha256 of the .hip files the kernel is built from: a stale counter figure is refused, not quoted)."""

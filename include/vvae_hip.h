@@ -175,6 +175,21 @@ int vvae_encoder_head_bwd(const void* mean, const void* v, const void* logvar, c
                           const float* dsel, const float* gkl, long gkl_pitch_b, long gkl_pitch_t, const void* dlv_ext, void* dmean, void* dv,
                           float* part1, float* part2, float* part3, float* partb, int B, int T, int HW, int LD, void* stream);
 
+/* The rl flavour's counterpart (reference train/rl_model.py:50-60,119-147): the selection is the probability sigmoid(logits); every clip is doubled into a
+ * pair (samples 2k, 2k + 1 of the outputs) whose members draw their own Bernoulli frame mask u2 < probability and gate the shared latent with it.  u2 fp32
+ * (2B T); logvar2, mean2, comp2 bf16 (2B, T, HW, LD); prob fp32 (2B T), pair-doubled; mask2 fp32 (2B T); kl_frame2 fp32 (2B, T).  bwd: dcomp2 bf16 (2B, T, HW, LD), dprob2 fp32
+ * (2B T) (the gradient at the pair-doubled probability), gkl at [i gkl_pitch_b + t gkl_pitch_t] for i < 2B, dlv_ext bf16 (B, T, HW, LD): each may be NULL
+ * -> dmean, dv bf16 (B, T, HW, LD) and the partial rows of vvae_encoder_head_bwd. */
+int vvae_encoder_head_rl_fwd(const void* mean, const void* v, const float* w1, const float* b1, const float* w2, const float* b2,
+                             const float* u2, const float* eps, const float* mask, long mask_pitch, const float* fill, void* logvar2,
+                             void* mean2, void* comp2, float* prob, float* mask2, float* y, float* s1, float* kl_frame2, int B, int T, int HW,
+                             int LD, void* stream);
+int vvae_encoder_head_rl_bwd(const void* mean, const void* v, const void* logvar2, const float* eps, const float* mask, long mask_pitch,
+                             const float* fill, const float* w1, const float* w2, const float* y, const float* s1, const float* mask2,
+                             const void* dcomp2, const float* dprob2, const float* gkl, long gkl_pitch_b, long gkl_pitch_t, const void* dlv_ext,
+                             void* dmean, void* dv, float* part1, float* part2, float* part3, float* partb, int B, int T, int HW, int LD,
+                             void* stream);
+
 /* ---- y = silu(x) over a contiguous bf16 tensor of n elements (n % 8 == 0): the activation between the MLP's two Linear layers
  *      (train/layers.py:186-189). ---- */
 int vvae_silu_bf16(const void* x, void* y, long n, void* stream);
@@ -370,6 +385,8 @@ int vvae_gemm_pp_bf16(const void* A, int lda, const void* B, int ldb, void* C, i
 /* Timing-only hook of the -DPP_ABLATION build of vvae_gemm_pp_bf16 (tools/pp_ablation.py): bit 0 no DMA, bit 1 no fragment reads, bit 2 no MFMAs
  * in the plain product's main loop (wrong results); the shipped library ignores it. */
 int vvae_gemm_pp_ablate(int bits);
+/* Tuning hook of vvae_gemm_pp_bf16: 1 (default) = the last epilogue of a launch goes through the idle operand rings, all units of a wave at once; 0 = unit by unit. */
+int vvae_gemm_pp_final_ring(int on);
 /* Test / tuning hook: start-time stagger between the two workgroup cohorts of vvae_gemm_nt_bf16, in units of 2048 cycles (default 0 = off: a gain on
  * back-to-back copies of one product, none inside the train step). */
 int vvae_gemm_nt_stagger(int units);

@@ -188,3 +188,116 @@ def test_encoder_head_vs_oracle(dev, b, t, hw, ld):
         assert leaf.grad is not None and leaf.grad.shape == g_ref[k].shape, k
         bar(k, leaf.grad, g_emu[k], g_ref[k])
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("b,t,hw,ld", [(2, 3, 16, 96), (1, 4, 256, 96), (2, 2, 40, 8)])
+def test_encoder_head_rl_vs_oracle(dev, b, t, hw, ld):
+    """ops.encoder_head_rl (the rl flavour's heads, reparameterisation, KL, pair doubling, Bernoulli frame masks and latent gate, one launch
+    each way) against oracle.model.encoder_heads(flavour="rl") + reparameterise + bernoulli_mask + latent_gate + oracle.loss.kl_per_sample
+    (train/rl_model.py:50-60,119-147), fp32 and bf16-emulated: identical frame masks, pair-doubled outputs, every gradient within the bf16 bar.
+    Gradients arrive at the compressed representation, at the pair-doubled probability (as the REINFORCE term's does) and at the KL term."""
+    from video_vae_amd import ops
+    g = torch.Generator().manual_seed(300 + hw)
+    bf = torch.bfloat16
+    mean_in = (torch.randn(b, t, hw, ld, generator=g) * 0.5).to(bf).float()
+    v_in = (torch.randn(b, t, hw, ld, generator=g) * 1.5).to(bf).float()
+    eye = torch.eye(ld)
+    p = {"spatial_compression.kernel": torch.cat([eye, torch.zeros(ld, ld)]), "spatial_compression.bias": torch.zeros(ld),
+         "variance_estimator.kernel": torch.cat([torch.zeros(ld, ld), eye]), "variance_estimator.bias": torch.zeros(ld),
+         "selection_layer1.kernel": torch.randn(ld, 1, generator=g) * ld ** -0.5, "selection_layer1.bias": torch.randn(1, generator=g) * 0.1,
+         "selection_layer2.kernel": torch.randn(hw, 1, generator=g) * hw ** -0.5, "selection_layer2.bias": torch.randn(1, generator=g) * 0.1}
+    fill = torch.randn(1, 1, 1, ld, generator=g) * 0.02
+    eps = torch.randn(b, t, hw, ld, generator=g)
+    mask = torch.ones(b, t)
+    mask[0, -1] = 0.0
+    # uniforms far from any selection probability (those are sigmoid(1 + O(0.3)) ~ 0.7): 0.05 keeps the frame, 0.97 drops it, on both paths
+    u2 = torch.where(torch.rand(2 * b, t, 1, 1, generator=g) < 0.6, torch.full((), 0.05), torch.full((), 0.97))
+    u2[0, 0], u2[1, 0] = 0.05, 0.97
+    gcomp = torch.randn(2 * b, t, hw, ld, generator=g).to(bf)
+    gsel = torch.randn(2 * b, t, 1, 1, generator=g)
+    gkl = torch.randn(2 * b, generator=g)
+    learn = ("selection_layer1.kernel", "selection_layer1.bias", "selection_layer2.kernel", "selection_layer2.bias")
+
+    def oracle(dtype):
+        x = torch.cat([mean_in, v_in], dim=-1).requires_grad_(True)
+        po = {k: (v.clone().requires_grad_(True) if k in learn else v) for k, v in p.items()}
+        fo = fill.clone().requires_grad_(True)
+        mean, lv, prob = OM.encoder_heads(po, x, None, True, "rl", dtype)
+        z = OM.reparameterise(mean, lv, eps, True, dtype)
+        sel2 = prob.reshape(b, t, 1, 1).repeat_interleave(2, dim=0)                # rl_model.py:136
+        m2 = OM.bernoulli_mask(sel2, u2).float()
+        comp = OM.latent_gate(fo, m2, z.repeat_interleave(2, dim=0))
+        kl = OLoss.kl_per_sample(mean.repeat_interleave(2, dim=0), lv.repeat_interleave(2, dim=0), mask.repeat_interleave(2, dim=0), dtype)
+        ((comp * gcomp.float()).sum() + (sel2 * gsel).sum() + (kl * gkl).sum()).backward()
+        grads = {"d mean": x.grad[..., :ld], "d v": x.grad[..., ld:], "d fill": fo.grad}
+        grads.update({"d " + k: po[k].grad for k in learn})
+        return {"log_variance": lv.detach().repeat_interleave(2, dim=0), "mean": mean.detach().repeat_interleave(2, dim=0), "comp": comp.detach(),
+                "sel": sel2.detach(), "mask": m2, "kl": kl.detach()}, grads
+    (o_ref, g_ref), (o_emu, g_emu) = oracle(torch.float32), oracle(bf)
+    assert torch.equal(o_emu["mask"], o_ref["mask"]) and 0 < float(o_ref["mask"].sum()) < 2 * b * t
+
+    names = ("d mean", "d v", "d selection_layer1.kernel", "d selection_layer1.bias", "d selection_layer2.kernel", "d selection_layer2.bias", "d fill")
+    vals = (mean_in.to(dev, bf), v_in.to(dev, bf), p["selection_layer1.kernel"].to(dev), p["selection_layer1.bias"].to(dev),
+            p["selection_layer2.kernel"].to(dev), p["selection_layer2.bias"].to(dev), fill.to(dev))
+    leaves = {k: v.requires_grad_(True) for k, v in zip(names, vals)}
+    lv2, mean2, comp2, sel2, mask2, klf = ops.encoder_head_rl(*leaves.values(), u2.to(dev), eps.to(dev), mask.to(dev))
+    kl = klf.sum(1)
+    ((comp2.float() * gcomp.to(dev).float()).sum() + (sel2 * gsel.to(dev)).sum() + (kl * gkl.to(dev)).sum()).backward()
+    assert comp2.shape == (2 * b, t, hw, ld) and comp2.dtype == bf and sel2.shape == mask2.shape == (2 * b, t, 1, 1) and klf.shape == (2 * b, t)
+    assert torch.equal(mask2.cpu(), o_ref["mask"])
+    assert torch.equal(mean2[0::2], mean2[1::2]) and torch.equal(lv2[0::2], lv2[1::2]) and torch.equal(sel2[0::2], sel2[1::2])
+    assert torch.equal(mean2[0::2].cpu().float(), mean_in)
+    bad = []
+
+    def bar(name, got, emu, ref):
+        e_got, e_emu = rel_l2(got, ref), rel_l2(emu, ref)
+        allowed = BF16_FACTOR * max(e_emu, ONE_BF16_ROUNDING if ref.numel() == 1 else 0.0) + BF16_FLOOR
+        if not e_got <= allowed:
+            bad.append(f"{name}: gpu vs fp32 oracle {e_got:.3e}, emulated oracle {e_emu:.3e}, allowed {allowed:.3e}")
+    for k, got in (("log_variance", lv2), ("comp", comp2), ("sel", sel2), ("kl", kl)):
+        bar(k, got, o_emu[k], o_ref[k])
+    for k, leaf in leaves.items():
+        assert leaf.grad is not None and leaf.grad.shape == g_ref[k].shape, k
+        bar(k, leaf.grad, g_emu[k], g_ref[k])
+    assert not bad, "\n".join(bad)
+
+
+def test_rl_model_fused_heads_equal_the_unfused_path(dev):
+    """rl_model.VideoVAE.forward through ops.encoder_head_rl against the same model with the fused heads switched off (framework softplus /
+    log / addmm / sigmoid / repeat_interleave, ops.reparameterise_kl, ops.rl_gate): the 6-tuple, the loss terms and the flat gradient."""
+    import video_vae_amd as V
+    from video_vae_amd import loss as L, ops, optim, rl_model
+    from test_gpu_model import TINY
+    kw = dict(TINY, height=64, width=64)          # hw = 64 patches, latent 48: shapes the fused heads take
+    m = rl_model.VideoVAE(rngs=V.Rngs(2), dtype=torch.bfloat16, **kw).to(dev)
+    opt = optim.Optimizer(m, 0.0)
+    g = torch.Generator().manual_seed(3)
+    video = torch.rand((2, 8, 64, 64, 3), generator=g).to(dev, torch.bfloat16)
+    mask = torch.ones(2, 8, device=dev)
+    mask[1, 6:] = 0
+    noise = {"reparam_eps": torch.randn((2, 8, 64, 48), generator=g), "bernoulli_u": torch.where(torch.rand((4, 8, 1, 1), generator=g) < 0.6, 0.03, 0.98)}
+    noise["bernoulli_u"][0::2, 0], noise["bernoulli_u"][1::2, 0] = 0.03, 0.98
+    runs = []
+    for fused in (True, False):
+        rl_model.FUSED_HEADS[0] = fused
+        try:
+            rngs = V.Rngs(3)
+            for k, v in noise.items():
+                rngs.inject(k, v)
+            opt.zero_grad()
+            loss, aux = L.loss_fn(m, video, L.expand_mask(mask, 64), mask, rngs, L.HPARAMS)
+            with ops.deferred_wgrad(opt):
+                loss.backward()
+            for bk in range(len(opt.buckets)):
+                if not opt.landed[bk]:
+                    opt._land(bk)
+            runs.append((loss.detach().clone(), {k: v.detach().clone() for k, v in aux.items()}, opt.g.clone()))
+        finally:
+            rl_model.FUSED_HEADS[0] = True
+    (l1, a1, g1), (l0, a0, g0) = runs
+    assert_close(l1, l0, rtol=2e-3, atol=1e-5, what="loss")
+    for k in a0:
+        if k != "reconstruction":
+            assert_close(a1[k], a0[k], rtol=2e-3, atol=1e-5, what=k)
+    assert_close_scaled(a1["reconstruction"].float(), a0["reconstruction"].float(), rel=2e-2, what="reconstruction")
+    assert_close_scaled(g1, g0, rel=2e-2, what="flat gradient")

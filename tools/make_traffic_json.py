@@ -24,6 +24,7 @@ KERNELS = {
     "layernorm_fwd_kernel": (["layernorm_fwd_kernel"], ["layernorm.hip", "common.hpp"]),
     "layernorm_bwd_kernel": (["layernorm_bwd_kernel"], ["layernorm.hip", "common.hpp"]),
     "gemm_nt_kernel": (["gemm_nt_kernel"], ["gemm_nt.hip", "common.hpp"]),
+    "gemm_pp_kernel": (["gemm_pp_kernel"], ["gemm_pp.hip", "common.hpp"]),
 }
 
 

@@ -57,7 +57,11 @@ for N, K in [(1536, 768), (768, 1536), (768, 512), (512, 768), (768, 768), (1536
         ts = [tmg(lambda: ops.gemm_nt(a, b, bias, form=form)), tmg(lambda: ops.gemm_nt(a, b, bias, res, ops.EPI_RES, form=form)),
               tmg(lambda: ops.gemm_nt(a, b, bias, None, ops.EPI_SILU, form=form)), tmg(lambda: ops.gemm_nt(a, b, None, res, ops.EPI_MUL_DSILU, form=form))]
         row.append(f"{form}: plain {ts[0]:6.1f} ({fl / ts[0] / 1e6:5.0f} TF) +res {ts[1]:6.1f} silu-pair {ts[2]:6.1f} *dsilu {ts[3]:6.1f}")
-    t0 = tmg(lambda: ops.gemm_nt(a, b, bias, form="pp"))
-    lib().vvae_gemm_pp_ablate(0)
-    row.append(f"pp pieces in front: plain {t0:6.1f}")
+    reps = []
+    for _ in range(2):                                             # last epilogue of a launch: unit by unit (0) / through the idle rings (1), alternating
+        for fr in (0, 1):
+            lib().vvae_gemm_pp_final_ring(fr)
+            reps.append((fr, tmg(lambda: ops.gemm_nt(a, b, bias, form="pp")), tmg(lambda: ops.gemm_nt(a, b, None, res, ops.EPI_MUL_DSILU, form="pp"))))
+    lib().vvae_gemm_pp_final_ring(1)
+    row.append("pp last epilogue (rings?, plain, *dsilu): " + " ".join(f"({fr}, {p0:.1f}, {p3:.1f})" for fr, p0, p3 in reps))
     print("   " + " | ".join(row), flush=True)

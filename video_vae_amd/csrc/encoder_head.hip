@@ -62,12 +62,19 @@ __device__ __forceinline__ float seq_len(const float* __restrict__ mrow, int T)
     return fmaxf(s, 1.0f);
 }
 
+// The rl flavour (RL = true; reference train/rl_model.py:50-60,119-147): the selection is the PROBABILITY sigmoid(logits) (no Gumbel noise, no
+// rounding), every clip is doubled into a pair (samples 2k, 2k + 1) whose members draw their own Bernoulli frame mask u < probability and
+// gate the shared latent with it; log-variance and mean are returned pair-doubled as well.  ``u``: (2B, T) uniforms; ``logvar`` / ``comp``: (2B, T,
+// HW, LD); ``mean2`` likewise; ``mask2`` (2B, T) the sampled frame masks; ``sel_out`` (2B, T) the pair-doubled probability; ``y_out`` the logits; ``kl_frame`` (B, T).
+struct EhRl { bf16_t* mean2; float* mask2; };
+
 // LDS: w2b[HW] | pt[HW * CG] | red[16] | slot[4]
+template <bool RL>
 __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
     const bf16_t* __restrict__ mean, const bf16_t* __restrict__ v, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u, const float* __restrict__ eps,
     const float* __restrict__ mask, const float* __restrict__ fill, bf16_t* __restrict__ logvar, bf16_t* __restrict__ comp,
-    float* __restrict__ sel_out, float* __restrict__ y_out, float* __restrict__ s1_out, float* __restrict__ kl_frame, EhDims d)
+    float* __restrict__ sel_out, float* __restrict__ y_out, float* __restrict__ s1_out, float* __restrict__ kl_frame, EhDims d, EhRl rl)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w2b = lds;
@@ -106,11 +113,25 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
     }
     const float dot2 = block_total(acc, red, slot);
     const float logits = bfr(bfr(dot2 + bfr(b2[0])) + 1.f);
-    float uc = u[f];
-    uc = uc < 1e-20f ? 1e-20f : (uc > 1.f - 1e-20f ? 1.f - 1e-20f : uc);
-    const float y = logits + logf(uc / (1.f - uc));
-    const float sel = rintf(1.f / (1.f + expf(-y)));
-    if (tid == 0) { sel_out[f] = sel; y_out[f] = y; }
+    float y, sel;
+    bool keep2[2] = {false, false};
+    if (RL) {
+        y = logits;
+        sel = bfr(1.f / (1.f + expf(-y)));                    // the probability, an array of the compute dtype (rl_model.py:59)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) keep2[p] = u[(long)(2 * b + p) * d.T + t] < sel;          // rl_model.py:141-142
+        if (tid < 2) rl.mask2[(long)(2 * b + tid) * d.T + t] = keep2[tid] ? 1.f : 0.f;
+    } else {
+        float uc = u[f];
+        uc = uc < 1e-20f ? 1e-20f : (uc > 1.f - 1e-20f ? 1.f - 1e-20f : uc);
+        y = logits + logf(uc / (1.f - uc));
+        sel = rintf(1.f / (1.f + expf(-y)));
+    }
+    if (tid == 0) {
+        y_out[f] = y;
+        if (RL) { sel_out[(long)(2 * b) * d.T + t] = sel; sel_out[(long)(2 * b + 1) * d.T + t] = sel; }      // the pair-doubled probability
+        else sel_out[f] = sel;
+    }
 
     // ---- phase B: log-variance, reparameterisation, gate, KL ----
     float kl = 0.f;
@@ -122,26 +143,48 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_fwd_kernel(
             VecIO<bf16_t, 8>::load(v + g, vv);
             const float4 e0 = *reinterpret_cast<const float4*>(eps + g), e1 = *reinterpret_cast<const float4*>(eps + g + 4);
             const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+            float zz[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 lv[e] = bfr(__logf(softplus_bf(vv[e])));
-                const float z = m[e] + ee[e] * __expf(0.5f * lv[e]);
-                o[e] = sel != 0.f ? z : fr[e];
+                zz[e] = m[e] + ee[e] * __expf(0.5f * lv[e]);
+                o[e] = sel != 0.f ? zz[e] : fr[e];
                 kl += 0.5f * (__expf(lv[e]) - 1.f - lv[e] + m[e] * m[e]);
             }
-            VecIO<bf16_t, 8>::store(logvar + g, lv);
-            VecIO<bf16_t, 8>::store(comp + g, o);
+            if (RL) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {                  // the pair's rows: frame (2b + p, t) of the doubled batch
+                    const long g2 = ((long)(2 * b + p) * d.T + t) * d.HW * d.LD + cg * 8 + (long)j * d.LD;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = keep2[p] ? zz[e] : fr[e];
+                    VecIO<bf16_t, 8>::store(logvar + g2, lv);
+                    VecIO<bf16_t, 8>::store(rl.mean2 + g2, m);
+                    VecIO<bf16_t, 8>::store(comp + g2, o);
+                }
+            } else {
+                VecIO<bf16_t, 8>::store(logvar + g, lv);
+                VecIO<bf16_t, 8>::store(comp + g, o);
+            }
         }
     const float klt = block_total(kl, red, slot);
     if (tid == 0) {
         const float* mrow = mask + (long)b * d.mask_pitch;
-        kl_frame[f] = klt * mrow[t] / (seq_len(mrow, d.T) * (float)d.T * (float)d.HW * (float)d.LD);
+        const float kf = klt * mrow[t] / (seq_len(mrow, d.T) * (float)d.T * (float)d.HW * (float)d.LD);
+        if (RL) {                                             // both members of a pair share mean / log-variance / mask: the same KL share
+            kl_frame[(long)(2 * b) * d.T + t] = kf;
+            kl_frame[(long)(2 * b + 1) * d.T + t] = kf;
+        } else kl_frame[f] = kf;
     }
 }
 
 // LDS: w2b[HW] | colred[TY * LD] | red[16] | slot[4]
 // part1 (F, LD) = dW1, part2 (F, HW) = dW2, part3 (F, LD) = d fill, partb (2, F, 4) = [db1 0 0 0] then [db2 0 0 0]: this frame's row of each
 // (row widths are multiples of four floats: what the caller's fold kernels take).
+// RL: ``logvar`` is the pair-doubled forward output (row 2b is read), ``dcomp`` (2B, T, HW, LD) and ``sel_in`` = the frame masks (2B, T): the latent's
+// gradient is the sum of the pair members that kept the frame, the fill token's the sum of those that dropped it; no gradient flows through the
+// sampled mask (rl_model.py:141-144); ``dsel`` (2B, T): the gradient at the pair-doubled probability (its two rows add up); ``y_in`` the logits;
+// ``gkl`` as in the model flavour, (B, T).
+template <bool RL>
 __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
     const bf16_t* __restrict__ mean, const bf16_t* __restrict__ v, const bf16_t* __restrict__ logvar, const float* __restrict__ eps,
     const float* __restrict__ mask, const float* __restrict__ fill, const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ y_in,
@@ -158,8 +201,12 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
     const int tid = threadIdx.x, cg = tid % d.CG, ty = tid / d.CG;
     const bool active = ty < d.TY;
     const long base = (long)f * d.HW * d.LD + cg * 8;
-    const float sel = sel_in[f];
+    const long f2 = (long)(2 * b) * d.T + t;                     // RL: frame (2b, t) of the doubled batch; its pair partner is d.T frames further
+    const long base2 = f2 * d.HW * d.LD + cg * 8, pair = (long)d.T * d.HW * d.LD;
+    const float sel = RL ? 0.f : sel_in[f];
     const bool keep = sel != 0.f;
+    const bool k0 = RL && sel_in[f2] != 0.f, k1 = RL && sel_in[f2 + d.T] != 0.f;
+    const long lvbase = RL ? base2 : base;                       // where this frame's log-variance lies
 
     for (int j = tid; j < d.HW; j += blockDim.x) w2b[j] = bfr(w2[j]);
     float w1r[8], fr[8];
@@ -170,7 +217,7 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
     float ds = 0.f, dfa[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) dfa[e] = 0.f;
-    if (active && dcomp)
+    if (!RL && active && dcomp)
         for (int j = ty; j < d.HW; j += d.TY) {
             const long g = base + (long)j * d.LD;
             float m[8], lvv[8], dc[8];
@@ -191,12 +238,16 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
     const float yy = y_in[f];
     const float sg = 1.f / (1.f + expf(-yy));
     const float dl_f = (dsg + (dsel ? dsel[f] : 0.f)) * sg * (1.f - sg);
-    const float dl = (d.dbg & 1) ? dl_f : bfr(dl_f);
+    const float dl = RL ? bfr((dsel ? dsel[f2] + dsel[f2 + d.T] : 0.f) * sg * (1.f - sg)) : ((d.dbg & 1) ? dl_f : bfr(dl_f));
 
     // ---- phase 2: token / element gradients ----
     const float* mrow = mask + (long)b * d.mask_pitch;
     float kscale = 0.f;
-    if (gkl) kscale = gkl[(long)b * gkl_pitch_b + (long)t * gkl_pitch_t] * mrow[t] / (seq_len(mrow, d.T) * (float)d.T * (float)d.HW * (float)d.LD);
+    if (gkl) {
+        const float gk = RL ? gkl[(long)(2 * b) * gkl_pitch_b + (long)t * gkl_pitch_t] + gkl[(long)(2 * b + 1) * gkl_pitch_b + (long)t * gkl_pitch_t]
+                            : gkl[(long)b * gkl_pitch_b + (long)t * gkl_pitch_t];
+        kscale = gk * mrow[t] / (seq_len(mrow, d.T) * (float)d.T * (float)d.HW * (float)d.LD);
+    }
     float dw1[8], db1 = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dw1[e] = 0.f;
@@ -207,8 +258,22 @@ __global__ __launch_bounds__(EH_MAX_THREADS) void encoder_head_bwd_kernel(
             float m[8], vv[8], lvv[8], dc[8], dm[8], dvv[8], dx[8];
             VecIO<bf16_t, 8>::load(mean + g, m);
             VecIO<bf16_t, 8>::load(v + g, vv);
-            VecIO<bf16_t, 8>::load(logvar + g, lvv);
-            if (dcomp && keep) VecIO<bf16_t, 8>::load(dcomp + g, dc);
+            VecIO<bf16_t, 8>::load(logvar + lvbase + (long)j * d.LD, lvv);
+            if (RL) {
+                float d0[8], d1[8];
+                if (dcomp) {
+                    VecIO<bf16_t, 8>::load(dcomp + base2 + (long)j * d.LD, d0);
+                    VecIO<bf16_t, 8>::load(dcomp + base2 + pair + (long)j * d.LD, d1);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { d0[e] = 0.f; d1[e] = 0.f; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dc[e] = (k0 ? d0[e] : 0.f) + (k1 ? d1[e] : 0.f);
+                    dfa[e] += (k0 ? 0.f : d0[e]) + (k1 ? 0.f : d1[e]);
+                }
+            } else if (dcomp && keep) VecIO<bf16_t, 8>::load(dcomp + g, dc);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dc[e] = 0.f;
@@ -305,8 +370,8 @@ extern "C" int vvae_encoder_head_fwd(const void* mean, const void* v, const floa
         !eh_dims(B, T, HW, LD, mask_pitch, d, threads) || !vvae_encoder_head_ok(B, T, HW, LD) ||
         ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)eps | (uintptr_t)logvar | (uintptr_t)comp) % 16) return VVAE_ERR_BAD_ARG;
     const size_t lds = ((size_t)HW + (size_t)HW * d.CG + 20) * 4;
-    hipLaunchKernelGGL(encoder_head_fwd_kernel, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
-                       w1, b1, w2, b2, u, eps, mask, fill, (bf16_t*)logvar, (bf16_t*)comp, sel, y, s1, kl_frame, d);
+    hipLaunchKernelGGL(encoder_head_fwd_kernel<false>, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
+                       w1, b1, w2, b2, u, eps, mask, fill, (bf16_t*)logvar, (bf16_t*)comp, sel, y, s1, kl_frame, d, EhRl{nullptr, nullptr});
     VVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -326,9 +391,52 @@ extern "C" int vvae_encoder_head_bwd(const void* mean, const void* v, const void
         ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)logvar | (uintptr_t)eps | (uintptr_t)dcomp | (uintptr_t)dlv_ext | (uintptr_t)dmean | (uintptr_t)dv) % 16)
         return VVAE_ERR_BAD_ARG;
     const size_t lds = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
-    hipLaunchKernelGGL(encoder_head_bwd_kernel, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
+    hipLaunchKernelGGL(encoder_head_bwd_kernel<false>, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
                        (const bf16_t*)logvar, eps, mask, fill, w1, w2, y, s1, sel, (const bf16_t*)dcomp, dsel, gkl, gkl_pitch_b, gkl_pitch_t, (const bf16_t*)dlv_ext, (bf16_t*)dmean,
                        (bf16_t*)dv, part1, part2, part3, partb, d);
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// The rl flavour's heads, reparameterisation, KL, pair doubling, Bernoulli frame masks and latent gate in one launch each way (reference
+// train/rl_model.py:50-60,119-147).  mean, v bf16 (B, T, HW, LD); u fp32 (2B, T) uniforms; eps fp32 (B, T, HW, LD); mask rows of T per CLIP.
+// -> logvar2, mean2, comp2 bf16 (2B, T, HW, LD) (samples 2k, 2k + 1 are a pair); prob2 fp32 (2B T) = sigmoid(logits) rounded to bf16, pair-doubled; mask2 fp32
+//    (2B T) = u < prob; y fp32 (B T) the logits and s1 fp32 (B T, HW) (kept for backward); kl_frame2 fp32 (2B, T): summed over a row's frames it is the
+//    per-sample KL term of that member of the doubled batch.
+extern "C" int vvae_encoder_head_rl_fwd(const void* mean, const void* v, const float* w1, const float* b1, const float* w2, const float* b2,
+                                        const float* u2, const float* eps, const float* mask, long mask_pitch, const float* fill, void* logvar2,
+                                        void* mean2, void* comp2, float* prob, float* mask2, float* y, float* s1, float* kl_frame2, int B, int T, int HW,
+                                        int LD, void* stream)
+{
+    EhDims d; int threads;
+    if (!mean || !v || !w1 || !b1 || !w2 || !b2 || !u2 || !eps || !mask || !fill || !logvar2 || !mean2 || !comp2 || !prob || !mask2 || !y || !s1 ||
+        !kl_frame2 || !eh_dims(B, T, HW, LD, mask_pitch, d, threads) || !vvae_encoder_head_ok(B, T, HW, LD) ||
+        ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)eps | (uintptr_t)logvar2 | (uintptr_t)mean2 | (uintptr_t)comp2) % 16) return VVAE_ERR_BAD_ARG;
+    const size_t lds = ((size_t)HW + (size_t)HW * d.CG + 20) * 4;
+    hipLaunchKernelGGL(encoder_head_fwd_kernel<true>, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
+                       w1, b1, w2, b2, u2, eps, mask, fill, (bf16_t*)logvar2, (bf16_t*)comp2, prob, y, s1, kl_frame2, d, EhRl{(bf16_t*)mean2, mask2});
+    VVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// logvar2: the forward's pair-doubled output; mask2 (2B T) its frame masks; dcomp2 bf16 (2B, T, HW, LD) or NULL; dprob2 fp32 (2B T) or NULL: the gradient
+// at the pair-doubled probability; gkl fp32 or NULL: the gradient of kl_frame2[i][t] at gkl[i * gkl_pitch_b + t * gkl_pitch_t], i < 2B; dlv_ext bf16
+// (B, T, HW, LD) or NULL.  -> dmean, dv bf16 (B, T, HW, LD) and the partial rows of vvae_encoder_head_bwd (one per frame of the B T).
+extern "C" int vvae_encoder_head_rl_bwd(const void* mean, const void* v, const void* logvar2, const float* eps, const float* mask, long mask_pitch,
+                                        const float* fill, const float* w1, const float* w2, const float* y, const float* s1, const float* mask2,
+                                        const void* dcomp2, const float* dprob2, const float* gkl, long gkl_pitch_b, long gkl_pitch_t, const void* dlv_ext,
+                                        void* dmean, void* dv, float* part1, float* part2, float* part3, float* partb, int B, int T, int HW, int LD,
+                                        void* stream)
+{
+    EhDims d; int threads;
+    if (!mean || !v || !logvar2 || !eps || !mask || !fill || !w1 || !w2 || !y || !s1 || !mask2 || !dmean || !dv || !part1 || !part2 || !part3 || !partb ||
+        !eh_dims(B, T, HW, LD, mask_pitch, d, threads) || !vvae_encoder_head_ok(B, T, HW, LD) ||
+        ((uintptr_t)mean | (uintptr_t)v | (uintptr_t)logvar2 | (uintptr_t)eps | (uintptr_t)dcomp2 | (uintptr_t)dlv_ext | (uintptr_t)dmean | (uintptr_t)dv) % 16)
+        return VVAE_ERR_BAD_ARG;
+    const size_t lds = ((size_t)HW + (size_t)d.TY * LD + 20) * 4;
+    hipLaunchKernelGGL(encoder_head_bwd_kernel<true>, dim3(B * T), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)mean, (const bf16_t*)v,
+                       (const bf16_t*)logvar2, eps, mask, fill, w1, w2, y, s1, mask2, (const bf16_t*)dcomp2, dprob2, gkl, gkl_pitch_b, gkl_pitch_t,
+                       (const bf16_t*)dlv_ext, (bf16_t*)dmean, (bf16_t*)dv, part1, part2, part3, partb, d);
     VVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -35,7 +35,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 64, ROWB = BK * 2;
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SILU = 2, EPI_MUL_DSILU = 3 };
 
-struct Dims { int M, N, K, lda, ldb, ldc, ldr, ldc2, tiles; };
+struct Dims { int M, N, K, lda, ldb, ldc, ldr, ldc2, tiles, final_ring; };
 
 template <int BM_, int BN_>
 struct Cfg {
@@ -82,6 +82,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f
 // give-back item 6: in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz); the values go to a buffer nothing else reads
 __device__ unsigned long long g_pp_stamps[256 * 4];
 #endif
+int g_pp_final_ring = 1;  // vvae_gemm_pp_final_ring: the last epilogue of a launch through the idle operand rings (1) or through the wave's 1.25 KB (0)
 int g_pp_ablate = 0;      // builds with -DPP_ABLATION only (tools/pp_ablation.py): 1 no DMA behind the prologue, 2 no fragment reads, 4 no MFMAs
 
 template <typename C, int EPI, int ABL = 0>
@@ -208,7 +209,14 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
     const float* bias_lds = reinterpret_cast<const float*>(smem + C::BIAS_OFF);
     constexpr bool has_res = EPI == EPI_RES || EPI == EPI_MUL_DSILU;
     const int w_off = fr * C::SCR_PITCH + kg * 8, r_off = (lane >> 2) * C::SCR_PITCH + (lane & 3) * 16;
-    auto epilogue = [&](int tile) {
+    // ``final_tag``: the LAST epilogue of the launch.  The operand rings are quiet then (every staged k-tile has landed and been read), so each
+    // wave takes 16 KB of them as scratch for ALL its units at once: all writes, one wait, all reads, all stores -- instead of twelve dependent
+    // LDS round trips through the 1.25 KB it owns while the rings are live.
+    auto epilogue = [&](int tile, auto final_tag) {
+        constexpr bool FINAL = decltype(final_tag)::value;
+        constexpr int NU = (NB16 / 2) * MB16;                // units of a wave
+        static_assert(NU * C::SCR_WAVE <= 16 * 1024 && 8 * 16 * 1024 <= C::SCR_OFF, "final scratch inside the rings");
+        unsigned char* sbase = FINAL ? smem + wave * 16 * 1024 : scr;
         int m0, n0;
         origin(tile, m0, n0);
         const long row0 = (long)(m0 + wm * C::WTM + (lane >> 2));
@@ -224,48 +232,63 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int j = 0; j < MB16; ++j) rq[ip][j] = *reinterpret_cast<const uint4*>(res + (row0 + j * 16) * d.ldr + col0 + ip * 32);
         }
+        auto park = [&](int ip, int j, unsigned char* dst) {     // acc (+ bias) of one unit, rounded, into scratch rows
 #pragma unroll
-        for (int ip = 0; ip < NB16 / 2; ++ip) {
-            float4 bv[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                bv[h] = bias ? *reinterpret_cast<const float4*>(bias_lds + bcol + (2 * ip + h) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < MB16; ++j) {
-                const long gm = row0 + j * 16;
-                const int gn = col0 + ip * 32;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 a = acc[2 * ip + h][j];
-                    uint2 pk;
-                    pk.x = pack2(a[0] + bv[h].x, a[1] + bv[h].y);
-                    pk.y = pack2(a[2] + bv[h].z, a[3] + bv[h].w);
-                    *reinterpret_cast<uint2*>(scr + w_off + h * 32) = pk;
-                }
-                const uint4 v = *reinterpret_cast<const uint4*>(scr + r_off);
-                if (EPI == EPI_NONE) {
-                    *reinterpret_cast<uint4*>(Cout + gm * d.ldc + gn) = v;
-                } else {
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                    float x[8], y[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
-                    if (EPI == EPI_SILU) {
-                        *reinterpret_cast<uint4*>(C2 + gm * d.ldc2 + gn) = v;         // the rounded pre-activation, kept for backward
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
-                    } else {
-                        const uint4 rp = rq[has_res ? ip : 0][j];
-                        const uint32_t rw[4] = {rp.x, rp.y, rp.z, rp.w};
-                        float r[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { r[2 * e] = __uint_as_float(rw[e] << 16); r[2 * e + 1] = __uint_as_float(rw[e] & 0xffff0000u); }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) y[e] = EPI == EPI_RES ? x[e] + r[e] : x[e] * dsilu_f(r[e]);
-                    }
-                    VecIO<bf16_t, 8>::store(Cout + gm * d.ldc + gn, y);
-                }
+            for (int h = 0; h < 2; ++h) {
+                const float4 bv = bias ? *reinterpret_cast<const float4*>(bias_lds + bcol + (2 * ip + h) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const f32x4 a = acc[2 * ip + h][j];
+                uint2 pk;
+                pk.x = pack2(a[0] + bv.x, a[1] + bv.y);
+                pk.y = pack2(a[2] + bv.z, a[3] + bv.w);
+                *reinterpret_cast<uint2*>(dst + w_off + h * 32) = pk;
             }
+        };
+        auto finish = [&](int ip, int j, const uint4 v) {        // a lane's 8 consecutive channels of one token: tail, 16-byte store
+            const long gm = row0 + j * 16;
+            const int gn = col0 + ip * 32;
+            if (EPI == EPI_NONE) {
+                *reinterpret_cast<uint4*>(Cout + gm * d.ldc + gn) = v;
+            } else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                float x[8], y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+                if (EPI == EPI_SILU) {
+                    *reinterpret_cast<uint4*>(C2 + gm * d.ldc2 + gn) = v;             // the rounded pre-activation, kept for backward
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
+                } else {
+                    const uint4 rp = rq[has_res ? ip : 0][j];
+                    const uint32_t rw[4] = {rp.x, rp.y, rp.z, rp.w};
+                    float r[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { r[2 * e] = __uint_as_float(rw[e] << 16); r[2 * e + 1] = __uint_as_float(rw[e] & 0xffff0000u); }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = EPI == EPI_RES ? x[e] + r[e] : x[e] * dsilu_f(r[e]);
+                }
+                VecIO<bf16_t, 8>::store(Cout + gm * d.ldc + gn, y);
+            }
+        };
+        if (FINAL) {
+            uint4 v[NU];
+#pragma unroll
+            for (int ip = 0; ip < NB16 / 2; ++ip)
+#pragma unroll
+                for (int j = 0; j < MB16; ++j) park(ip, j, sbase + (ip * MB16 + j) * C::SCR_WAVE);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) v[u] = *reinterpret_cast<const uint4*>(sbase + u * C::SCR_WAVE + r_off);
+#pragma unroll
+            for (int ip = 0; ip < NB16 / 2; ++ip)
+#pragma unroll
+                for (int j = 0; j < MB16; ++j) finish(ip, j, v[ip * MB16 + j]);
+        } else {
+#pragma unroll
+            for (int ip = 0; ip < NB16 / 2; ++ip)
+#pragma unroll
+                for (int j = 0; j < MB16; ++j) {
+                    park(ip, j, sbase);
+                    finish(ip, j, *reinterpret_cast<const uint4*>(sbase + r_off));
+                }
         }
     };
     constexpr int NST = (EPI == EPI_SILU ? 2 : 1) * (NB16 / 2) * MB16;     // stores a wave's epilogue leaves in flight
@@ -274,8 +297,8 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
     // ---- prologue: the launch's bias vector (waves 0 .. N/256-1, one 1-KiB piece each); weights of k-tile 0 (waves 0-3); tokens of k-tiles 0, 1
     if (bias && wave * 256 + lane * 4 < d.N) glds16(bias + wave * 256 + lane * 4, smem + C::BIAS_OFF + wave * 1024);
     stage_next();
-    if (grp && G > 1) stage_next();
-    wait_vm<0>();
+    if (grp && G > 1) { stage_next(); wait_vm<PA>(); }       // k-tile 0 has landed; the token pieces of k-tile 1 may still be in flight
+    else wait_vm<0>();
     phase_barrier();
 #ifdef PP_ABLATION
     if (tid == 0 && blockIdx.x < 256) { g_pp_stamps[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); g_pp_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
@@ -287,7 +310,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             const bool ep = kt == 0 && g > 0;                // the previous tile's accumulators are still in the registers
             if (!has_res) read_frags();
             if (g + 1 < G) stage_next();                     // ahead of the epilogue's stores: see the wait below
-            if (ep) epilogue(tile - (int)gridDim.x);
+            if (ep) epilogue(tile - (int)gridDim.x, std::false_type{});
             if (has_res) read_frags();                       // tails with a second operand: its prefetch registers and the fragments are not live together
             wait_lgkm0();                                    // fragments in registers: the slots may be overwritten behind the barrier
             phase_barrier();
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
 #ifdef PP_ABLATION
         if (tid == 0 && blockIdx.x < 256) { g_pp_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); g_pp_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-        epilogue(tile - (int)gridDim.x);
+        if (d.final_ring) epilogue(tile - (int)gridDim.x, std::true_type{}); else epilogue(tile - (int)gridDim.x, std::false_type{});
         phase_barrier();                        // waves 4-7 run one segment longer
     } else {
         // ================= waves 4-7: L(g) at segment 2g + 1, C(g) at 2g + 2; they stage the token rows of k-tile g + 2 in L(g) =================
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             const bool st = g + 2 < G;
             if (!has_res) read_frags();
             if (st) stage_next();
-            if (ep) epilogue(tile - (int)gridDim.x);
+            if (ep) epilogue(tile - (int)gridDim.x, std::false_type{});
             if (has_res) read_frags();
             // tokens of k-tile g + 1 (staged in L(g-1), or the prologue) have landed; younger: an epilogue's stores of L(g-1) or of this phase
             // (never both: a tile has at least two k-tiles) and the pieces just staged
@@ -326,7 +349,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             phase_barrier();
             if (++kt == nk) { kt = 0; tile += gridDim.x; }
         }
-        epilogue(tile - (int)gridDim.x);
+        if (d.final_ring) epilogue(tile - (int)gridDim.x, std::true_type{}); else epilogue(tile - (int)gridDim.x, std::false_type{});
     }
 }
 
@@ -371,6 +394,7 @@ int launch_epi(const void* A, const void* B, void* Cout, const float* bias, cons
     }
     Dims dd = d;
     dd.tiles = (d.M / C::BM) * (d.N / C::BN);
+    dd.final_ring = g_pp_final_ring;
     // one workgroup per CU walking tiles b, b + 256, ... when they divide evenly, else one tile per workgroup
     const int grid = (dd.tiles > 256 && dd.tiles % 256 == 0) ? 256 : dd.tiles;
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::NT), C::LDS, s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)Cout, bias, (const bf16_t*)res, (bf16_t*)C2, dd);
@@ -390,6 +414,13 @@ int launch(const void* A, const void* B, void* Cout, const float* bias, const vo
 }
 
 }  // namespace pp
+
+// Tuning hook: 1 (default) = the last epilogue of a launch uses the idle operand rings as scratch for all of a wave's units at once; 0 = unit by unit.
+extern "C" int vvae_gemm_pp_final_ring(int on)
+{
+    pp::g_pp_final_ring = on ? 1 : 0;
+    return 0;
+}
 
 // Timing-only hook of the -DPP_ABLATION build (tools/pp_ablation.py): bit 0 no DMA behind the prologue, bit 1 no fragment reads, bit 2 no MFMAs
 // in the main loop of the plain product (wrong results).  The shipped library ignores it.
@@ -422,7 +453,7 @@ extern "C" int vvae_gemm_pp_bf16(const void* A, int lda, const void* B, int ldb,
         ((uintptr_t)C % 16) || (bias && ((uintptr_t)bias % 16))) return VVAE_ERR_BAD_ARG;
     if ((epi == pp::EPI_RES || epi == pp::EPI_MUL_DSILU) && (!res || ldr % 8 || ldr < N || ((uintptr_t)res % 16))) return VVAE_ERR_BAD_ARG;
     if (epi == pp::EPI_SILU && (!C2 || ldc2 % 8 || ldc2 < N || ((uintptr_t)C2 % 16))) return VVAE_ERR_BAD_ARG;
-    pp::Dims d{M, N, K, lda, ldb, ldc, ldr, ldc2, 0};
+    pp::Dims d{M, N, K, lda, ldb, ldc, ldr, ldc2, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     if (pp::pick(M, N, K) == 192) return pp::launch<pp::Pp192>(A, B, C, bias, res, C2, d, epi, s);
     return pp::launch<pp::Pp128>(A, B, C, bias, res, C2, d, epi, s);

@@ -1605,6 +1605,82 @@ def encoder_head(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt):
     return _EncoderHead.apply(mean, v, w1, b1, w2, b2, fill, u, eps, mask_bt)
 
 
+class _EncoderHeadRl(torch.autograd.Function):
+    """The rl flavour's heads + reparameterisation + KL + pair doubling + Bernoulli frame masks + latent gate in ONE launch each way
+    (vvae_encoder_head_rl_fwd / _bwd; reference train/rl_model.py:50-60,119-147): what rl_model.VideoVAE.forward did with softplus, log, two
+    addmm, add, sigmoid, ops.reparameterise_kl, five repeat_interleave and ops.rl_gate (and their backward launches)."""
+
+    @staticmethod
+    def forward(ctx, mean, v, w1, b1, w2, b2, fill, u2, eps, mask_bt):
+        b, t, hw, ld = mean.shape
+        mean, v = mean.contiguous(), v.contiguous()
+        dev = mean.device
+        w1f, b1f, w2f, b2f, ff = _f32(w1), _f32(b1), _f32(w2), _f32(b2), _f32(fill)
+        u2 = u2.reshape(2 * b, t).to(torch.float32).contiguous()
+        eps = eps.to(torch.float32).contiguous()
+        if mask_bt.dtype != torch.float32 or (mask_bt.shape[1] > 1 and mask_bt.stride(1) != 1):
+            mask_bt = mask_bt.to(torch.float32).contiguous()
+        shape2 = (2 * b, t, hw, ld)
+        logvar2, mean2, comp2 = (torch.empty(shape2, dtype=mean.dtype, device=dev) for _ in range(3))
+        sel2 = torch.empty((2 * b, t, 1, 1), dtype=torch.float32, device=dev)             # the pair-doubled probability
+        mask2 = torch.empty((2 * b, t, 1, 1), dtype=torch.float32, device=dev)
+        y = torch.empty((b * t,), dtype=torch.float32, device=dev)
+        s1 = torch.empty((b * t, hw), dtype=torch.float32, device=dev)
+        kl2 = torch.empty((2 * b, t), dtype=torch.float32, device=dev)
+        mp = mask_bt.stride(0) if mask_bt.shape[0] > 1 else 0
+        check(lib().vvae_encoder_head_rl_fwd(_p(mean), _p(v), _p(w1f), _p(b1f), _p(w2f), _p(b2f), _p(u2), _p(eps), _p(mask_bt), mp, _p(ff),
+                                             _p(logvar2), _p(mean2), _p(comp2), _p(sel2), _p(mask2), _p(y), _p(s1), _p(kl2), b, t, hw, ld, _stream()),
+              "vvae_encoder_head_rl_fwd")
+        ctx.save_for_backward(mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, mask2, logvar2)
+        ctx.params = (w1, b1, w2, b2, fill)
+        ctx.mark_non_differentiable(mask2)
+        ctx.set_materialize_grads(False)
+        return logvar2, mean2, comp2, sel2, mask2, kl2
+
+    @staticmethod
+    def backward(ctx, dlv2, dmean2, dcomp2, dsel2, _dmask2, gkl):
+        mean, v, eps, mask_bt, ff, w1f, w2f, y, s1, mask2, logvar2 = ctx.saved_tensors
+        w1, b1, w2, b2, fill = ctx.params
+        b, t, hw, ld = mean.shape
+        dev = mean.device
+        if dcomp2 is not None:
+            dcomp2 = dcomp2.to(torch.bfloat16).contiguous()
+        if dsel2 is not None:
+            dsel2 = dsel2.reshape(2 * b, t).to(torch.float32).contiguous()
+        # gradients arriving at the pair-doubled log-variance / mean copies (the loss reads them only through kl2; a caller that does
+        # use them pays two small framework launches)
+        dlv_ext = None if dlv2 is None else dlv2.reshape(b, 2, t, hw, ld).sum(1).to(torch.bfloat16).contiguous()
+        gb = gt = 0
+        if gkl is not None:
+            if gkl.dtype != torch.float32:
+                gkl = gkl.to(torch.float32)
+            gb, gt = gkl.stride(0), gkl.stride(1)
+        dmean, dv = torch.empty_like(mean), torch.empty_like(v)
+        f = b * t
+        part = torch.empty((2 * f * ld + f * hw + 8 * f,), dtype=torch.float32, device=dev)
+        p1, p2, p3 = part[:f * ld].view(f, ld), part[f * ld:f * (ld + hw)].view(f, hw), part[f * (ld + hw):f * (2 * ld + hw)].view(f, ld)
+        pb = part[f * (2 * ld + hw):].view(2, f, 4)
+        mp = mask_bt.stride(0) if mask_bt.shape[0] > 1 else 0
+        check(lib().vvae_encoder_head_rl_bwd(_p(mean), _p(v), _p(logvar2), _p(eps), _p(mask_bt), mp, _p(ff), _p(w1f), _p(w2f), _p(y), _p(s1), _p(mask2),
+                                             _p(dcomp2), _p(dsel2), _p(gkl), gb, gt, _p(dlv_ext), _p(dmean), _p(dv), _p(p1), _p(p2), _p(p3), _p(pb), b, t,
+                                             hw, ld, _stream()), "vvae_encoder_head_rl_bwd")
+        if dmean2 is not None:
+            dmean = dmean + dmean2.reshape(b, 2, t, hw, ld).sum(1).to(dmean.dtype)
+        dw1, _ = fold_partials(p1, w1, None, ld)
+        dw2, _ = fold_partials(p2, w2, None, hw)
+        dfill, _ = fold_partials(p3, fill, None, ld)
+        db1, _ = fold_partials(pb[0], b1, None, 1)
+        db2, _ = fold_partials(pb[1], b2, None, 1)
+        like = lambda g, p: None if g is None else g.reshape(p.shape).to(p.dtype)
+        return (dmean, dv, like(dw1, w1), like(db1, b1), like(dw2, w2), like(db2, b2), like(dfill, fill), None, None, None)
+
+
+def encoder_head_rl(mean, v, w1, b1, w2, b2, fill, u2, eps, mask_bt):
+    """-> (log_variance, mean, compressed_representation: bf16 (2b, t, hw, ld), pair-doubled; selection probability (2b, t, 1, 1) fp32;
+    selection_mask (2b, t, 1, 1) in {0, 1}; kl (2b, t): the per-sample KL term of the doubled batch as one partial sum per frame)."""
+    return _EncoderHeadRl.apply(mean, v, w1, b1, w2, b2, fill, u2, eps, mask_bt)
+
+
 # --------------------------------------------------------------------------------------------- the rl flavour's latent gate
 class _RlGate(torch.autograd.Function):
     """Pair doubling + Bernoulli frame masks + fill * (1 - mask) + z * mask of rl_model.VideoVAE (reference train/rl_model.py:136-145) in one

@@ -107,7 +107,10 @@ class Optimizer:
         # the MLP's fc1, whose product also emits SiLU); refreshed after every update from the bf16 shadow, one grouped launch per 64
         self.tpairs = []
         if self.shadow is not None and dev.type == "cuda":
-            want = [p for p in self.params if getattr(p, "want_t", False) and p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0]
+            # (the grouped transpose wants 16-byte aligned operands: a shadow slot behind an odd-sized parameter is 8-byte aligned only -- that layer
+            #  then simply has no transposed shadow and its forward runs the library product)
+            want = [p for p in self.params if getattr(p, "want_t", False) and p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0
+                    and p.bf16.data_ptr() % 16 == 0]
             if want:
                 tbuf = torch.zeros(sum(p.numel() for p in want), dtype=torch.bfloat16, device=dev)
                 o = 0

@@ -4,9 +4,12 @@ from einops import rearrange
 from torch import nn
 
 from . import ops
+from .layers import linear_pair
 from .model import Encoder as _Encoder, Decoder, frame_mask  # Decoder is identical in both flavours (rl_model.py:62-97)
 
 __all__ = ["Encoder", "Decoder", "VideoVAE"]
+
+FUSED_HEADS = [True]      # test switch: False = the unfused heads (framework ops + ops.reparameterise_kl + ops.rl_gate)
 
 
 class Encoder(_Encoder):
@@ -36,8 +39,24 @@ class VideoVAE(nn.Module):
         self.fill_token = nn.Parameter(torch.randn((1, 1, 1, ld), generator=key.generator("cpu")) * 0.02)
 
     def forward(self, x, mask, rngs, train=True):
-        mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
         self._kl = None
+        enc = self.encoder
+        if train and FUSED_HEADS[0] and type(enc) is Encoder and enc.gated_ok(x, self.fill_token):
+            # GPU train step: everything behind the encoder's two 768 -> ld products -- softplus / log, both selection layers, the sigmoid, the
+            # reparameterisation, the KL term, the pair doubling of mean / log-variance / selection, the Bernoulli frame masks and the latent gate --
+            # in one launch each way (ops.encoder_head_rl).  The noise draws keep the reference's order: reparameterisation, then Bernoulli.
+            sl1, sl2 = enc.selection_layer1, enc.selection_layer2
+            h = enc._features(x, mask)
+            mean1, v = linear_pair(h, enc.spatial_compression, enc.variance_estimator)
+            b, t = mean1.shape[0], mean1.shape[1]
+            eps = rngs.draw("reparam_eps", "normal", mean1.shape, mean1.device)
+            u = rngs.draw("bernoulli_u", "uniform", (2 * b, t, 1, 1), mean1.device)
+            log_variance, mean, compressed_representation, selection, selection_mask, kl2 = ops.encoder_head_rl(
+                mean1, v, sl1.kernel, sl1.bias, sl2.kernel, sl2.bias, self.fill_token, u, eps, frame_mask(mask, b, t))
+            self._kl = (mean, log_variance, kl2.sum(1))
+            reconstruction = self.decoder(compressed_representation, mask.repeat_interleave(2, dim=0), rngs, train=train)
+            return reconstruction, compressed_representation, selection, selection_mask, log_variance, mean
+        mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
         kl = None
         if train:
             noise = rngs.draw("reparam_eps", "normal", log_variance.shape, log_variance.device)
