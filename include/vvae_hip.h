@@ -150,8 +150,8 @@ int vvae_loss_tail_plain(const float* mse_ps, int mse_cols, const float* kl_ps, 
 /* The same for the pair / REINFORCE loss of the rl flavour (train/rl_nonadversarial.py:130-186; samples 2k, 2k + 1 are a pair): mse, mae fp32
  * (B2, cols) partial sums, perc fp32 [B2] or NULL, kl fp32 [B2], sel (probabilities) / act (sampled actions) / mask fp32 (B2, T).  out fp32 [9] = loss,
  * MSE, perceptual, selection_loss, kl_loss, mean density, mean trajectory probability, rl_loss, MAE.  grads fp32 [4 B2 + B2 T] = d loss / d mse |
- * mae | perc | kl (per sample) | sel.  B2 even, <= 1024. */
-int vvae_loss_tail_rl(const float* mse, const float* mae, int cols, const float* perc, const float* kl, const float* sel, const float* act,
+ * mae | perc | kl (per sample) | sel.  kl: (B2, kl_cols) partial sums of the per-sample term (kl_cols = 1: the term itself).  B2 even, <= 1024. */
+int vvae_loss_tail_rl(const float* mse, const float* mae, int cols, const float* perc, const float* kl, int kl_cols, const float* sel, const float* act,
                       const float* mask, int B2, int T, float max_compression_rate, float magnify_negatives_rate, float gamma1,
                       float gamma2, float gamma3, float gamma4, float rl_loss_weight, float* out, float* grads, void* stream);
 

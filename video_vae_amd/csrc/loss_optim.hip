@@ -260,17 +260,20 @@ __global__ __launch_bounds__(256) void loss_tail_plain_kernel(const float* __res
 // grads = [d / d mse_i | d / d mae_i | d / d perc_i | d / d kl_i | d / d sel_it]  (B2 each, then B2 * T).
 // mse / mae arrive as (B2, cols) partial sums (cols >= 1); perc may be NULL (zeros).  One workgroup, fixed summation order.
 __global__ __launch_bounds__(256) void loss_tail_rl_kernel(const float* __restrict__ mse, const float* __restrict__ mae, int cols,
-                                                          const float* __restrict__ perc, const float* __restrict__ kl,
+                                                          const float* __restrict__ perc, const float* __restrict__ kl, int kl_cols,
                                                           const float* __restrict__ sel, const float* __restrict__ act, const float* __restrict__ mask,
                                                           int B2, int T, float inv_max_rate, float magnify, float g1, float g2, float g3, float g4,
                                                           float w, float* __restrict__ out, float* __restrict__ grads)
 {
-    __shared__ float psl[TAIL_MAX_B], ms[TAIL_MAX_B], ma[TAIL_MAX_B], sq[TAIL_MAX_B], dens[TAIL_MAX_B], dis[TAIL_MAX_B], traj[TAIL_MAX_B];
+    __shared__ float psl[TAIL_MAX_B], ms[TAIL_MAX_B], ma[TAIL_MAX_B], sq[TAIL_MAX_B], dens[TAIL_MAX_B], dis[TAIL_MAX_B], traj[TAIL_MAX_B], klr[TAIL_MAX_B];
     const float invB = 1.f / (float)B2;
     for (int i = threadIdx.x; i < B2; i += 256) {
         float a = 0.f, c = 0.f;
         for (int k = 0; k < cols; ++k) { a += mse[(long)i * cols + k]; c += mae[(long)i * cols + k]; }
         ms[i] = a; ma[i] = c;
+        float kb = 0.f;                                        // kl arrives as (B2, kl_cols) partial sums of the per-sample term (one per frame from ops.encoder_head_rl)
+        for (int k = 0; k < kl_cols; ++k) kb += kl[(long)i * kl_cols + k];
+        klr[i] = kb;
         float len = 0.f, ssum = 0.f, tp = 1.f;
         for (int t = 0; t < T; ++t) {
             const float m = mask[i * T + t];
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void loss_tail_rl_kernel(const float* __restri
         const float d = density - inv_max_rate;
         const float mm = d < 0.f ? d * magnify : d;
         sq[i] = mm * mm; dens[i] = density; traj[i] = tp;
-        psl[i] = a + g3 * (perc ? perc[i] : 0.f) + g1 * sq[i] + g2 * kl[i] + g4 * c;
+        psl[i] = a + g3 * (perc ? perc[i] : 0.f) + g1 * sq[i] + g2 * kb + g4 * c;
         grads[i] = invB; grads[B2 + i] = g4 * invB; grads[2 * B2 + i] = g3 * invB; grads[3 * B2 + i] = g2 * invB;
     }
     __syncthreads();
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256) void loss_tail_rl_kernel(const float* __restri
     if (threadIdx.x == 0) {
         float a = 0.f, c = 0.f, pc = 0.f, q = 0.f, k = 0.f, dn = 0.f, tp = 0.f, rl = 0.f, ps = 0.f;
         for (int i = 0; i < B2; ++i) {
-            a += ms[i]; c += ma[i]; pc += perc ? perc[i] : 0.f; q += sq[i]; k += kl[i]; dn += dens[i]; tp += traj[i]; rl += dis[i]; ps += psl[i];
+            a += ms[i]; c += ma[i]; pc += perc ? perc[i] : 0.f; q += sq[i]; k += klr[i]; dn += dens[i]; tp += traj[i]; rl += dis[i]; ps += psl[i];
         }
         out[0] = ps * invB + w * rl * invB;
         out[1] = a * invB; out[2] = pc * invB; out[3] = q * invB; out[4] = k * invB; out[5] = dn * invB; out[6] = tp * invB; out[7] = rl * invB;
@@ -472,15 +475,15 @@ extern "C" int vvae_loss_tail_plain(const float* mse_ps, int mse_cols, const flo
     return 0;
 }
 
-// The rl flavour's loss tail (see loss_tail_rl_kernel).  mse, mae fp32 (B2, cols); perc fp32 [B2] or NULL; kl fp32 [B2]; sel (probabilities), act
+// The rl flavour's loss tail (see loss_tail_rl_kernel).  mse, mae fp32 (B2, cols); perc fp32 [B2] or NULL; kl fp32 (B2, kl_cols) partial sums; sel (probabilities), act
 // (sampled actions), mask fp32 (B2, T) contiguous; B2 even, <= 1024.  out fp32 [9]; grads fp32 [4 B2 + B2 T].
-extern "C" int vvae_loss_tail_rl(const float* mse, const float* mae, int cols, const float* perc, const float* kl, const float* sel, const float* act,
+extern "C" int vvae_loss_tail_rl(const float* mse, const float* mae, int cols, const float* perc, const float* kl, int kl_cols, const float* sel, const float* act,
                                  const float* mask, int B2, int T, float max_compression_rate, float magnify_negatives_rate, float gamma1,
                                  float gamma2, float gamma3, float gamma4, float rl_loss_weight, float* out, float* grads, void* stream)
 {
-    if (!mse || !mae || cols <= 0 || !kl || !sel || !act || !mask || !out || !grads || B2 <= 0 || (B2 & 1) || B2 > TAIL_MAX_B || T <= 0 ||
+    if (!mse || !mae || cols <= 0 || !kl || kl_cols <= 0 || !sel || !act || !mask || !out || !grads || B2 <= 0 || (B2 & 1) || B2 > TAIL_MAX_B || T <= 0 ||
         !(max_compression_rate > 0.f)) return VVAE_ERR_BAD_ARG;
-    hipLaunchKernelGGL(loss_tail_rl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse, mae, cols, perc, kl, sel, act, mask, B2, T,
+    hipLaunchKernelGGL(loss_tail_rl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse, mae, cols, perc, kl, kl_cols, sel, act, mask, B2, T,
                        1.f / max_compression_rate, magnify_negatives_rate, gamma1, gamma2, gamma3, gamma4, rl_loss_weight, out, grads);
     VVAE_LAUNCH_CHECK();
     return 0;

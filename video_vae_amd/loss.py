@@ -103,6 +103,8 @@ def loss_fn(model, video, mask, original_mask, rngs, hparams, perceptual_loss_fn
         per_sample_error, per_sample_MAE = mse_p.sum(1), mae_p.sum(1)
     else:
         per_sample_error, per_sample_MAE = ops.masked_mse_mae(video, reconstruction, output_mask, video_div=2)
+    if kl_loss.dim() == 2:                               # per-frame partial sums (ops.encoder_head_rl)
+        kl_loss = kl_loss.sum(1)
     if perceptual_loss_fn is None:
         perceptual_loss = torch.zeros_like(per_sample_error)
     elif getattr(perceptual_loss_fn, "takes_target_div", False):

@@ -1483,12 +1483,13 @@ class _RlLossTail(torch.autograd.Function):
         sel = selection.reshape(b2, t).to(torch.float32).contiguous()
         act = actions.reshape(b2, t).to(torch.float32).contiguous()
         cols = mse.numel() // b2
+        kl_cols = kl.numel() // b2                       # (2b,) or (2b, k) partial sums of the per-sample term (ops.encoder_head_rl: one per frame)
         pc = perc.to(torch.float32).contiguous() if perc is not None else None
-        check(lib().vvae_loss_tail_rl(_p(mse.contiguous()), _p(mae.contiguous()), cols, _p(pc), _p(kl.to(torch.float32).contiguous()), _p(sel), _p(act),
+        check(lib().vvae_loss_tail_rl(_p(mse.contiguous()), _p(mae.contiguous()), cols, _p(pc), _p(kl.to(torch.float32).contiguous()), kl_cols, _p(sel), _p(act),
                                       _p(mask), b2, t, float(max_rate), float(magnify), float(g1), float(g2), float(g3), float(g4), float(w), _p(out),
                                       _p(grads), _stream()), "vvae_loss_tail_rl")
         ctx.save_for_backward(grads)
-        ctx.meta = (b2, t, mse.shape, mae.shape, perc is not None, selection.shape, selection.dtype)
+        ctx.meta = (b2, t, mse.shape, mae.shape, perc is not None, selection.shape, selection.dtype, kl.shape)
         aux = out[1:]
         ctx.mark_non_differentiable(aux)
         ctx.set_materialize_grads(False)
@@ -1499,7 +1500,7 @@ class _RlLossTail(torch.autograd.Function):
         if go is None:
             return (None,) * 14
         (grads,) = ctx.saved_tensors
-        b2, t, mse_shape, mae_shape, has_perc, sel_shape, sel_dtype = ctx.meta
+        b2, t, mse_shape, mae_shape, has_perc, sel_shape, sel_dtype, kl_shape = ctx.meta
         unit = _UNIT_GRAD.get((go.device.type, go.device.index))
         g = grads if (unit is not None and go.data_ptr() == unit.data_ptr() and go.numel() == 1) else grads * go
         gmse, gmae = g[:b2], g[b2:2 * b2]
@@ -1507,14 +1508,17 @@ class _RlLossTail(torch.autograd.Function):
             gmse = gmse.unsqueeze(1).expand(mse_shape)
         if len(mae_shape) == 2:
             gmae = gmae.unsqueeze(1).expand(mae_shape)
-        return (gmse, gmae, g[2 * b2:3 * b2] if has_perc else None, g[3 * b2:4 * b2], g[4 * b2:].view(sel_shape).to(sel_dtype), None, None,
+        gkl = g[3 * b2:4 * b2]
+        if len(kl_shape) == 2:                           # every partial sum of a sample has the sample's gradient: a stride-0 view, no launch
+            gkl = gkl.unsqueeze(1).expand(kl_shape)
+        return (gmse, gmae, g[2 * b2:3 * b2] if has_perc else None, gkl, g[4 * b2:].view(sel_shape).to(sel_dtype), None, None,
                 None, None, None, None, None, None, None)
 
 
 def rl_loss_tail_ok(mse, mae, kl, selection, actions, mask):
     return (mse.is_cuda and all(x.dtype == torch.float32 for x in (mse, mae, kl, mask)) and mask.dim() == 2 and mask.is_contiguous()
             and mask.shape[0] % 2 == 0 and mask.shape[0] <= 1024 and selection.numel() == mask.numel() and actions.numel() == mask.numel()
-            and mse.dim() in (1, 2) and mse.shape == mae.shape and mse.shape[0] == mask.shape[0] and kl.shape == (mask.shape[0],))
+            and mse.dim() in (1, 2) and mse.shape == mae.shape and mse.shape[0] == mask.shape[0] and kl.dim() in (1, 2) and kl.shape[0] == mask.shape[0])
 
 
 def rl_loss_tail(mse, mae, perc, kl, selection, actions, mask, hparams):

@@ -53,8 +53,10 @@ class VideoVAE(nn.Module):
             u = rngs.draw("bernoulli_u", "uniform", (2 * b, t, 1, 1), mean1.device)
             log_variance, mean, compressed_representation, selection, selection_mask, kl2 = ops.encoder_head_rl(
                 mean1, v, sl1.kernel, sl1.bias, sl2.kernel, sl2.bias, self.fill_token, u, eps, frame_mask(mask, b, t))
-            self._kl = (mean, log_variance, kl2.sum(1))
-            reconstruction = self.decoder(compressed_representation, mask.repeat_interleave(2, dim=0), rngs, train=train)
+            self._kl = (mean, log_variance, kl2)          # (2b, t) per-frame partial sums: the rl loss tail adds a sample's up itself
+            # the decoder gets the UN-doubled mask: its temporal attention broadcasts a mask row over the consecutive sequences that share it
+            # (layers.Attention: div = sequences // mask rows), and the members of a pair are consecutive samples
+            reconstruction = self.decoder(compressed_representation, mask, rngs, train=train)
             return reconstruction, compressed_representation, selection, selection_mask, log_variance, mean
         mean, log_variance, selection = self.encoder(x, mask, rngs, train=train)
         kl = None
