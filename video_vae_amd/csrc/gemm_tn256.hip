@@ -20,7 +20,15 @@
 //   * the bias gradient (column sums of B) rides along as an all-ones row operand in the m-tile-0 workgroups.
 #include "common.hpp"
 
+#ifndef TN_ABL            // timing-only builds (tools/tn_ablation.py): bit 0 no DMA behind the prologue, bit 1 no fragment reads behind the first, bit 2 no MFMAs
+#define TN_ABL 0
+#endif
+
 namespace tn256 {
+
+#ifdef TN_STAMPS
+__device__ unsigned long long g_tn_stamps[256 * 4];
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4v __attribute__((ext_vector_type(4)));
@@ -72,6 +80,7 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
         gb[i] = B + (long)(k_beg + row) * ldb + n0 + chunk * 8;
     }
     auto issue = [&](int t, int stage) {
+        if ((TN_ABL & 1) && t >= S) return;
         unsigned char* sb = smem + stage * STAGE + (2 * wave) * 1024;
         const long ka = (long)t * KS * lda, kb = (long)t * KS * ldb;
         glds16(ga[0] + ka, sb);
@@ -117,13 +126,29 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
     vvae_phase_barrier();
     if (grp) vvae_phase_barrier();
     int st = 0;
+    bf16x8 af[8], bfr[4];
+#ifdef TN_STAMPS
+    if (tid == 0 && blockIdx.x < 256) { g_tn_stamps[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); g_tn_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // Round 4 (tools/tn_ablation.py, profiles/r04_tn_ablation.txt): a stage takes ~1 520 cycles where its two MFMA phases are 1 152; with the DMA
+    // or the fragment reads switched off 1 170-1 200, the DMA alone 909 -- 32 KB per stage at 36 B/clk per CU, the rate the XCD's L2 delivers with
+    // every CU pulling (MI355X_MICROARCH.md "Indexed rows": 66-73 GB/s per CU).  Moving fragment reads into the MFMA phase changed nothing
+    // (1 518-1 537; 1 792 with six of eight moved): the stage is fabric time + what of the MFMA time does not overlap it, not one wave's read phase.
     for (int t = 0; t < nk; ++t) {
         const unsigned char* cur = smem + st * STAGE;
-        bf16x8 af[8], bfr[4];
+        const bool reads = !((TN_ABL & 2) && t > 0);
+        if (reads) {
 #pragma unroll
-        for (int ib = 0; ib < 8; ++ib) af[ib] = frag(cur + aoff[ib]);
+            for (int ib = 0; ib < 8; ++ib) af[ib] = frag(cur + aoff[ib]);
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) bfr[jb] = frag(cur + boff[jb]);
+            for (int jb = 0; jb < 4; ++jb) bfr[jb] = frag(cur + boff[jb]);
+        } else {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) { u32x4 u = __builtin_bit_cast(u32x4, af[ib]); asm volatile("" : "+v"(u)); af[ib] = __builtin_bit_cast(bf16x8, u); }
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) { u32x4 u = __builtin_bit_cast(u32x4, bfr[jb]); asm volatile("" : "+v"(u)); bfr[jb] = __builtin_bit_cast(bf16x8, u); }
+        }
         if (t >= 1 && t - 1 + S < nk) issue(t - 1 + S, st == 0 ? S - 1 : st - 1);
         const int issued = t + S < nk ? t + S : nk;
         wait_tiles(issued - t - 2);
@@ -131,8 +156,11 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
 #pragma unroll
         for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ib], bfr[jb], acc[ib][jb], 0, 0, 0);
-        if (do_bias) {
+            for (int jb = 0; jb < 4; ++jb) {
+                if (!(TN_ABL & 4)) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ib], bfr[jb], acc[ib][jb], 0, 0, 0);
+                else { typedef unsigned u32x4 __attribute__((ext_vector_type(4))); const u32x4 ua = __builtin_bit_cast(u32x4, af[ib]), ub = __builtin_bit_cast(u32x4, bfr[jb]); asm volatile("" :: "v"(ua), "v"(ub)); }
+            }
+        if (do_bias && !(TN_ABL & 4)) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) accb[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[jb], accb[jb], 0, 0, 0);
         }
@@ -140,6 +168,9 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
         st = st + 1 == S ? 0 : st + 1;
     }
     if (!grp) vvae_phase_barrier();
+#ifdef TN_STAMPS
+    if (tid == 0 && blockIdx.x < 256) { g_tn_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); g_tn_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
     // ---- tile -> memory.  acc[ib][jb][j]: m = 128 wm + 16 ib + 4 g + j, n = 64 wn + 16 jb + (lane & 15)
     const int nl = lane & 15;
@@ -254,6 +285,13 @@ int launch_grouped(const GroupArgs& g, int total_tiles, hipStream_t s)
 }
 
 }  // namespace tn256
+
+#ifdef TN_STAMPS
+extern "C" int vvae_gemm_tn_stamps(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tn256::g_tn_stamps), sizeof(unsigned long long) * 256 * 4, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Grouped dense weight gradients: for i < n: C_i (M_i, N_i) fp32 (contiguous, overwritten) = A_i^T B_i, db_i (N_i) fp32 or NULL =
 // column sums of B_i, with A_i (K, M_i) / B_i (K, N_i) bf16 token-major (row pitches lda_i / ldb_i), all sharing K.
