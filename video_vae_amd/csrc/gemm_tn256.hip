@@ -39,6 +39,10 @@ constexpr int OPB = KS * ROW;                  // 16 KB per operand and stage
 constexpr int STAGE = 2 * OPB;
 constexpr int LDS_BYTES = S * STAGE;           // 128 KB
 constexpr int P = 4;                           // DMA pieces per wave and stage (2 A + 2 B)
+#ifndef TN_ALATE
+#define TN_ALATE 3
+#endif
+constexpr int ALATE = TN_ALATE;                // A fragments (of 8) a wave reads in its READ phase; the others BETWEEN the products of its MFMA phase
 
 struct Dims { int M, N, K, lda, ldb, klen, tiles_m, tiles_n; };
 
@@ -130,16 +134,20 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
 #ifdef TN_STAMPS
     if (tid == 0 && blockIdx.x < 256) { g_tn_stamps[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); g_tn_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-    // Round 4 (tools/tn_ablation.py, profiles/r04_tn_ablation.txt): a stage takes ~1 520 cycles where its two MFMA phases are 1 152; with the DMA
-    // or the fragment reads switched off 1 170-1 200, the DMA alone 909 -- 32 KB per stage at 36 B/clk per CU, the rate the XCD's L2 delivers with
-    // every CU pulling (MI355X_MICROARCH.md "Indexed rows": 66-73 GB/s per CU).  Moving fragment reads into the MFMA phase changed nothing
-    // (1 518-1 537; 1 792 with six of eight moved): the stage is fabric time + what of the MFMA time does not overlap it, not one wave's read phase.
+    // Round 4 (tools/tn_ablation.py, profiles/r04_tn_ablation.txt): a stage took ~1 520 cycles where its two MFMA phases are 1 152; with the DMA
+    // OR the fragment reads switched off 1 170-1 200, the DMA alone 909.  A wave's read phase is serial -- 24 transposed reads to issue, then 4 DMA
+    // pieces that each hold the wave until the texture path takes them (~113 cycles a piece with four waves pulling) -- and outlasted the partner's
+    // 36 products.  Reads parked in FRONT of the wave's own products only moved the issue time (1 518-1 537; 1 792 with six of eight A fragments
+    // there).  So: the read phase fetches what the first products need (A fragments 0 .. ALATE-1, the four B fragments); every other A fragment is
+    // requested in the issue slots BETWEEN the products of the MFMA phase (a product holds the pipe 16 cycles and issues in 4), two block rows
+    // ahead of its use.  A stage is then still being read one segment later than before, so its slot is refilled one step later: two stages in
+    // flight instead of three.
     for (int t = 0; t < nk; ++t) {
         const unsigned char* cur = smem + st * STAGE;
         const bool reads = !((TN_ABL & 2) && t > 0);
         if (reads) {
 #pragma unroll
-            for (int ib = 0; ib < 8; ++ib) af[ib] = frag(cur + aoff[ib]);
+            for (int ib = 0; ib < ALATE; ++ib) af[ib] = frag(cur + aoff[ib]);
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) bfr[jb] = frag(cur + boff[jb]);
         } else {
@@ -149,21 +157,40 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ A, const b
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) { u32x4 u = __builtin_bit_cast(u32x4, bfr[jb]); asm volatile("" : "+v"(u)); bfr[jb] = __builtin_bit_cast(bf16x8, u); }
         }
-        if (t >= 1 && t - 1 + S < nk) issue(t - 1 + S, st == 0 ? S - 1 : st - 1);
-        const int issued = t + S < nk ? t + S : nk;
+        // the slot of stage t - 2 is free: its last readers were the other half's products of step t - 2, two segments ago
+        if (t >= 2 && t - 2 + S < nk) issue(t - 2 + S, (st + S - 2) % S);
+        const int issued = t >= 2 ? (t + S - 1 < nk ? t + S - 1 : nk) : npro;
         wait_tiles(issued - t - 2);
         vvae_phase_barrier();
 #pragma unroll
-        for (int ib = 0; ib < 8; ++ib)
+        for (int ib = 0; ib < 8; ++ib) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
                 if (!(TN_ABL & 4)) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ib], bfr[jb], acc[ib][jb], 0, 0, 0);
                 else { typedef unsigned u32x4 __attribute__((ext_vector_type(4))); const u32x4 ua = __builtin_bit_cast(u32x4, af[ib]), ub = __builtin_bit_cast(u32x4, bfr[jb]); asm volatile("" :: "v"(ua), "v"(ub)); }
+                if (jb == 0 && ib + ALATE < 8 && reads) af[ib + ALATE] = frag(cur + aoff[ib + ALATE]);
             }
+        }
+        if (!(TN_ABL & 6)) {
+            // pin the order above: product, the two reads of a late fragment, three products -- per block row that still has a fragment to request
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) {
+                if (ib + ALATE < 8) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+        }
         if (do_bias && !(TN_ABL & 4)) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) accb[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[jb], accb[jb], 0, 0, 0);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every late read has its data (its products waited on it): the stage may be refilled
         vvae_phase_barrier();
         st = st + 1 == S ? 0 : st + 1;
     }
