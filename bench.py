@@ -16,7 +16,8 @@ reference's production model (train/rl_nonadversarial.py:234-236) in the train/m
 batch fixed, gradients all-reduced over RCCL overlapped with backward (video_vae_amd/ddp.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant Conv3d kernel: algorithmic bytes per launch / HIP-event duration measured inside the timed steps;
+  roofline     -- the north-star Conv3d kernel: algorithmic bytes and FLOPs per launch / HIP-event duration measured inside the timed steps, against
+                  the lower of the HBM and the matrix roof for that launch (`frac`; the HBM fraction is always there as `frac_hbm`);
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's math) timed on the host cores on a bounded sample.
 """
 import argparse
@@ -546,20 +547,24 @@ def main():
                 mf = bound == "mfma"
                 return {"bound": bound, "achieved": tfs if mf else gbs, "peak": MFMA_PEAK_TFS if mf else HBM_PEAK_GBS,
                         "unit": "TFLOP/s" if mf else "GB/s", "frac": (tfs / MFMA_PEAK_TFS) if mf else (gbs / HBM_PEAK_GBS),
+                        "frac_hbm": gbs / HBM_PEAK_GBS, "intensity_flop_per_byte": (f_l / b_l) if b_l > 0 else None,
+                        "bound_why": f"algorithmic FLOP/B of the mean launch against the machine balance {MFMA_PEAK_TFS * 1e3 / HBM_PEAK_GBS:.0f} FLOP/B "
+                                     "(2 500 TFLOP/s dense bf16 / 8 TB/s): above it the matrix roof is the lower one",
                         "traffic": measured_traffic(kname)[0], "traffic_note": measured_traffic(kname)[1],
                         "mfma_busy": measured_traffic(kname, "mfma_busy")[0], "kernel": kname, "avg_ms": avg_ms, "launches_timed": top["n"],
                         "launches_per_step": top["n"] / nsteps_timed, "alg_bytes_per_launch": b_l, "alg_flops_per_launch": f_l,
                         "alg_GBps": gbs, "alg_TFLOPps": tfs, "frac_mfma": tfs / MFMA_PEAK_TFS,
                         "kernel_ms_per_step": top["ms"] / nsteps_timed, "timed_in": timed_in}
 
-            # `roofline`: the north-star kernel -- Conv3d forward + input gradient (conv3d_bf16_roll_kernel / conv3d_bf16_deep_kernel, every UNet layer) --
-            # priced against HBM as BASELINE.json's north_star fixes it (V*(Cin+Cout)*e bytes per launch), with its
-            # matrix-core rate beside it.  `roofline_step_dominant`: the hand-written kernel with the largest total time per step
-            # (all its shapes together), bound set by arithmetic intensity against the machine balance (312 FLOP/B).
+            # `roofline`: the north-star kernel -- Conv3d forward + input gradient (conv3d_bf16_roll_kernel / conv3d_bf16_deep_kernel, every UNet layer);
+            # algorithmic bytes per launch as SURVEY 8d fixes them (V*(Cin+Cout)*e).  Its bound is the lower of the two roofs for the mean launch:
+            # 71 GFLOP over 152 MB = 468 FLOP/B, above the machine balance of 312, so the matrix roof (28 us per launch) lies below the HBM roof
+            # (19 us) -- rounds 1-3 printed the HBM fraction under "frac"; it stays beside it as `frac_hbm`.  `roofline_step_dominant`: the
+            # hand-written kernel with the largest total time per step (all its shapes together), bound by the same rule.
             conv_k = next((k for k in fam if k.startswith("conv3d_bf16")), None) or next((k for k in fam if k.startswith("conv3d")), None)
             kname, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
             if conv_k is not None:
-                out["roofline"] = roof(conv_k, fam[conv_k], "hbm")
+                out["roofline"] = roof(conv_k, fam[conv_k])
                 out["roofline_step_dominant"] = roof(kname, top)
             else:
                 out["roofline"] = roof(kname, top)

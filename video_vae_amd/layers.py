@@ -223,6 +223,8 @@ class _SiluLinearBf16(torch.autograd.Function):
             return ops.gemm_nt(a, wo, bias.detach(), res.reshape(-1, wb.shape[1]), ops.EPI_RES).view(res.shape)
         if res is not None:                                          # x_skip + linear2(silu(h)): the add rides in the library product
             return ops.linear_residual(a, wb, bb, res.reshape(-1, wb.shape[1]), wt).view(res.shape)
+        if (OWN & 1) and wo is not None and bias.dtype == torch.float32 and ops.gemm_nt_supported(a, wo):      # the same product Linear itself runs
+            return ops.gemm_nt(a, wo, bias.detach()).view(*h.shape[:-1], wb.shape[1])
         return torch.addmm(bb, a, wb if wt is None else wt.t()).view(*h.shape[:-1], wb.shape[1])
 
     @staticmethod
