@@ -81,6 +81,10 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f
 // diagnostic build only: shader-clock and 100 MHz wall stamps around the main loop of wave 0 of every workgroup (MI355X_MICROARCH.md, DVFS
 // give-back item 6: in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz); the values go to a buffer nothing else reads
 __device__ unsigned long long g_pp_stamps[256 * 4];
+__device__ unsigned long long g_pp_tl[256 * 8];       // 100 MHz wall stamps of one launch's phases per workgroup (tools/pp_timeline.py)
+#define PP_TL(slot, who) do { if (tid == (who) && blockIdx.x < 256) g_pp_tl[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PP_TL(slot, who) do { } while (0)
 #endif
 int g_pp_final_ring = 1;  // vvae_gemm_pp_final_ring: the last epilogue of a launch through the idle operand rings (1) or through the wave's 1.25 KB (0)
 int g_pp_ablate = 0;      // builds with -DPP_ABLATION only (tools/pp_ablation.py): 1 no DMA behind the prologue, 2 no fragment reads, 4 no MFMAs
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: scalar branches, SGPR address parts
+    PP_TL(0, 0);
     const int wm = wave / C::WN, wn = wave % C::WN, grp = wave >> 2, wq = wave & 3;
     constexpr int MB16 = C::MB16, NB16 = C::NB16, PA = C::PA, PB = C::PB;
     constexpr int abl = ABL;
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
     if (grp && G > 1) { stage_next(); wait_vm<PA>(); }       // k-tile 0 has landed; the token pieces of k-tile 1 may still be in flight
     else wait_vm<0>();
     phase_barrier();
+    PP_TL(1, 0);
 #ifdef PP_ABLATION
     if (tid == 0 && blockIdx.x < 256) { g_pp_stamps[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); g_pp_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -323,8 +329,17 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
 #ifdef PP_ABLATION
         if (tid == 0 && blockIdx.x < 256) { g_pp_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); g_pp_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+        PP_TL(2, 0);
         if (d.final_ring) epilogue(tile - (int)gridDim.x, std::true_type{}); else epilogue(tile - (int)gridDim.x, std::false_type{});
-        phase_barrier();                        // waves 4-7 run one segment longer
+        PP_TL(3, 0);
+#ifdef PP_ABLATION
+        wait_vm<0>();
+#endif
+        PP_TL(4, 0);
+        // no barrier behind it: waves 4-7 run one segment longer, and nothing they still do touches what these waves touch -- their last MFMA phase
+        // works from registers, and every wave's final epilogue stays inside its own 16 KB of the (by now quiet) rings.  (Round 4 first had a
+        // closing barrier here and at the end of the last MFMA phase of waves 4-7: their final epilogue waited for this one to finish -- 3 us
+        // of a 27 us launch, tools/pp_timeline.py.)
     } else {
         // ================= waves 4-7: L(g) at segment 2g + 1, C(g) at 2g + 2; they stage the token rows of k-tile g + 2 in L(g) =================
         phase_barrier();                        // segment 0: nothing to do yet
@@ -346,10 +361,16 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             phase_barrier();
             if (kt == 0) zero_acc();
             mfma_phase();
-            phase_barrier();
+            if (g + 1 < G) phase_barrier();     // (the last one would only wait for waves 0-3 to finish their final epilogue)
             if (++kt == nk) { kt = 0; tile += gridDim.x; }
         }
+        PP_TL(5, 256);
         if (d.final_ring) epilogue(tile - (int)gridDim.x, std::true_type{}); else epilogue(tile - (int)gridDim.x, std::false_type{});
+        PP_TL(6, 256);
+#ifdef PP_ABLATION
+        wait_vm<0>();
+#endif
+        PP_TL(7, 256);
     }
 }
 
@@ -434,6 +455,10 @@ extern "C" int vvae_gemm_pp_ablate(int bits)
 extern "C" int vvae_gemm_pp_stamps(unsigned long long* host_out)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pp::g_pp_stamps), sizeof(unsigned long long) * 256 * 4, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int vvae_gemm_pp_timeline(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pp::g_pp_tl), sizeof(unsigned long long) * 256 * 8, 0, hipMemcpyDeviceToHost);
 }
 #endif
 
