@@ -1355,6 +1355,10 @@ int deep_gn_blocks_any(BfDims d, int kh, int groups)
     return 0;
 }
 
+#ifndef WG_ABL            // timing-only builds (tools/r04_wg_abl.sh): bit 0 no MFMAs, bit 1 no fragment reads, bit 2 no staging behind the first planes
+#define WG_ABL 0
+#endif
+
 template <class C, bool TWO>
 __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel(const bf16_t* __restrict__ x, int ldx,
                                                                                  const bf16_t* __restrict__ dy, int lddy,
@@ -1391,6 +1395,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
     const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
+    [[maybe_unused]] bf16x8 fk = ones;
+    if (WG_ABL & 2) { typedef unsigned u32x4b __attribute__((ext_vector_type(4))); u32x4b u = __builtin_bit_cast(u32x4b, ones); asm volatile("" : "+v"(u)); fk = __builtin_bit_cast(bf16x8, u); }
     PlaneStager<C::NTHREADS, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx;
     PlaneStager<C::NTHREADS, TH, TW, COB / 8, PY> sy;
     PlaneStager<C::NTHREADS, HR, WR, CIB / 8, PX, C::SWX, C::WRP> sx2;      // PD == 2 only
@@ -1404,8 +1410,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
         xsrc = sp.x2 + ci0 - sp.xsplit;
         ldx = sp.ldx2;
     }
-#define FX(S, T_) do { if (TWO) (S).fetch(xsrc, ldx, n, (T_), hx, wx, d.T, d.H, d.W, tid); else (S).fetch(rx, ldx, ci0, n, (T_), hx, wx, d.T, d.H, d.W, tid); } while (0)
-#define FY(S, T_) (S).fetch(rdy, lddy, co0, n, (T_), h0, w0, d.T, d.H, d.W, tid)
+#define FX(S, T_) do { if ((WG_ABL & 4) && (T_) > 1) break; if (TWO) (S).fetch(xsrc, ldx, n, (T_), hx, wx, d.T, d.H, d.W, tid); else (S).fetch(rx, ldx, ci0, n, (T_), hx, wx, d.T, d.H, d.W, tid); } while (0)
+#define FY(S, T_) do { if ((WG_ABL & 4) && (T_) > 0) break; (S).fetch(rdy, lddy, co0, n, (T_), h0, w0, d.T, d.H, d.W, tid); } while (0)
+#define SX(S, P_, T_) do { if (!((WG_ABL & 4) && (T_) > 1)) (S).store((P_), tid); } while (0)
+#define SY(S, P_, T_) do { if (!((WG_ABL & 4) && (T_) > 0)) (S).store((P_), tid); } while (0)
 
     // A workgroup walks whole time-columns: for a fixed (n, h-tile, w-tile) it marches t = 0..T-1, so every X plane is
     // fetched from memory once (not KT times) and lives in the LDS ring for the three steps that use it.
@@ -1419,9 +1427,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
         const int hx = h0 - KH / 2, wx = w0 - KW / 2;
         __syncthreads();                                          // previous column is done with the ring
         FX(sx, -1);   // plane -1 = zeros
-        sx.store(ring + 3 * C::PLANE, tid);
+        SX(sx, ring + 3 * C::PLANE, -1);
         FX(sx, 0);
-        sx.store(ring, tid);
+        SX(sx, ring, 0);
         FX(sx, 1);
         FY(sy, 0);
         if (C::PD == 2 && d.T > 1) {                              // second register set: plane 2 and dY tile 1 are on their way too
@@ -1433,23 +1441,27 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
             // halo rows r0 + a0 + rr, rr = 0 .. THR+AGS-2, meet kernel rows a0 + aa at output rows r0 + h, h = rr - aa
             const unsigned char* xplane = ring + ((tt + dt - 1) & 3) * C::PLANE + (r0 + a0) * (C::WRP * PX) + 8 * pp;
             bf16x8 bfr[AGS];                                      // rolling window of dY fragments: row h lives in slot h % AGS
+            typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+            auto fake = [&](int) { return fk; };                  // timing builds without fragment reads: one register quad made up at kernel entry
 #pragma unroll
             for (int rr = 0; rr < C::THR + AGS - 1; ++rr) {
                 if (rr < C::THR) {
-                    bfr[rr % AGS] = tr_frag(ys + rr * TW * PY, 16 * PY);
-                    if (bias_wave) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[rr % AGS], accb, 0, 0, 0);
+                    bfr[rr % AGS] = (WG_ABL & 2) ? fake(rr) : tr_frag(ys + rr * TW * PY, 16 * PY);
+                    if (bias_wave && !(WG_ABL & 1)) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[rr % AGS], accb, 0, 0, 0);
                 }
                 if (KH % AGS != 0 && a0 + rr >= C::THR + KH - 1) continue;   // last dy group is short: its tail rows are not needed
 #pragma unroll
                 for (int b = 0; b < KW; ++b) {
                     const int lin = rr * C::WRP + b + lvox;       // SWX: 32-byte half ^= (voxel >> 2) & 1, same for voxel + 16
                     const int sw = C::SWX ? ((lin >> 2) & 1) << 5 : 0;
-                    const bf16x8 afr = tr_frag(xplane + lin * PX + ((wi * 32) ^ sw), 16 * PX);
+                    const bf16x8 afr = (WG_ABL & 2) ? fake(rr * 8 + b) : tr_frag(xplane + lin * PX + ((wi * 32) ^ sw), 16 * PX);
 #pragma unroll
                     for (int aa = 0; aa < AGS; ++aa) {
                         const int h = rr - aa;
-                        if (h >= 0 && h < C::THR && (KH % AGS == 0 || a0 + aa < KH))
-                            acc[aa][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[h % AGS], acc[aa][b], 0, 0, 0);
+                        if (h >= 0 && h < C::THR && (KH % AGS == 0 || a0 + aa < KH)) {
+                            if (!(WG_ABL & 1)) acc[aa][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[h % AGS], acc[aa][b], 0, 0, 0);
+                            else { const u32x4a ua = __builtin_bit_cast(u32x4a, afr), ub = __builtin_bit_cast(u32x4a, bfr[h % AGS]); asm volatile("" :: "v"(ua), "v"(ub)); }
+                        }
                     }
                 }
             }
@@ -1457,8 +1469,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
         if (C::PD == 2) {
             // two steps' operands in flight: a step of the 16-channel layers is ~0.5 us of matrix work against 1-2 us of loaded-HBM latency
             for (int tt = 0; tt < d.T; tt += 2) {
-                sx.store(ring + ((tt + 1) & 3) * C::PLANE, tid);
-                sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
+                SX(sx, ring + ((tt + 1) & 3) * C::PLANE, tt + 1);
+                SY(sy, ybuf + (tt & 1) * C::YBYTES, tt);
                 __syncthreads();
                 if (tt + 2 < d.T) {
                     FX(sx, tt + 3);
@@ -1466,8 +1478,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
                 }
                 step(tt);
                 if (tt + 1 >= d.T) break;
-                sx2.store(ring + ((tt + 2) & 3) * C::PLANE, tid);
-                sy2.store(ybuf + ((tt + 1) & 1) * C::YBYTES, tid);
+                SX(sx2, ring + ((tt + 2) & 3) * C::PLANE, tt + 2);
+                SY(sy2, ybuf + ((tt + 1) & 1) * C::YBYTES, tt + 1);
                 __syncthreads();
                 if (tt + 3 < d.T) {
                     FX(sx2, tt + 4);
@@ -1477,8 +1489,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
             }
         } else {
             for (int tt = 0; tt < d.T; ++tt) {
-                sx.store(ring + ((tt + 1) & 3) * C::PLANE, tid);      // plane tt+1 (zeros past the end)
-                sy.store(ybuf + (tt & 1) * C::YBYTES, tid);
+                SX(sx, ring + ((tt + 1) & 3) * C::PLANE, tt + 1);     // plane tt+1 (zeros past the end)
+                SY(sy, ybuf + (tt & 1) * C::YBYTES, tt);
                 __syncthreads();
                 if (tt + 1 < d.T) {                                   // next step's operands fly while this step computes
                     FX(sx, tt + 2);
@@ -1490,6 +1502,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MINW) void conv3d_wgrad_bf16_kernel
     }
 #undef FX
 #undef FY
+#undef SX
+#undef SY
     // ---- write this workgroup's partial sums: slab[block][dt][dy][dx][ci_local][co_local] (+ COB dbias partials) ----
     float* out = slab + (((long)bx * C::RG + rgp) * nsub + by) * C::SLAB_FLOATS;
     const int col = lane & 15, rg = lane >> 4;

@@ -73,6 +73,16 @@ __device__ __forceinline__ void phase_barrier()
 }
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }      // lgkmcnt(0), vmcnt / expcnt left alone
 
+#ifndef PP_NT
+#define PP_NT 0
+#endif
+__device__ __forceinline__ void st16(bf16_t* p, const uint4 v)       // one lane's 16 bytes of an output row
+{
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    const u32x4v w = {v.x, v.y, v.z, v.w};
+    if (PP_NT) __builtin_nontemporal_store(w, reinterpret_cast<u32x4v*>(p));
+    else *reinterpret_cast<u32x4v*>(p) = w;
+}
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
@@ -252,14 +262,14 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             const long gm = row0 + j * 16;
             const int gn = col0 + ip * 32;
             if (EPI == EPI_NONE) {
-                *reinterpret_cast<uint4*>(Cout + gm * d.ldc + gn) = v;
+                st16(Cout + gm * d.ldc + gn, v);
             } else {
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                 float x[8], y[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
                 if (EPI == EPI_SILU) {
-                    *reinterpret_cast<uint4*>(C2 + gm * d.ldc2 + gn) = v;             // the rounded pre-activation, kept for backward
+                    st16(C2 + gm * d.ldc2 + gn, v);                                    // the rounded pre-activation, kept for backward
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = silu_f(x[e]);
                 } else {
@@ -271,7 +281,9 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = EPI == EPI_RES ? x[e] + r[e] : x[e] * dsilu_f(r[e]);
                 }
-                VecIO<bf16_t, 8>::store(Cout + gm * d.ldc + gn, y);
+                uint4 o;
+                o.x = pack2(y[0], y[1]); o.y = pack2(y[2], y[3]); o.z = pack2(y[4], y[5]); o.w = pack2(y[6], y[7]);
+                st16(Cout + gm * d.ldc + gn, o);
             }
         };
         if (FINAL) {
