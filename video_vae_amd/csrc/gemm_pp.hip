@@ -328,7 +328,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             const bool ep = kt == 0 && g > 0;                // the previous tile's accumulators are still in the registers
             if (!has_res) read_frags();
             if (g + 1 < G) stage_next();                     // ahead of the epilogue's stores: see the wait below
-            if (ep) epilogue(tile - (int)gridDim.x, std::false_type{});
+            if (ep && !(abl & 8)) epilogue(tile - (int)gridDim.x, std::false_type{});
             if (has_res) read_frags();                       // tails with a second operand: its prefetch registers and the fragments are not live together
             wait_lgkm0();                                    // fragments in registers: the slots may be overwritten behind the barrier
             phase_barrier();
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(C::NT, 1) void gemm_pp_kernel(const bf16_t* __restr
             const bool st = g + 2 < G;
             if (!has_res) read_frags();
             if (st) stage_next();
-            if (ep) epilogue(tile - (int)gridDim.x, std::false_type{});
+            if (ep && !(abl & 8)) epilogue(tile - (int)gridDim.x, std::false_type{});
             if (has_res) read_frags();
             // tokens of k-tile g + 1 (staged in L(g-1), or the prologue) have landed; younger: an epilogue's stores of L(g-1) or of this phase
             // (never both: a tile has at least two k-tiles) and the pieces just staged
@@ -412,6 +412,7 @@ int launch_epi(const void* A, const void* B, void* Cout, const float* bias, cons
         case 5: k = gemm_pp_kernel<C, EPI_NONE, 5>; break;
         case 6: k = gemm_pp_kernel<C, EPI_NONE, 6>; break;
         case 7: k = gemm_pp_kernel<C, EPI_NONE, 7>; break;
+        case 8: k = gemm_pp_kernel<C, EPI_NONE, 8>; break;          // no epilogue for tiles in mid-launch (their output is never written): tools/pp_mid_epilogue.py
         default: break;
         }
     }
@@ -459,7 +460,7 @@ extern "C" int vvae_gemm_pp_final_ring(int on)
 // in the main loop of the plain product (wrong results).  The shipped library ignores it.
 extern "C" int vvae_gemm_pp_ablate(int bits)
 {
-    pp::g_pp_ablate = bits & 7;
+    pp::g_pp_ablate = bits & 15;
     return 0;
 }
 
