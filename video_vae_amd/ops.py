@@ -5,6 +5,8 @@ runs a hand-written HIP kernel from libvvae_hip.so on the current stream.
 Tensors must live on a GPU -- there is no CPU path.
 """
 import ctypes
+import os
+import sys
 
 import torch
 import torch.nn.functional as F
@@ -2069,6 +2071,8 @@ def flush_wgrad(items, optimizer, tiles=None, k=None):
     if tiles is None:
         tiles = sum((x2.shape[1] // 256) * (dy2.shape[1] // 256) for x2, dy2, _, _ in items)
         k = items[0][0].shape[0]
+    if os.environ.get("VVAE_WGRAD_DEBUG"):
+        print(f"[vvae] dense dW flush: {len(items)} products, {tiles} tiles of 256 x 256, K {k}: " + ("grouped" if tiles >= GROUP_MIN_TILES else "per product"), file=sys.stderr)
     if tiles >= GROUP_MIN_TILES:
         _gemm_tn_grouped(items, k)
     else:                                                    # too few tiles to fill the chip without splitting K
